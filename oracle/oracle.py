@@ -1,0 +1,164 @@
+"""ORACLE — TEST INFRASTRUCTURE ONLY.
+
+ctypes front-end of oracle/liboracle.so, the CPU restatement of RecGraph's DP hot path
+(see oracle/orc_common.hpp for what it follows and how it is pinned).  Only tests/,
+``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import this module;
+the product (``recgraph_amd``) never does.
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "liboracle.so")
+
+M0_SIMD, M0_SCALAR, M2, M4, M4_ABS, M8, M8_PRUNED, M8_ABS = 0, 10, 2, 4, 14, 8, 18, 28
+
+
+def build(force=False):
+    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".cpp", ".hpp"))]
+    if force or not os.path.exists(_LIB) or any(os.path.getmtime(s) > os.path.getmtime(_LIB) for s in srcs):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
+    return _LIB
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        l = C.CDLL(_LIB)
+        l.orc_graph_new.restype = C.c_void_p
+        l.orc_graph_new.argtypes = [C.c_char_p, C.c_int]
+        l.orc_lnz_literal.restype = C.c_void_p
+        l.orc_lnz_literal.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
+        l.orc_graph_free.argtypes = [C.c_void_p]
+        l.orc_graph_error.restype = C.c_char_p
+        l.orc_graph_error.argtypes = [C.c_void_p]
+        l.orc_graph_dump.restype = C.c_longlong
+        l.orc_graph_dump.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_longlong]
+        l.orc_align.restype = C.c_longlong
+        l.orc_align.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_char_p, C.c_longlong, C.POINTER(C.c_int),
+                                C.c_int, C.c_int, C.c_longlong, C.c_int, C.c_float, C.c_float, C.c_char_p,
+                                C.c_longlong, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_ulonglong)]
+        l.orc_bench.restype = C.c_double
+        l.orc_bench.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.POINTER(C.c_longlong), C.c_longlong,
+                                C.POINTER(C.c_int), C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_float,
+                                C.c_float, C.c_int, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]
+        l.orc_scores_match_mis.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]
+        l.orc_scores_from_mtx.argtypes = [C.c_char_p, C.POINTER(C.c_int)]
+        l.orc_missing_value.restype = C.c_int
+        l.orc_f32_cell_roundtrip_limit.restype = C.c_longlong
+        l.orc_f32_cell_roundtrip_limit.argtypes = [C.c_longlong]
+        _lib = l
+    return _lib
+
+
+ALPHABET = "ACGTN-"
+
+
+def scores_match_mis(m=2, x=-4, f32_variant=False):
+    out = (C.c_int * 36)()
+    lib().orc_scores_match_mis(m, x, 1 if f32_variant else 0, out)
+    return list(out)
+
+
+def scores_from_mtx(text):
+    out = (C.c_int * 36)()
+    lib().orc_scores_from_mtx(text.encode(), out)
+    return list(out)
+
+
+def scores_from_dict(d):
+    """{(a,b): v} -> 36 ints, absent keys = MISSING (the reference would panic on lookup)."""
+    miss = lib().orc_missing_value()
+    t = [miss] * 36
+    for (a, b), v in d.items():
+        t[ALPHABET.index(a) * 6 + ALPHABET.index(b)] = int(v)
+    return t
+
+
+class Graph:
+    def __init__(self, handle):
+        self.h = handle
+
+    @classmethod
+    def from_gfa_text(cls, text, want_path=True):
+        h = lib().orc_graph_new(text.encode(), 1 if want_path else 0)
+        err = lib().orc_graph_error(h).decode()
+        if err:
+            lib().orc_graph_free(h)
+            raise ValueError(err)
+        return cls(h)
+
+    @classmethod
+    def from_gfa(cls, path, want_path=True):
+        with open(path) as f:
+            return cls.from_gfa_text(f.read(), want_path)
+
+    @classmethod
+    def lnz_literal(cls, lnz, preds):
+        """LnzGraph literal as in the reference's unit tests: preds = {row: [pred rows]}; nwp = rows with preds."""
+        L = len(lnz)
+        nwp = bytes(1 if i in preds else 0 for i in range(L))
+        off = [0]
+        rows = []
+        for i in range(L):
+            rows += preds.get(i, [])
+            off.append(len(rows))
+        offa = (C.c_longlong * len(off))(*off)
+        rowa = (C.c_longlong * max(1, len(rows)))(*rows)
+        return cls(lib().orc_lnz_literal(lnz.encode(), nwp, offa, rowa))
+
+    def __del__(self):
+        try:
+            lib().orc_graph_free(self.h)
+        except Exception:
+            pass
+
+    def dump(self, which):
+        n = lib().orc_graph_dump(self.h, which, None, 0)
+        buf = C.create_string_buffer(n + 1)
+        lib().orc_graph_dump(self.h, which, buf, n + 1)
+        return buf.value.decode()
+
+    def align(self, mode, read, name="read", idx=1, scores=None, o=-4, e=-2, bta=None, b=1.0, f=0.01, R=4, r=0.1,
+              B=1.0):
+        """Returns (stdout text, score, would_panic, cells)."""
+        import numpy as np
+        if scores is None:
+            scores = scores_match_mis(2, -4)
+        if bta is None:
+            # main.rs:57: (b + f * seq.len() as f32) as usize, seq.len() = n + 1, all in f32
+            bta = int(np.float32(b) + np.float32(f) * np.float32(len(read) + 1))
+        sc = (C.c_int * 36)(*scores)
+        score = C.c_int(0)
+        flags = C.c_int(0)
+        cells = C.c_ulonglong(0)
+        cap = 1 << 16
+        while True:
+            buf = C.create_string_buffer(cap)
+            n = lib().orc_align(self.h, mode, read.encode(), name.encode(), idx, sc, o, e, bta, R, r, B, buf, cap,
+                                C.byref(score), C.byref(flags), C.byref(cells))
+            if n + 1 <= cap:
+                break
+            cap = n + 16
+        return buf.value.decode(), score.value, bool(flags.value), cells.value
+
+    def bench(self, mode, reads, scores=None, o=-4, e=-2, b=1.0, f=0.01, R=4, r=0.1, B=1.0, nthreads=1):
+        """Time `reads` (list of str) on `nthreads` host threads.  Returns (seconds, cells, checksum)."""
+        if scores is None:
+            scores = scores_match_mis(2, -4)
+        blob = "".join(reads).encode()
+        offs = [0]
+        for rd in reads:
+            offs.append(offs[-1] + len(rd))
+        offa = (C.c_longlong * len(offs))(*offs)
+        sc = (C.c_int * 36)(*scores)
+        cells = C.c_ulonglong(0)
+        chk = C.c_ulonglong(0)
+        secs = lib().orc_bench(self.h, mode, blob, offa, len(reads), sc, o, e, b, f, R, r, B, nthreads,
+                               C.byref(cells), C.byref(chk))
+        return secs, cells.value, chk.value
