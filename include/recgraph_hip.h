@@ -1,0 +1,141 @@
+/*
+ * recgraph_hip.h — C ABI of the MI355X-native RecGraph DP hot path.
+ *
+ * Drop-in boundary for the reference's per-read alignment calls.  Every entry point names the
+ * reference interface it replaces (file:line relative to the RecGraph source tree).  Plain
+ * pointers and sizes only; no C++/torch types cross this boundary.  All functions return
+ * RG_OK (0) or a negative rg_status; none of them aborts (the reference panics instead).
+ *
+ * Thread-safety: a graph handle is immutable after creation and may be shared; a batch handle
+ * must be used by one thread at a time.
+ */
+#ifndef RECGRAPH_HIP_H
+#define RECGRAPH_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum rg_status {
+    RG_OK = 0,
+    RG_ERR_ARG = -1,         /* bad argument (null pointer, unsupported mode, empty read ...) */
+    RG_ERR_GFA = -2,         /* GFA text not usable (non-numeric names, '-' orientations ...)  */
+    RG_ERR_NO_DEVICE = -3,   /* no HIP device / HIP runtime error: the product never falls back to CPU */
+    RG_ERR_GRAPH = -4,       /* graph violates a precondition of the reference (not topological, >64 paths ...) */
+    RG_ERR_CAPACITY = -5,    /* internal work buffer exhausted even after regrowth */
+    RG_ERR_HIP = -6
+} rg_status;
+
+/* per-read status bits (rg_result_status) */
+#define RG_READ_OK 0u
+#define RG_READ_BAND_WARNING 1u     /* reference prints "Band length probably too short, ..." (global_abpoa.rs:406-409, gap_global_abpoa.rs:225-227) */
+#define RG_READ_BAND_NOT_ENOUGH 2u  /* reference prints "band not enough for correct output" and an empty GAF (gaf_output.rs:861-864) */
+#define RG_READ_WOULD_PANIC 4u      /* reference would panic on this read (index out of range, set_path_cell('u') ...) */
+#define RG_READ_BAD_BASE 8u         /* read contains a character outside ACGTN (reference: HashMap unwrap panic) */
+
+/* Alignment modes: the `-m` values of the reference CLI (args_parser.rs:31-38) on the hot path. */
+#define RG_MODE_GLOBAL_POA 0        /* global_abpoa::exec_simd          src/global_abpoa.rs:10      */
+#define RG_MODE_GLOBAL_POA_SCALAR 10/* global_abpoa::exec (no-AVX2 path) src/global_abpoa.rs:260     */
+#define RG_MODE_GAP_POA 2           /* gap_global_abpoa::exec           src/gap_global_abpoa.rs:11  */
+#define RG_MODE_PATHWISE 4          /* pathwise_alignment::exec         src/pathwise_alignment.rs:5 */
+#define RG_MODE_RECOMBINATION 8     /* pathwise_alignment_recombination::exec (aln_mode 8) src/pathwise_alignment_recombination.rs:23 */
+
+/*
+ * Scoring and banding parameters.  Replaces the HashMap<(char,char),i32|f32> score matrix arguments
+ * (score_matrix.rs:35-51; api.rs:131,153) and the scalar arguments of the exec functions.
+ * scores[a*6+b] is the entry for the key (ALPHA[a], ALPHA[b]) with ALPHA = "ACGTN-"; RG_SCORE_MISSING
+ * marks a key the map does not hold.
+ */
+#define RG_SCORE_MISSING (-536870912)
+typedef struct rg_params {
+    int32_t mode;          /* RG_MODE_*                                                       */
+    int32_t scores[36];
+    int32_t gap_open;      /* o  (<= 0), gap_global_abpoa.rs:16                                */
+    int32_t gap_ext;       /* e  (<= 0), gap_global_abpoa.rs:17                                */
+    float band_b;          /* -b, main.rs:57: bta = (b + f * (n+1)) as usize                   */
+    float band_f;          /* -f                                                              */
+    int64_t bta_override;  /* >= 0: use this bases_to_add for every read (api.rs:22 callers)   */
+    int32_t base_rec_cost; /* -R, pathwise_alignment_recombination.rs:29                       */
+    float multi_rec_cost;  /* -r                                                              */
+    float rec_band_width;  /* -B                                                              */
+} rg_params;
+
+/* Fill *p with the CLI defaults (args_parser.rs:3-147: M=2 X=4 O=4 E=2 R=4 r=0.1 B=1 b=1 f=0.01). */
+void rg_params_default(rg_params* p, int32_t mode);
+/* score_matrix::create_score_matrix_match_mis (score_matrix.rs:35-51); f32_variant=1 gives
+ * create_score_matrix_match_mis_f32 (:52-66, gap = mismatch). */
+void rg_scores_match_mis(int32_t match, int32_t mismatch, int32_t f32_variant, int32_t* scores36);
+
+typedef struct rg_graph rg_graph;
+typedef struct rg_batch rg_batch;
+
+/*
+ * Graph ingestion.  Replaces graph::read_graph / create_graph_struct (graph.rs:11-102),
+ * pathwise_graph::read_graph_w_path / create_path_graph / create_reverse_path_graph /
+ * nodes_displacement_matrix (pathwise_graph.rs:127-305), utils::set_r_values (utils.rs:103-126) and
+ * utils::create_handle_pos_in_lnz (utils.rs:144-165).  The flattened graph is uploaded to HBM once.
+ */
+int32_t rg_graph_from_gfa(const char* gfa_text, int64_t len, rg_graph** out);
+/* Same, from an already flattened LnzGraph (graph.rs:23-27): pred rows of row i are
+ * pred_rows[pred_off[i] .. pred_off[i+1]) in pred_hash order, nwp[i] = pred_off[i+1] > pred_off[i],
+ * node_id[i] = segment id of row i (0 for row 0 and the final 'F' row). */
+int32_t rg_graph_create_lnz(const char* lnz, int64_t L, const int64_t* pred_off, const int64_t* pred_rows,
+                            const uint64_t* node_id, rg_graph** out);
+/* Same, from an already flattened PathGraph (pathwise_graph.rs:10-18): row_mask[i] bit k = paths_nodes[i][k];
+ * edges of row i are (edge_pred[e], edge_mask[e]) for e in [edge_off[i], edge_off[i+1]) (PredHash,
+ * pathwise_graph.rs:75-125; listed for segment-start rows and the 'F' row). */
+int32_t rg_graph_create_path(const char* lnz, int64_t L, int32_t P, const uint64_t* row_mask,
+                             const int64_t* edge_off, const int64_t* edge_pred, const uint64_t* edge_mask,
+                             const uint64_t* node_id, rg_graph** out);
+void rg_graph_destroy(rg_graph* g);
+int64_t rg_graph_rows(const rg_graph* g);   /* lnz.len() of the LnzGraph (or PathGraph if only that exists) */
+int32_t rg_graph_paths(const rg_graph* g);  /* paths_number, 0 without P lines */
+/* text dumps of the flattened arrays (same `which` codes as the test oracle) for construction tests */
+int64_t rg_graph_dump(const rg_graph* g, int32_t which, char* buf, int64_t cap);
+
+/*
+ * Batch alignment.  One call replaces the reference's per-read loop (main.rs:56-105, 174-213,
+ * 257-261, 297-312): reads are bases without the leading '$' (sequences.rs:5-45 is applied inside:
+ * upper-casing and '-' -> 'N'); read i is reads[read_off[i] .. read_off[i+1]).
+ *
+ *   rg_batch_create   uploads the reads and sizes every work buffer in HBM
+ *   rg_batch_run      runs the DP + traceback kernels on the device (inputs resident; this is the
+ *                     region bench.py times); may be called repeatedly
+ *   rg_batch_fetch    copies the alignment records back (one D2H of packed records)
+ *   rg_result_*       per-read accessors; rg_result_gaf formats exactly what the reference prints on
+ *                     stdout for that read (warning lines + GAFStruct::to_string, gaf_output.rs:70-94)
+ */
+int32_t rg_batch_create(const rg_graph* g, const rg_params* p, const char* reads, const int64_t* read_off,
+                        int64_t nreads, rg_batch** out);
+int32_t rg_batch_run(rg_batch* b);
+int32_t rg_batch_fetch(rg_batch* b);
+void rg_batch_destroy(rg_batch* b);
+
+int64_t rg_batch_size(const rg_batch* b);
+uint32_t rg_result_status(const rg_batch* b, int64_t i);
+int32_t rg_result_score(const rg_batch* b, int64_t i);   /* exec(..).0 of the reference (POA modes); best score otherwise */
+/* seq_index is seq_name.1 of the reference (0 = score only: empty text). Returns bytes needed (excl. NUL). */
+int64_t rg_result_gaf(const rg_batch* b, int64_t i, const char* name, int64_t seq_index, char* buf, int64_t cap);
+
+/* Measurement hooks for bench.py: DP cell-updates of the last run (SURVEY §8d unit of work) and
+ * per-kernel device time measured with HIP events on the stream the kernels were launched on. */
+uint64_t rg_batch_cell_updates(const rg_batch* b);
+int32_t rg_batch_kernel_count(const rg_batch* b);
+const char* rg_batch_kernel_name(const rg_batch* b, int32_t k);
+double rg_batch_kernel_ms(const rg_batch* b, int32_t k);       /* summed over launches of the last run */
+int64_t rg_batch_kernel_launches(const rg_batch* b, int32_t k);
+
+/* one-shot convenience: create + run + fetch */
+int32_t rg_align_batch(const rg_graph* g, const rg_params* p, const char* reads, const int64_t* read_off,
+                       int64_t nreads, rg_batch** out);
+
+const char* rg_last_error(void);
+int32_t rg_device_count(void);
+int32_t rg_set_device(int32_t dev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

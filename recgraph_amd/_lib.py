@@ -1,0 +1,97 @@
+"""ctypes binding of librecgraph_hip.so (the C ABI declared in include/recgraph_hip.h)."""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "librecgraph_hip.so")
+
+
+class RecGraphError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"recgraph_hip error {code}: {msg}")
+        self.code = code
+
+
+class Params(C.Structure):
+    _fields_ = [("mode", C.c_int32), ("scores", C.c_int32 * 36), ("gap_open", C.c_int32), ("gap_ext", C.c_int32),
+                ("band_b", C.c_float), ("band_f", C.c_float), ("bta_override", C.c_int64),
+                ("base_rec_cost", C.c_int32), ("multi_rec_cost", C.c_float), ("rec_band_width", C.c_float)]
+
+
+def library_path():
+    return _SO
+
+
+def build_library(force=False):
+    """Compile every HIP source for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    args = ["make", "-C", os.path.join(_HERE, "csrc"), "-j8"]
+    if force:
+        args.append("-B")
+    subprocess.check_call(args, stdout=subprocess.DEVNULL)
+    return _SO
+
+
+# every symbol include/recgraph_hip.h declares
+SYMBOLS = ["rg_params_default", "rg_scores_match_mis", "rg_graph_from_gfa", "rg_graph_create_lnz",
+           "rg_graph_create_path", "rg_graph_destroy", "rg_graph_rows", "rg_graph_paths", "rg_graph_dump",
+           "rg_batch_create", "rg_batch_run", "rg_batch_fetch", "rg_batch_destroy", "rg_batch_size",
+           "rg_result_status", "rg_result_score", "rg_result_gaf", "rg_batch_cell_updates", "rg_batch_kernel_count",
+           "rg_batch_kernel_name", "rg_batch_kernel_ms", "rg_batch_kernel_launches", "rg_align_batch", "rg_last_error",
+           "rg_device_count", "rg_set_device"]
+
+_lib = None
+
+
+def load():
+    """Load the HIP library; fails loudly when it has not been built (there is no CPU fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_SO):
+        raise RecGraphError(-3, f"{_SO} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                                "(the product has no CPU fallback)")
+    l = C.CDLL(_SO)
+    vp, i32, i64, u64 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64
+    P = C.POINTER
+    l.rg_params_default.argtypes = [P(Params), i32]
+    l.rg_scores_match_mis.argtypes = [i32, i32, i32, P(i32)]
+    l.rg_graph_from_gfa.argtypes = [C.c_char_p, i64, P(vp)]
+    l.rg_graph_create_lnz.argtypes = [C.c_char_p, i64, P(i64), P(i64), P(u64), P(vp)]
+    l.rg_graph_create_path.argtypes = [C.c_char_p, i64, i32, P(u64), P(i64), P(i64), P(u64), P(u64), P(vp)]
+    l.rg_graph_destroy.argtypes = [vp]
+    l.rg_graph_rows.argtypes = [vp]
+    l.rg_graph_rows.restype = i64
+    l.rg_graph_paths.argtypes = [vp]
+    l.rg_graph_dump.argtypes = [vp, i32, C.c_char_p, i64]
+    l.rg_graph_dump.restype = i64
+    l.rg_batch_create.argtypes = [vp, P(Params), C.c_char_p, P(i64), i64, P(vp)]
+    l.rg_align_batch.argtypes = [vp, P(Params), C.c_char_p, P(i64), i64, P(vp)]
+    for f in ("rg_batch_run", "rg_batch_fetch"):
+        getattr(l, f).argtypes = [vp]
+    l.rg_batch_destroy.argtypes = [vp]
+    l.rg_batch_size.argtypes = [vp]
+    l.rg_batch_size.restype = i64
+    l.rg_result_status.argtypes = [vp, i64]
+    l.rg_result_status.restype = C.c_uint32
+    l.rg_result_score.argtypes = [vp, i64]
+    l.rg_result_gaf.argtypes = [vp, i64, C.c_char_p, i64, C.c_char_p, i64]
+    l.rg_result_gaf.restype = i64
+    l.rg_batch_cell_updates.argtypes = [vp]
+    l.rg_batch_cell_updates.restype = u64
+    l.rg_batch_kernel_count.argtypes = [vp]
+    l.rg_batch_kernel_name.argtypes = [vp, i32]
+    l.rg_batch_kernel_name.restype = C.c_char_p
+    l.rg_batch_kernel_ms.argtypes = [vp, i32]
+    l.rg_batch_kernel_ms.restype = C.c_double
+    l.rg_batch_kernel_launches.argtypes = [vp, i32]
+    l.rg_batch_kernel_launches.restype = i64
+    l.rg_last_error.restype = C.c_char_p
+    l.rg_set_device.argtypes = [i32]
+    _lib = l
+    return l
+
+
+def check(rc):
+    if rc != 0:
+        raise RecGraphError(rc, load().rg_last_error().decode())

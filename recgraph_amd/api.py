@@ -1,0 +1,341 @@
+"""Host-side mirror of the reference's call surface for the DP hot path.
+
+Function names, argument meaning and defaults follow the reference (file:line relative to the
+RecGraph tree) so that the parity tests read like the reference's own tests:
+
+* ``align_global_no_gap`` / ``align_global_gap``  — ``src/api.rs:11``, ``src/api.rs:43``
+* ``create_score_matrix_i32`` / ``_f32``           — ``src/api.rs:131``, ``src/api.rs:153``
+* ``pathwise_alignment_exec``                      — ``src/pathwise_alignment.rs:5`` (+ ``main.rs:255-261``)
+* ``pathwise_alignment_recombination_exec``        — ``src/pathwise_alignment_recombination.rs:23``
+* ``GAFStruct``                                    — ``src/gaf_output.rs:6-94``
+* ``align_batch``                                  — the per-read loops of ``src/main.rs:56-105,174-213,257-261,297-312``
+
+Everything is computed by ``librecgraph_hip.so`` on the GPU; nothing here falls back to a CPU path.
+"""
+import ctypes as C
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import _lib
+from ._lib import Params, check
+
+ALPHABET = "ACGTN-"
+SCORE_MISSING = -536870912
+
+MODE_GLOBAL_POA = 0
+MODE_GLOBAL_POA_SCALAR = 10
+MODE_GAP_POA = 2
+MODE_PATHWISE = 4
+MODE_RECOMBINATION = 8
+
+READ_BAND_WARNING, READ_BAND_NOT_ENOUGH, READ_WOULD_PANIC, READ_BAD_BASE = 1, 2, 4, 8
+
+
+# ----------------------------------------------------------------------------------------------
+# score matrices (HashMap<(char,char), i32|f32> of the reference as a dict)
+# ----------------------------------------------------------------------------------------------
+def create_score_matrix_i32(match_score=None, mismatch_score=None, matrix_file_path=None):
+    """api.rs:131-152: match/mismatch default 2/-4; any pairing with '-' scores 2*mismatch;
+    a .mtx file (score_matrix.rs:67-105) sets every gap entry to -200."""
+    if matrix_file_path is not None:
+        return _matrix_from_mtx(matrix_file_path)
+    m = 2 if match_score is None else match_score
+    x = -4 if mismatch_score is None else mismatch_score
+    out = (C.c_int32 * 36)()
+    _lib.load().rg_scores_match_mis(m, x, 0, out)
+    return _dict_from_table(out)
+
+
+def create_score_matrix_f32(match_score=None, mismatch_score=None, matrix_file_path=None):
+    """api.rs:153-164: as above but the gap entries equal the mismatch score (score_matrix.rs:52-66)."""
+    if matrix_file_path is not None:
+        return {k: float(v) for k, v in _matrix_from_mtx(matrix_file_path).items()}
+    m = 2 if match_score is None else int(match_score)
+    x = -4 if mismatch_score is None else int(mismatch_score)
+    out = (C.c_int32 * 36)()
+    _lib.load().rg_scores_match_mis(m, x, 1, out)
+    return {k: float(v) for k, v in _dict_from_table(out).items()}
+
+
+def _matrix_from_mtx(path):
+    rows = [ln.split() for ln in open(path).read().splitlines() if ln.strip()]
+    cols = rows[0]
+    d = {}
+    for r in rows[1:]:
+        for c, v in zip(cols, r[1:]):
+            d[(r[0][0], c[0])] = int(v)
+    for ch in "ACGTN":
+        d[(ch, "-")] = -200
+        d[("-", ch)] = -200
+    d.pop(("-", "-"), None)
+    return d
+
+
+def _dict_from_table(t):
+    return {(a, b): int(t[i * 6 + j]) for i, a in enumerate(ALPHABET) for j, b in enumerate(ALPHABET)
+            if t[i * 6 + j] != SCORE_MISSING}
+
+
+def _table_from_dict(d):
+    t = [SCORE_MISSING] * 36
+    for (a, b), v in d.items():
+        if float(v) != int(v):
+            raise ValueError("non-integer scores are outside the exact range of the f32 path (SURVEY A.1 item 9)")
+        t[ALPHABET.index(a) * 6 + ALPHABET.index(b)] = int(v)
+    return t
+
+
+# ----------------------------------------------------------------------------------------------
+@dataclass
+class GAFStruct:
+    """gaf_output.rs:6-20; ``to_string`` is gaf_output.rs:70-94."""
+    query_name: str = ""
+    query_length: int = 0
+    query_start: int = 0
+    query_end: int = 0
+    strand: str = " "
+    path: list = field(default_factory=lambda: [0])
+    path_length: int = 0
+    path_start: int = 0
+    path_end: int = 0
+    residue_matches_number: int = 0
+    alignment_block_length: str = ""
+    mapping_quality: str = ""
+    comments: str = ""
+
+    def to_string(self):
+        return "\t".join([self.query_name, str(self.query_length), str(self.query_start), str(self.query_end),
+                          self.strand, ">" + ">".join(str(p) for p in self.path), str(self.path_length),
+                          str(self.path_start), str(self.path_end), str(self.residue_matches_number),
+                          self.alignment_block_length, self.mapping_quality, self.comments])
+
+    @classmethod
+    def from_line(cls, line):
+        f = line.split("\t", 12)
+        path = [int(x) for x in f[5].split(">")[1:]] if f[5] != ">" else []
+        return cls(f[0], int(f[1]), int(f[2]), int(f[3]), f[4], path, int(f[6]), int(f[7]), int(f[8]), int(f[9]),
+                   f[10], f[11], f[12])
+
+
+class Graph:
+    """A flattened graph resident in HBM (LnzGraph, graph.rs:23-27, and — when the GFA has P lines —
+    PathGraph + reverse PathGraph + distance tables, pathwise_graph.rs:10-18,250-354)."""
+
+    def __init__(self, handle):
+        self._h = handle
+
+    @classmethod
+    def from_gfa_text(cls, text):
+        lib = _lib.load()
+        h = C.c_void_p()
+        b = text.encode()
+        check(lib.rg_graph_from_gfa(b, len(b), C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def from_gfa(cls, path):
+        """graph::read_graph (graph.rs:11) / pathwise_graph::read_graph_w_path (pathwise_graph.rs:127)."""
+        with open(path) as f:
+            return cls.from_gfa_text(f.read())
+
+    @classmethod
+    def from_lnz(cls, lnz, pred_hash, node_id=None):
+        """LnzGraph literal as the reference's unit tests build it (global_abpoa.rs:576-755):
+        ``pred_hash`` = {row: [predecessor rows]}, nwp = rows that have an entry."""
+        lib = _lib.load()
+        L = len(lnz)
+        off, rows = [0], []
+        for i in range(L):
+            rows += list(pred_hash.get(i, []))
+            off.append(len(rows))
+        offa = (C.c_int64 * len(off))(*off)
+        rowa = (C.c_int64 * max(1, len(rows)))(*rows)
+        ida = (C.c_uint64 * L)(*node_id) if node_id is not None else None
+        h = C.c_void_p()
+        check(lib.rg_graph_create_lnz(lnz.encode(), L, offa, rowa, ida, C.byref(h)))
+        return cls(h)
+
+    def __del__(self):
+        try:
+            _lib.load().rg_graph_destroy(self._h)
+        except Exception:
+            pass
+
+    @property
+    def rows(self):
+        return _lib.load().rg_graph_rows(self._h)
+
+    @property
+    def paths_number(self):
+        return _lib.load().rg_graph_paths(self._h)
+
+    def dump(self, which):
+        lib = _lib.load()
+        n = lib.rg_graph_dump(self._h, which, None, 0)
+        buf = C.create_string_buffer(n + 1)
+        lib.rg_graph_dump(self._h, which, buf, n + 1)
+        return buf.value.decode()
+
+
+def make_params(mode, score_matrix=None, o=None, e=None, b=None, f=None, bta=None, R=None, r=None, B=None):
+    p = Params()
+    _lib.load().rg_params_default(C.byref(p), mode)
+    if score_matrix is not None:
+        t = score_matrix if isinstance(score_matrix, (list, tuple)) else _table_from_dict(score_matrix)
+        for i in range(36):
+            p.scores[i] = t[i]
+    if o is not None:
+        p.gap_open = o
+    if e is not None:
+        p.gap_ext = e
+    if b is not None:
+        p.band_b = b
+    if f is not None:
+        p.band_f = f
+    if bta is not None:
+        p.bta_override = int(bta)
+    if R is not None:
+        p.base_rec_cost = R
+    if r is not None:
+        p.multi_rec_cost = r
+    if B is not None:
+        p.rec_band_width = B
+    return p
+
+
+class Batch:
+    """One rg_batch: reads resident in HBM, re-runnable (what bench.py times)."""
+
+    def __init__(self, graph, reads, params):
+        lib = _lib.load()
+        self.graph = graph
+        self.n = len(reads)
+        blob = "".join(reads).encode()
+        offs = np.zeros(self.n + 1, dtype=np.int64)
+        np.cumsum([len(x) for x in reads], out=offs[1:])
+        self._h = C.c_void_p()
+        check(lib.rg_batch_create(graph._h, C.byref(params), blob, offs.ctypes.data_as(C.POINTER(C.c_int64)), self.n,
+                                  C.byref(self._h)))
+
+    def __del__(self):
+        try:
+            _lib.load().rg_batch_destroy(self._h)
+        except Exception:
+            pass
+
+    def run(self):
+        check(_lib.load().rg_batch_run(self._h))
+
+    def fetch(self):
+        check(_lib.load().rg_batch_fetch(self._h))
+
+    def status(self, i):
+        return _lib.load().rg_result_status(self._h, i)
+
+    def score(self, i):
+        return _lib.load().rg_result_score(self._h, i)
+
+    def gaf_text(self, i, name, seq_index=1):
+        lib = _lib.load()
+        nb = name.encode()
+        n = lib.rg_result_gaf(self._h, i, nb, seq_index, None, 0)
+        buf = C.create_string_buffer(n + 1)
+        lib.rg_result_gaf(self._h, i, nb, seq_index, buf, n + 1)
+        return buf.value.decode()
+
+    @property
+    def cell_updates(self):
+        return _lib.load().rg_batch_cell_updates(self._h)
+
+    def kernel_stats(self):
+        lib = _lib.load()
+        return {lib.rg_batch_kernel_name(self._h, k).decode(): (lib.rg_batch_kernel_ms(self._h, k),
+                                                                 lib.rg_batch_kernel_launches(self._h, k))
+                for k in range(lib.rg_batch_kernel_count(self._h))}
+
+
+def align_batch(graph, reads, names=None, mode=MODE_GLOBAL_POA, seq_index_base=1, **kw):
+    """The reference's per-read loop as one device batch.  Returns, per read, exactly the text the
+    reference prints on stdout (warning lines + GAF line), and the per-read status bits."""
+    p = make_params(mode, **kw)
+    b = Batch(graph, reads, p)
+    b.run()
+    b.fetch()
+    names = names or ["read%d" % i for i in range(len(reads))]
+    return [b.gaf_text(i, names[i], seq_index_base + i) for i in range(len(reads))], [b.status(i) for i in
+                                                                                      range(len(reads))]
+
+
+def _single(graph, read, name, mode, seq_index=1, **kw):
+    p = make_params(mode, **kw)
+    b = Batch(graph, [read], p)
+    b.run()
+    b.fetch()
+    st = b.status(0)
+    if st & (READ_WOULD_PANIC | READ_BAD_BASE):
+        raise _lib.RecGraphError(-1, "the reference panics on this input (status %d)" % st)
+    return b, b.gaf_text(0, name, seq_index)
+
+
+def _f32_usize(x):
+    return int(np.float32(x))
+
+
+def align_global_no_gap(read, graph, sequence_name=None, score_matrix=None, bases_to_add=None):
+    """api.rs:11-40.  Defaults: f32 matrix (2, -4, gaps -4), bases_to_add = len * 0.1, name ("no_name", 1)."""
+    sm = score_matrix if score_matrix is not None else create_score_matrix_f32(2, -4)
+    bta = _f32_usize(np.float32(len(read)) * np.float32(0.1 if bases_to_add is None else bases_to_add))
+    name, idx = sequence_name if sequence_name is not None else ("no_name", 1)
+    if idx == 0:
+        raise _lib.RecGraphError(-1, "alignment.1.unwrap() on None (api.rs:38)")
+    _, text = _single(graph, read, name, MODE_GLOBAL_POA, idx, score_matrix=sm, bta=bta)
+    lines = text.rstrip("\n").split("\n")
+    return GAFStruct.from_line(lines[-1]) if "band not enough" not in text else GAFStruct()
+
+
+def align_global_gap(read, graph, sequence_name=None, score_matrix=None, bases_to_add=None, o=None, e=None):
+    """api.rs:43-72.  Defaults: i32 matrix (2, -4), o = -10, e = -6, bases_to_add = len * 0.1."""
+    sm = score_matrix if score_matrix is not None else create_score_matrix_i32(2, -4)
+    bta = _f32_usize(np.float32(len(read)) * np.float32(0.1 if bases_to_add is None else bases_to_add))
+    name, idx = sequence_name if sequence_name is not None else ("no_name", 1)
+    if idx == 0:
+        raise _lib.RecGraphError(-1, "alignment.1.unwrap() on None (api.rs:70)")
+    _, text = _single(graph, read, name, MODE_GAP_POA, idx, score_matrix=sm, bta=bta, o=-10 if o is None else o,
+                      e=-6 if e is None else e)
+    return GAFStruct.from_line(text.rstrip("\n").split("\n")[-1])
+
+
+def global_abpoa_exec(sequence, seq_name, graph, score_matrix, bta, scalar=True):
+    """global_abpoa::exec (global_abpoa.rs:260) / exec_simd (:10): returns (score, GAFStruct | None).
+    ``sequence`` carries the leading '$' like the reference's read arrays."""
+    mode = MODE_GLOBAL_POA_SCALAR if scalar else MODE_GLOBAL_POA
+    b, text = _single(graph, "".join(sequence[1:]), seq_name[0], mode, seq_name[1], score_matrix=score_matrix, bta=bta)
+    gaf = GAFStruct.from_line(text.rstrip("\n").split("\n")[-1]) if seq_name[1] != 0 and text and "band not" not in text else None
+    return b.score(0), gaf
+
+
+def gap_global_abpoa_exec(sequence, seq_name, graph, score_matrix, o, e, bta):
+    """gap_global_abpoa::exec (gap_global_abpoa.rs:11): returns (score, GAFStruct | None)."""
+    b, text = _single(graph, "".join(sequence[1:]), seq_name[0], MODE_GAP_POA, seq_name[1], score_matrix=score_matrix,
+                      bta=bta, o=o, e=e)
+    gaf = GAFStruct.from_line(text.rstrip("\n").split("\n")[-1]) if seq_name[1] != 0 and text else None
+    return b.score(0), gaf
+
+
+def pathwise_alignment_exec(sequence, graph, score_matrix=None):
+    """pathwise_alignment::exec (pathwise_alignment.rs:5): query_name is "Temp" until the caller
+    overwrites it (main.rs:259)."""
+    _, text = _single(graph, "".join(sequence[1:]), "Temp", MODE_PATHWISE, 1, score_matrix=score_matrix)
+    return GAFStruct.from_line(text.rstrip("\n"))
+
+
+def pathwise_alignment_recombination_exec(aln_mode, sequence, graph, score_matrix=None, base_rec_cost=4,
+                                          multi_rec_cost=0.1, rbw=1.0):
+    """pathwise_alignment_recombination::exec (pathwise_alignment_recombination.rs:23); the reverse graph
+    and the displacement matrix arguments of the reference are derived inside the graph handle."""
+    if aln_mode != 8:
+        raise _lib.RecGraphError(-1, "only aln_mode 8 is on the accelerated path")
+    _, text = _single(graph, "".join(sequence[1:]), "Temp", MODE_RECOMBINATION, 1, score_matrix=score_matrix,
+                      R=base_rec_cost, r=multi_rec_cost, B=rbw)
+    return GAFStruct.from_line(text.rstrip("\n"))

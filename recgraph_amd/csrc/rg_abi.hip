@@ -1,0 +1,499 @@
+// extern "C" surface of librecgraph_hip (see include/recgraph_hip.h) and the batch driver:
+// uploads graph + reads, sizes the HBM work buffers, launches the DP / search / traceback kernels
+// on one HIP stream with HIP-event timing per kernel, copies the packed records back.
+//
+// There is deliberately NO CPU fallback: without a usable HIP device every batch call returns
+// RG_ERR_NO_DEVICE.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <memory>
+
+#include "rg_host.hpp"
+#include "rg_path_args.hpp"
+#include "rg_poa_args.hpp"
+
+using namespace rg;
+
+#define HIPCHK(x)                                                                                       \
+    do {                                                                                                \
+        hipError_t e_ = (x);                                                                            \
+        if (e_ != hipSuccess)                                                                           \
+            return fail(e_ == hipErrorNoDevice || e_ == hipErrorInvalidDevice ? RG_ERR_NO_DEVICE : RG_ERR_HIP, \
+                        std::string(#x) + ": " + hipGetErrorString(e_));                                \
+    } while (0)
+
+template <typename T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    int alloc(size_t count) {
+        if (count <= n && p) return RG_OK;
+        if (p) { (void)hipFree(p); p = nullptr; n = 0; }
+        if (count == 0) count = 1;
+        HIPCHK(hipMalloc((void**)&p, count * sizeof(T)));
+        n = count;
+        return RG_OK;
+    }
+    int upload(const std::vector<T>& v) {
+        int rc = alloc(v.size());
+        if (rc) return rc;
+        if (!v.empty()) HIPCHK(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+        return RG_OK;
+    }
+};
+
+struct rg_graph {
+    HostGraph h;
+    // LnzGraph view
+    DevBuf<uint8_t> d_lnz;
+    DevBuf<int> d_pred_off, d_pred_rows, d_r_values, d_min_pred;
+    // PathGraph view
+    DevBuf<uint64_t> d_row_mask;
+    DevBuf<int> d_knm, d_dfs, d_dfe, d_fgoff, d_rgoff, d_segfirst, d_seglast;
+    DevBuf<GroupDesc> d_fgroups, d_rgroups;
+    DevBuf<unsigned long long> d_node_id;
+    DevBuf<int> d_eoff, d_epred, d_roff, d_rsucc;
+    DevBuf<uint64_t> d_emask, d_rmask;
+    DevBuf<uint8_t> d_pnwp, d_rnwp;
+    bool on_device = false;
+};
+
+static int base_code(char c) {
+    switch (c) {
+        case 'A': return 0; case 'C': return 1; case 'G': return 2; case 'T': return 3; case 'N': return 4;
+        default: return -1;
+    }
+}
+
+static int upload_graph(rg_graph* g) {
+    if (g->on_device) return RG_OK;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(RG_ERR_NO_DEVICE, "no HIP device");
+    const HostGraph& h = g->h;
+    std::vector<uint8_t> codes(h.L, 0);
+    for (int i = 1; i + 1 < h.L; ++i) {
+        int c = base_code(h.lnz[i]);
+        if (c < 0) return fail(RG_ERR_GRAPH, "graph base outside ACGTN (the reference panics on the score lookup)");
+        codes[i] = (uint8_t)c;
+    }
+    int rc;
+    if ((rc = g->d_lnz.upload(codes))) return rc;
+    if (h.has_lnz) {
+        if ((rc = g->d_pred_off.upload(h.pred_off)) || (rc = g->d_pred_rows.upload(h.pred_rows)) ||
+            (rc = g->d_r_values.upload(h.r_values)) || (rc = g->d_min_pred.upload(h.min_pred)))
+            return rc;
+    }
+    if (h.has_path) {
+        std::vector<unsigned long long> ids(h.node_id.begin(), h.node_id.end());
+        std::vector<int> segfirst(h.L), seglast(h.L);
+        for (int i = 0; i < h.L; ++i) {
+            // "first row of its segment" / "last row of its segment" flags of the recombination tie rule
+            // (pathwise_alignment_recombination.rs:847-851)
+            segfirst[i] = i >= 1 && h.node_id[i] != h.node_id[i - 1];
+            seglast[i] = (i + 1 == h.L) || h.node_id[i] != h.node_id[i + 1];
+        }
+        if ((rc = g->d_row_mask.upload(h.row_mask)) || (rc = g->d_knm.upload(h.knm)) || (rc = g->d_dfs.upload(h.dfs)) ||
+            (rc = g->d_dfe.upload(h.dfe)) || (rc = g->d_fgoff.upload(h.fgoff)) || (rc = g->d_rgoff.upload(h.rgoff)) ||
+            (rc = g->d_fgroups.upload(h.fgroups)) || (rc = g->d_rgroups.upload(h.rgroups)) ||
+            (rc = g->d_node_id.upload(ids)) || (rc = g->d_segfirst.upload(segfirst)) ||
+            (rc = g->d_seglast.upload(seglast)) || (rc = g->d_eoff.upload(h.eoff)) || (rc = g->d_epred.upload(h.epred)) ||
+            (rc = g->d_emask.upload(h.emask)) || (rc = g->d_roff.upload(h.roff)) || (rc = g->d_rsucc.upload(h.rsucc)) ||
+            (rc = g->d_rmask.upload(h.rmask)) || (rc = g->d_pnwp.upload(h.pnwp)) || (rc = g->d_rnwp.upload(h.rnwp)))
+            return rc;
+    }
+    g->on_device = true;
+    return RG_OK;
+}
+
+struct KernelStat {
+    std::string name;
+    double ms = 0;
+    long long launches = 0;
+};
+
+struct rg_batch {
+    rg_graph* g = nullptr;
+    rg_params p;
+    int64_t nreads = 0;
+    std::string reads;                 // upper-cased bases, '-' -> 'N'
+    std::vector<long long> off;
+    std::vector<uint8_t> codes, bad;
+    std::vector<int> bta;
+    int max_n = 0;
+    hipStream_t stream = nullptr;
+    // device inputs
+    DevBuf<uint8_t> d_reads, d_bad;
+    DevBuf<long long> d_off;
+    DevBuf<int> d_bta, d_col0;
+    // work + outputs
+    DevBuf<int> d_arena_m;
+    DevBuf<uint32_t> d_arena_pw;
+    DevBuf<int4> d_rinfo;
+    DevBuf<DevRecord> d_rec;
+    DevBuf<uint8_t> d_ops;
+    DevBuf<int32_t> d_oprows;
+    DevBuf<unsigned long long> d_cells;
+    long long cap_cells = 0, ops_stride = 0;
+    PathWork pw;                       // m4/m8 buffers
+    // host results
+    std::vector<DevRecord> rec;
+    std::vector<uint8_t> ops;
+    std::vector<int32_t> oprows;
+    bool fetched = false;
+    uint64_t cells = 0;
+    std::vector<KernelStat> stats;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+    ~rg_batch() {
+        for (auto& e : ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+};
+
+namespace {
+
+struct Timed {
+    rg_batch* b;
+    std::vector<std::pair<int, int>> pending;  // (stat index, event index)
+    size_t used = 0;
+    explicit Timed(rg_batch* b_) : b(b_) {}
+    int stat(const char* name) {
+        for (size_t i = 0; i < b->stats.size(); ++i) if (b->stats[i].name == name) return (int)i;
+        b->stats.push_back(KernelStat{name, 0, 0});
+        return (int)b->stats.size() - 1;
+    }
+    template <typename F>
+    int run(const char* name, F&& launch) {
+        if (used == b->ev_pool.size()) {
+            hipEvent_t a, c;
+            HIPCHK(hipEventCreate(&a));
+            HIPCHK(hipEventCreate(&c));
+            b->ev_pool.emplace_back(a, c);
+        }
+        auto& ev = b->ev_pool[used];
+        HIPCHK(hipEventRecord(ev.first, b->stream));
+        launch();
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipEventRecord(ev.second, b->stream));
+        pending.emplace_back(stat(name), (int)used);
+        ++used;
+        return RG_OK;
+    }
+    int collect() {
+        HIPCHK(hipStreamSynchronize(b->stream));
+        for (auto& pe : pending) {
+            float ms = 0;
+            HIPCHK(hipEventElapsedTime(&ms, b->ev_pool[pe.second].first, b->ev_pool[pe.second].second));
+            b->stats[pe.first].ms += ms;
+            b->stats[pe.first].launches += 1;
+        }
+        pending.clear();
+        used = 0;
+        return RG_OK;
+    }
+};
+
+bool is_poa(int mode) { return mode == RG_MODE_GLOBAL_POA || mode == RG_MODE_GLOBAL_POA_SCALAR || mode == RG_MODE_GAP_POA; }
+
+int run_poa(rg_batch* b) {
+    rg_graph* g = b->g;
+    const HostGraph& h = g->h;
+    if (!h.has_lnz) return fail(RG_ERR_ARG, "graph has no LnzGraph view");
+    const int mode = b->p.mode;
+    const int planes = mode == RG_MODE_GAP_POA ? 3 : 1;
+    Timed T(b);
+    for (auto& s : b->stats) { s.ms = 0; s.launches = 0; }
+    for (int attempt = 0; attempt < 8; ++attempt) {
+        int rc;
+        if ((rc = b->d_arena_m.alloc((size_t)b->nreads * b->cap_cells * planes)) ||
+            (rc = b->d_arena_pw.alloc((size_t)b->nreads * b->cap_cells * planes)))
+            return rc;
+        HIPCHK(hipMemsetAsync(b->d_cells.p, 0, sizeof(unsigned long long), b->stream));
+        PoaArgs a;
+        a.g = DevLnz{h.L, g->d_lnz.p, g->d_pred_off.p, g->d_pred_rows.p, g->d_r_values.p, g->d_min_pred.p};
+        for (int i = 0; i < 36; ++i) a.sc.t[i] = b->p.scores[i];
+        a.reads = b->d_reads.p; a.read_off = b->d_off.p; a.bad = b->d_bad.p; a.bta = b->d_bta.p; a.col0 = b->d_col0.p;
+        a.nreads = (int)b->nreads; a.gap_open = b->p.gap_open; a.gap_ext = b->p.gap_ext;
+        a.cap_cells = b->cap_cells; a.arena_m = b->d_arena_m.p; a.arena_pw = b->d_arena_pw.p; a.rinfo = b->d_rinfo.p;
+        a.rec = b->d_rec.p; a.ops = b->d_ops.p; a.oprows = b->d_oprows.p; a.ops_stride = b->ops_stride;
+        a.cells = b->d_cells.p;
+        if (mode == RG_MODE_GLOBAL_POA) { if ((rc = T.run("k_m0_simd", [&] { launch_m0_simd(a, b->stream); }))) return rc; }
+        else if (mode == RG_MODE_GAP_POA) { if ((rc = T.run("k_m2_gap", [&] { launch_m2(a, b->stream); }))) return rc; }
+        else { if ((rc = T.run("k_m0_scalar", [&] { launch_m0_scalar(a, b->stream); }))) return rc; }
+        if ((rc = T.collect())) return rc;
+        // overflow check: a read whose band cells did not fit asks for a bigger arena
+        b->rec.resize(b->nreads);
+        HIPCHK(hipMemcpy(b->rec.data(), b->d_rec.p, sizeof(DevRecord) * b->nreads, hipMemcpyDeviceToHost));
+        bool ovf = false;
+        for (auto& r : b->rec) if (r.status & ST_OVERFLOW) { ovf = true; break; }
+        if (!ovf) {
+            unsigned long long c = 0;
+            HIPCHK(hipMemcpy(&c, b->d_cells.p, sizeof c, hipMemcpyDeviceToHost));
+            b->cells = c;
+            return RG_OK;
+        }
+        const long long full = (long long)h.L * (b->max_n + 1);
+        if (b->cap_cells >= full) return fail(RG_ERR_CAPACITY, "band arena overflow at full size");
+        b->cap_cells = std::min(full, b->cap_cells * 4);
+    }
+    return fail(RG_ERR_CAPACITY, "band arena overflow");
+}
+
+}  // namespace
+
+// pathwise driver lives in rg_path_driver.hip
+int rg_run_pathwise(rg_batch* b);
+namespace rg {
+int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params& p, PathWork& w, const uint8_t* d_reads,
+                    const long long* d_off, const uint8_t* d_bad, int nreads, int max_n, DevRecord* d_rec, uint8_t* d_ops,
+                    long long ops_stride, unsigned long long* d_cells, hipStream_t stream,
+                    std::vector<std::pair<std::string, std::pair<double, long long>>>& stats);
+}
+
+extern "C" {
+
+const char* rg_last_error(void) { return g_last_error.c_str(); }
+
+int32_t rg_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+int32_t rg_set_device(int32_t dev) {
+    HIPCHK(hipSetDevice(dev));
+    return RG_OK;
+}
+
+void rg_scores_match_mis(int32_t m, int32_t x, int32_t f32_variant, int32_t* s) {
+    // score_matrix.rs:35-66
+    for (int i = 0; i < 6; ++i)
+        for (int j = 0; j < 6; ++j) {
+            if (i == j) s[i * 6 + j] = m;
+            else if (!f32_variant && (i == 5 || j == 5)) s[i * 6 + j] = 2 * x;
+            else s[i * 6 + j] = x;
+        }
+    s[4 * 6 + 4] = x;
+    s[5 * 6 + 5] = RG_SCORE_MISSING;
+}
+
+void rg_params_default(rg_params* p, int32_t mode) {
+    memset(p, 0, sizeof *p);
+    p->mode = mode;
+    rg_scores_match_mis(2, -4, 0, p->scores);
+    p->gap_open = -4;
+    p->gap_ext = -2;
+    p->band_b = 1.0f;
+    p->band_f = 0.01f;
+    p->bta_override = -1;
+    p->base_rec_cost = 4;
+    p->multi_rec_cost = 0.1f;
+    p->rec_band_width = 1.0f;
+}
+
+int32_t rg_graph_from_gfa(const char* gfa_text, int64_t len, rg_graph** out) {
+    if (!gfa_text || !out) return fail(RG_ERR_ARG, "null argument");
+    auto g = std::make_unique<rg_graph>();
+    int rc = build_from_gfa(gfa_text, len, g->h);
+    if (rc) return rc;
+    *out = g.release();
+    return RG_OK;
+}
+int32_t rg_graph_create_lnz(const char* lnz, int64_t L, const int64_t* pred_off, const int64_t* pred_rows,
+                            const uint64_t* node_id, rg_graph** out) {
+    if (!out) return fail(RG_ERR_ARG, "null argument");
+    auto g = std::make_unique<rg_graph>();
+    int rc = build_from_lnz(lnz, L, pred_off, pred_rows, node_id, g->h);
+    if (rc) return rc;
+    *out = g.release();
+    return RG_OK;
+}
+int32_t rg_graph_create_path(const char* lnz, int64_t L, int32_t P, const uint64_t* row_mask, const int64_t* edge_off,
+                             const int64_t* edge_pred, const uint64_t* edge_mask, const uint64_t* node_id, rg_graph** out) {
+    if (!out) return fail(RG_ERR_ARG, "null argument");
+    auto g = std::make_unique<rg_graph>();
+    int rc = build_from_path(lnz, L, P, row_mask, edge_off, edge_pred, edge_mask, node_id, g->h);
+    if (rc) return rc;
+    *out = g.release();
+    return RG_OK;
+}
+void rg_graph_destroy(rg_graph* g) { delete g; }
+int64_t rg_graph_rows(const rg_graph* g) { return g ? g->h.L : 0; }
+int32_t rg_graph_paths(const rg_graph* g) { return g && g->h.has_path ? g->h.P : 0; }
+int64_t rg_graph_dump(const rg_graph* g, int32_t which, char* buf, int64_t cap) {
+    std::string s = dump_graph(g->h, which);
+    if (buf && (int64_t)s.size() + 1 <= cap) memcpy(buf, s.c_str(), s.size() + 1);
+    return (int64_t)s.size();
+}
+
+int32_t rg_batch_create(const rg_graph* gc, const rg_params* p, const char* reads, const int64_t* read_off, int64_t nreads,
+                        rg_batch** out) {
+    if (!gc || !p || !reads || !read_off || !out || nreads < 1) return fail(RG_ERR_ARG, "null/empty argument");
+    rg_graph* g = const_cast<rg_graph*>(gc);
+    const int mode = p->mode;
+    if (!(is_poa(mode) || mode == RG_MODE_PATHWISE || mode == RG_MODE_RECOMBINATION)) return fail(RG_ERR_ARG, "unsupported mode");
+    if (is_poa(mode) && !g->h.has_lnz) return fail(RG_ERR_ARG, "graph has no LnzGraph view");
+    if (!is_poa(mode) && !g->h.has_path) return fail(RG_ERR_ARG, "graph has no paths (P lines)");
+    if (mode == RG_MODE_RECOMBINATION && (p->base_rec_cost < 0 || p->multi_rec_cost < 0))
+        return fail(RG_ERR_ARG, "recombination costs must be non-negative");
+    if (mode == RG_MODE_GLOBAL_POA && g->h.L >= (1 << 20))
+        return fail(RG_ERR_GRAPH, "m0: rows >= 2^20 break the reference's f32 path-cell decoding (gaf_output.rs:783-786)");
+    if ((mode == RG_MODE_GAP_POA || mode == RG_MODE_GLOBAL_POA_SCALAR) && g->h.L > 65536)
+        return fail(RG_ERR_GRAPH, "rows >= 65536 are truncated by the reference's u16 path cells (bitfield_path.rs:41)");
+    int rc = upload_graph(g);
+    if (rc) return rc;
+    auto b = std::make_unique<rg_batch>();
+    b->g = g;
+    b->p = *p;
+    b->nreads = nreads;
+    b->off.resize(nreads + 1);
+    const long long base = read_off[0];
+    for (int64_t i = 0; i <= nreads; ++i) b->off[i] = read_off[i] - base;
+    b->reads.assign(reads + base, reads + read_off[nreads]);
+    b->codes.resize(b->reads.size());
+    b->bad.assign(nreads, 0);
+    b->bta.resize(nreads);
+    for (int64_t r = 0; r < nreads; ++r) {
+        const long long n = b->off[r + 1] - b->off[r];
+        if (n < 1) return fail(RG_ERR_ARG, "empty read");
+        b->max_n = std::max<int>(b->max_n, (int)n);
+        for (long long k = b->off[r]; k < b->off[r + 1]; ++k) {
+            char c = b->reads[k];
+            c = c == '-' ? 'N' : (char)toupper((unsigned char)c);  // sequences.rs:13-22
+            b->reads[k] = c;
+            int code = base_code(c);
+            if (code < 0) { b->bad[r] = 1; code = 4; }
+            b->codes[k] = (uint8_t)code;
+        }
+        // main.rs:57: (b + f * seq.len() as f32) as usize, seq.len() = n + 1
+        float v = p->band_b + p->band_f * (float)(n + 1);
+        long long bt = p->bta_override >= 0 ? p->bta_override : (v > 0 ? (long long)v : 0);
+        b->bta[r] = (int)std::min<long long>(bt, 1 << 28);
+    }
+    HIPCHK(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
+    if ((rc = b->d_reads.upload(b->codes)) || (rc = b->d_off.upload(b->off)) || (rc = b->d_bad.upload(b->bad)) ||
+        (rc = b->d_bta.upload(b->bta)))
+        return rc;
+    if ((rc = b->d_rec.alloc(nreads)) || (rc = b->d_cells.alloc(1))) return rc;
+    const HostGraph& h = g->h;
+    b->ops_stride = (long long)h.L + b->max_n + 8;
+    if ((rc = b->d_ops.alloc((size_t)nreads * b->ops_stride))) return rc;
+    if (is_poa(mode)) {
+        // column-0 chain of m0 (global_abpoa.rs:36-46): depends on graph + scores only
+        std::vector<int> col0(h.L, 0);
+        for (int i = 1; i + 1 < h.L; ++i) {
+            int c = base_code(h.lnz[i]);
+            col0[i] = col0[h.min_pred[i]] + p->scores[c * 6 + 5];
+        }
+        if ((rc = b->d_col0.upload(col0))) return rc;
+        if ((rc = b->d_oprows.alloc((size_t)nreads * b->ops_stride)) || (rc = b->d_rinfo.alloc((size_t)nreads * h.L))) return rc;
+        long long maxbta = 0;
+        for (int v : b->bta) maxbta = std::max<long long>(maxbta, v);
+        const long long per_row = std::min<long long>(b->max_n + 1, 2 * maxbta + 40);
+        b->cap_cells = (long long)h.L * per_row;
+    }
+    *out = b.release();
+    return RG_OK;
+}
+
+int32_t rg_batch_run(rg_batch* b) {
+    if (!b) return fail(RG_ERR_ARG, "null batch");
+    b->fetched = false;
+    if (is_poa(b->p.mode)) return run_poa(b);
+    return rg_run_pathwise(b);
+}
+
+int32_t rg_batch_fetch(rg_batch* b) {
+    if (!b) return fail(RG_ERR_ARG, "null batch");
+    b->rec.resize(b->nreads);
+    HIPCHK(hipMemcpy(b->rec.data(), b->d_rec.p, sizeof(DevRecord) * b->nreads, hipMemcpyDeviceToHost));
+    b->ops.resize((size_t)b->nreads * b->ops_stride);
+    HIPCHK(hipMemcpy(b->ops.data(), b->d_ops.p, b->ops.size(), hipMemcpyDeviceToHost));
+    if (is_poa(b->p.mode)) {
+        b->oprows.resize((size_t)b->nreads * b->ops_stride);
+        HIPCHK(hipMemcpy(b->oprows.data(), b->d_oprows.p, b->oprows.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+    }
+    b->fetched = true;
+    return RG_OK;
+}
+
+void rg_batch_destroy(rg_batch* b) { delete b; }
+int64_t rg_batch_size(const rg_batch* b) { return b ? b->nreads : 0; }
+
+static uint32_t public_status(uint32_t s) { return s & 0xffu; }
+
+uint32_t rg_result_status(const rg_batch* b, int64_t i) {
+    if (!b || !b->fetched || i < 0 || i >= b->nreads) return RG_READ_WOULD_PANIC;
+    return public_status(b->rec[i].status);
+}
+int32_t rg_result_score(const rg_batch* b, int64_t i) {
+    if (!b || !b->fetched || i < 0 || i >= b->nreads) return 0;
+    return b->rec[i].score;
+}
+
+int64_t rg_result_gaf(const rg_batch* b, int64_t i, const char* name, int64_t seq_index, char* buf, int64_t cap) {
+    if (!b || !b->fetched || i < 0 || i >= b->nreads) return fail(RG_ERR_ARG, "result not available");
+    const DevRecord& d = b->rec[i];
+    std::string out;
+    if ((d.status & (ST_BAD_BASE | ST_WOULD_PANIC)) == 0 && seq_index != 0) {
+        ReadRecord r;
+        r.status = public_status(d.status); r.score = d.score; r.fscore = d.fscore; r.end_row = d.end_row; r.end_col = d.end_col;
+        r.stop_row = d.stop_row; r.stop_col = d.stop_col; r.best_path = d.best_path; r.rev_path = d.rev_path; r.fen = d.fen;
+        r.rsn = d.rsn; r.rec_col = d.rec_col; r.displacement = d.displacement; r.n_ops = d.n_ops; r.n_fwd_ops = d.n_fwd_ops;
+        r.ops = b->ops.data() + (size_t)i * b->ops_stride;
+        r.rows = is_poa(b->p.mode) ? b->oprows.data() + (size_t)i * b->ops_stride : nullptr;
+        std::string read = b->reads.substr((size_t)b->off[i], (size_t)(b->off[i + 1] - b->off[i]));
+        std::string nm = name ? name : "";
+        switch (b->p.mode) {
+            case RG_MODE_GLOBAL_POA: out = format_m0_simd(b->g->h, read, nm, r); break;
+            case RG_MODE_GLOBAL_POA_SCALAR:
+            case RG_MODE_GAP_POA: out = format_poa_banded(b->g->h, read, nm, r); break;
+            default: out = format_pathwise(b->g->h, read, nm, r, b->p.mode); break;
+        }
+    } else if ((d.status & (ST_BAD_BASE | ST_WOULD_PANIC)) == 0 && (d.status & ST_BAND_WARNING)) {
+        out = "Band length probably too short, maybe try with larger b and f\n";
+    }
+    if (buf && (int64_t)out.size() + 1 <= cap) memcpy(buf, out.c_str(), out.size() + 1);
+    return (int64_t)out.size();
+}
+
+uint64_t rg_batch_cell_updates(const rg_batch* b) { return b ? b->cells : 0; }
+int32_t rg_batch_kernel_count(const rg_batch* b) { return b ? (int32_t)b->stats.size() : 0; }
+const char* rg_batch_kernel_name(const rg_batch* b, int32_t k) { return b->stats[k].name.c_str(); }
+double rg_batch_kernel_ms(const rg_batch* b, int32_t k) { return b->stats[k].ms; }
+int64_t rg_batch_kernel_launches(const rg_batch* b, int32_t k) { return b->stats[k].launches; }
+
+int32_t rg_align_batch(const rg_graph* g, const rg_params* p, const char* reads, const int64_t* read_off, int64_t nreads,
+                       rg_batch** out) {
+    rg_batch* b = nullptr;
+    int rc = rg_batch_create(g, p, reads, read_off, nreads, &b);
+    if (rc) return rc;
+    if ((rc = rg_batch_run(b)) || (rc = rg_batch_fetch(b))) { rg_batch_destroy(b); return rc; }
+    *out = b;
+    return RG_OK;
+}
+
+}  // extern "C"
+
+// ---- pathwise modes: buffers are owned by PathWork, kernels by rg_path_driver.hip ----
+int rg_run_pathwise(rg_batch* b) {
+    rg_graph* g = b->g;
+    const HostGraph& h = g->h;
+    PathGraphDev gd;
+    gd.L = h.L; gd.P = h.P; gd.lnz = g->d_lnz.p; gd.row_mask = g->d_row_mask.p; gd.knm = g->d_knm.p;
+    gd.dfs = g->d_dfs.p; gd.dfe = g->d_dfe.p; gd.fgoff = g->d_fgoff.p; gd.rgoff = g->d_rgoff.p;
+    gd.fgroups = g->d_fgroups.p; gd.rgroups = g->d_rgroups.p; gd.fslots = h.fslots; gd.rslots = h.rslots;
+    gd.node_id = g->d_node_id.p; gd.segfirst = g->d_segfirst.p; gd.seglast = g->d_seglast.p;
+    gd.eoff = g->d_eoff.p; gd.epred = g->d_epred.p; gd.emask = g->d_emask.p; gd.roff = g->d_roff.p; gd.rsucc = g->d_rsucc.p;
+    gd.rmask = g->d_rmask.p; gd.pnwp = g->d_pnwp.p; gd.rnwp = g->d_rnwp.p;
+    std::vector<std::pair<std::string, std::pair<double, long long>>> st;
+    int rc = path_driver_run(h, gd, b->p, b->pw, b->d_reads.p, b->d_off.p, b->d_bad.p, (int)b->nreads, b->max_n, b->d_rec.p,
+                             b->d_ops.p, b->ops_stride, b->d_cells.p, b->stream, st);
+    b->stats.clear();
+    for (auto& s : st) b->stats.push_back(KernelStat{s.first, s.second.first, s.second.second});
+    if (rc) return rc;
+    unsigned long long c = 0;
+    HIPCHK(hipMemcpy(&c, b->d_cells.p, sizeof c, hipMemcpyDeviceToHost));
+    b->cells = c;
+    return RG_OK;
+}

@@ -1,0 +1,69 @@
+// Device-side shared definitions (HIP, gfx950).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rg {
+
+constexpr int WAVE = 64;
+
+// scoring table by value in kernel arguments: t[a*6+b], alphabet "ACGTN-" -> 0..5
+struct DevScores {
+    int t[36];
+};
+
+// flattened LnzGraph in HBM (graph.rs:23-27 restated as CSR)
+struct DevLnz {
+    int L;
+    const uint8_t* lnz;       // base codes 0..4 per row (rows 0 and L-1 unused)
+    const int* pred_off;      // L+1
+    const int* pred_rows;
+    const int* r_values;      // L
+    const int* min_pred;      // L
+};
+
+// per-read header written by the kernels, read back by the host (fixed stride)
+struct DevRecord {
+    uint32_t status;
+    int32_t score;
+    float fscore;
+    int32_t end_row, end_col;
+    int32_t stop_row, stop_col;
+    int32_t best_path, rev_path;
+    int32_t fen, rsn, rec_col, displacement;
+    int32_t n_ops, n_fwd_ops;
+    int32_t pad;
+};
+
+// traceback op codes (one byte per op, walk order)
+enum : uint8_t { OP_D = 1, OP_U = 2, OP_L = 3, OP_CONT = 0x80 };
+
+// status bits mirror include/recgraph_hip.h
+enum : uint32_t { ST_BAND_WARNING = 1u, ST_BAND_NOT_ENOUGH = 2u, ST_WOULD_PANIC = 4u, ST_BAD_BASE = 8u, ST_OVERFLOW = 0x100u };
+
+__device__ __forceinline__ int wave_incl_sum(int v, int lane) {
+#pragma unroll
+    for (int d = 1; d < WAVE; d <<= 1) {
+        int o = __shfl_up(v, d, WAVE);
+        if (lane >= d) v += o;
+    }
+    return v;
+}
+__device__ __forceinline__ int wave_incl_max(int v, int lane) {
+#pragma unroll
+    for (int d = 1; d < WAVE; d <<= 1) {
+        int o = __shfl_up(v, d, WAVE);
+        if (lane >= d) v = max(v, o);
+    }
+    return v;
+}
+__device__ __forceinline__ long long wave_max_ll(long long v) {
+#pragma unroll
+    for (int d = WAVE / 2; d >= 1; d >>= 1) {
+        long long o = __shfl_xor(v, d, WAVE);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+
+}  // namespace rg

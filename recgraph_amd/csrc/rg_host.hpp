@@ -1,0 +1,93 @@
+// Internal host-side structures of librecgraph_hip (not part of the C ABI).
+//
+// Layout choices: every graph array is a flat CSR/SoA vector sized for one upload to HBM; the
+// reference's HashMap/BitVec containers (graph.rs:23-27, pathwise_graph.rs:10-18,75-78) have no
+// counterpart here.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/recgraph_hip.h"
+
+namespace rg {
+
+extern thread_local std::string g_last_error;
+int fail(int code, const std::string& msg);
+
+// one edge group of a DP row in the pathwise modes: all paths entering `row` through the same
+// predecessor row share the direction chosen by the group's alpha path
+struct GroupDesc {
+    int32_t pred;     // predecessor row (successor row in the reverse program)
+    uint32_t ga;      // group alpha path id
+    uint64_t mask;    // member paths
+    int32_t slot;     // index of this (row, group) in the direction-word store
+    int32_t pad;
+};
+
+struct HostGraph {
+    // ---- shared linearisation (graph.rs:41-57 == pathwise_graph.rs:147-165) ----
+    int32_t L = 0;                    // rows incl. '$' (row 0) and 'F' (row L-1)
+    std::string lnz;
+    std::vector<uint64_t> node_id;    // segment id per row, 0 for rows 0 and L-1
+    std::vector<int32_t> seg_off;     // 1-based offset of the row inside its segment (0 for row 0 / F)
+
+    // ---- LnzGraph view (m0/m2) ----
+    bool has_lnz = false;
+    std::vector<int32_t> pred_off, pred_rows;   // CSR; empty range = single predecessor row-1
+    std::vector<int32_t> r_values;              // utils.rs:103-126
+    std::vector<int32_t> min_pred;              // numerically smallest predecessor (column-0 chain)
+
+    // ---- PathGraph view (m4/m8) ----
+    bool has_path = false;
+    int32_t P = 0;
+    std::vector<uint64_t> row_mask;             // paths through each row (all ones for rows 0, L-1)
+    std::vector<int32_t> alphas;
+    std::vector<uint8_t> pnwp, rnwp;            // forward / reverse "row has listed predecessors"
+    std::vector<int32_t> eoff, epred;           // forward PredHash, CSR, ascending pred row
+    std::vector<uint64_t> emask;
+    std::vector<int32_t> roff, rsucc;           // reverse PredHash
+    std::vector<uint64_t> rmask;
+    std::vector<int32_t> dfs, dfe;              // pathwise_graph.rs:306-354; ndm[i][j] recomputed from these
+    std::vector<int32_t> knm;                   // highest path id NOT through the row, -1 if none
+    // DP programs: groups of row i are fgroups[fgoff[i] .. fgoff[i+1])
+    std::vector<int32_t> fgoff, rgoff;
+    std::vector<GroupDesc> fgroups, rgroups;
+    int32_t fslots = 0, rslots = 0;
+    int32_t max_path_rows = 0;
+};
+
+// GFA text -> HostGraph (both views when P lines exist)
+int build_from_gfa(const char* text, int64_t len, HostGraph& g);
+int build_from_lnz(const char* lnz, int64_t L, const int64_t* pred_off, const int64_t* pred_rows,
+                   const uint64_t* node_id, HostGraph& g);
+int build_from_path(const char* lnz, int64_t L, int32_t P, const uint64_t* row_mask, const int64_t* edge_off,
+                    const int64_t* edge_pred, const uint64_t* edge_mask, const uint64_t* node_id, HostGraph& g);
+std::string dump_graph(const HostGraph& g, int which);
+
+// ---- alignment records as they come back from the device ----
+struct ReadRecord {
+    uint32_t status = 0;
+    int32_t score = 0;
+    float fscore = 0.f;          // m0: best f32 score; m8 rec: recombination score
+    int32_t end_row = 0;         // last_row (POA) / ending node
+    int32_t end_col = 0;         // last_col (absolute column)
+    int32_t stop_row = 0, stop_col = 0;   // where the POA traceback stopped
+    int32_t best_path = -1, rev_path = -1;
+    int32_t fen = 0, rsn = 0, rec_col = 0, displacement = 0;
+    int32_t rev_ending = 0;
+    int32_t n_ops = 0;           // traceback ops in walk order
+    const uint8_t* ops = nullptr;
+    const int32_t* rows = nullptr;   // row consumed by each op (D/U), -1 for L
+    int32_t n_fwd_ops = 0;       // m8 rec: ops of the forward half (walk order), the rest is the reverse half
+};
+
+// GAF text exactly as the reference prints it
+std::string format_m0_simd(const HostGraph& g, const std::string& read, const std::string& name, const ReadRecord& r);
+std::string format_poa_banded(const HostGraph& g, const std::string& read, const std::string& name,
+                              const ReadRecord& r);
+std::string format_pathwise(const HostGraph& g, const std::string& read, const std::string& name,
+                            const ReadRecord& r, int mode);
+std::string f32_display(float v);
+
+}  // namespace rg

@@ -1,0 +1,44 @@
+// Argument blocks and work buffers of the pathwise (-m 4 / -m 8) kernels.
+#pragma once
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "rg_device.hpp"
+#include "rg_host.hpp"
+
+namespace rg {
+
+// flattened PathGraph (+ reverse PredHash, DP programs) in HBM
+struct PathGraphDev {
+    int L, P;
+    const uint8_t* lnz;
+    const uint64_t* row_mask;
+    const int* knm;
+    const int* dfs;
+    const int* dfe;
+    const int* fgoff;
+    const int* rgoff;
+    const GroupDesc* fgroups;
+    const GroupDesc* rgroups;
+    int fslots, rslots;
+    const unsigned long long* node_id;
+    const int* segfirst;
+    const int* seglast;
+    const int* eoff;
+    const int* epred;
+    const uint64_t* emask;
+    const int* roff;
+    const int* rsucc;
+    const uint64_t* rmask;
+    const uint8_t* pnwp;
+    const uint8_t* rnwp;
+};
+
+struct PathWorkImpl;
+struct PathWork {
+    PathWorkImpl* impl = nullptr;
+    ~PathWork();
+};
+
+}  // namespace rg

@@ -1,0 +1,32 @@
+// Kernel argument blocks shared between the launchers (.hip) and the batch driver.
+#pragma once
+#include "rg_device.hpp"
+
+namespace rg {
+
+struct PoaArgs {
+    DevLnz g;
+    DevScores sc;
+    const uint8_t* reads;      // base codes, all reads concatenated
+    const long long* read_off; // nreads+1
+    const uint8_t* bad;        // per read: 1 = contains a base outside ACGTN
+    const int* bta;            // per read bases_to_add (main.rs:57)
+    const int* col0;           // m0: m[i][0] per row (global_abpoa.rs:36-46), depends on scores only
+    int nreads;
+    int gap_open, gap_ext;     // m2
+    long long cap_cells;       // arena capacity per read (cells)
+    int* arena_m;              // [nreads][cap_cells] (m2: 3 planes)
+    uint32_t* arena_pw;        // [nreads][cap_cells] (m2: 3 planes)
+    int4* rinfo;               // [nreads][L]  {arena offset, first stored column, right, best_scoring_pos}
+    DevRecord* rec;            // [nreads]
+    uint8_t* ops;              // [nreads][ops_stride]
+    int32_t* oprows;           // [nreads][ops_stride]
+    long long ops_stride;
+    unsigned long long* cells; // DP cell-update counter
+};
+
+void launch_m0_simd(const PoaArgs& a, hipStream_t s);
+void launch_m2(const PoaArgs& a, hipStream_t s);
+void launch_m0_scalar(const PoaArgs& a, hipStream_t s);
+
+}  // namespace rg
