@@ -332,6 +332,7 @@ int32_t rg_batch_create(const rg_graph* gc, const rg_params* p, const char* read
     rg_graph* g = const_cast<rg_graph*>(gc);
     const int mode = p->mode;
     if (!(is_poa(mode) || mode == RG_MODE_PATHWISE || mode == RG_MODE_RECOMBINATION)) return fail(RG_ERR_ARG, "unsupported mode");
+    if (mode == RG_MODE_GAP_POA || mode == RG_MODE_GLOBAL_POA_SCALAR) return fail(RG_ERR_ARG, "mode not built into this library yet");
     if (is_poa(mode) && !g->h.has_lnz) return fail(RG_ERR_ARG, "graph has no LnzGraph view");
     if (!is_poa(mode) && !g->h.has_path) return fail(RG_ERR_ARG, "graph has no paths (P lines)");
     if (mode == RG_MODE_RECOMBINATION && (p->base_rec_cost < 0 || p->multi_rec_cost < 0))

@@ -1,13 +1,258 @@
-// Pathwise driver (placeholder until the kernels land in this file).
-#include "rg_path_args.hpp"
+// Batch driver of the pathwise modes (-m 4, -m 8): sizes the HBM work buffers, runs the kernel
+// pipeline on one stream with HIP-event timing per kernel, regrows the candidate lists on overflow.
+//
+//   -m 4:  sweep(F, dirs) -> seed -> layer(F) -> trace
+//   -m 8:  sweep(F1: column maxima) -> seed -> thr -> sweep(R: dirs, candidates, column maxima)
+//          -> thr -> sweep(F2: dirs, candidates) -> search -> layer(F) -> layer(R) -> trace
+#include <algorithm>
+#include <cstring>
+
+#include "rg_path_kernels.hpp"
+
 namespace rg {
-struct PathWorkImpl {};
+
+#define HIPCHK(x)                                                                            \
+    do {                                                                                     \
+        hipError_t e_ = (x);                                                                 \
+        if (e_ != hipSuccess) return fail(RG_ERR_HIP, std::string(#x) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+template <typename T>
+struct Buf {
+    T* p = nullptr;
+    size_t n = 0;
+    ~Buf() { if (p) (void)hipFree(p); }
+    int alloc(size_t count) {
+        if (p && count <= n) return RG_OK;
+        if (p) { (void)hipFree(p); p = nullptr; n = 0; }
+        if (!count) count = 1;
+        HIPCHK(hipMalloc((void**)&p, count * sizeof(T)));
+        n = count;
+        return RG_OK;
+    }
+    int upload(const std::vector<T>& v) {
+        int rc = alloc(v.size());
+        if (rc) return rc;
+        if (!v.empty()) HIPCHK(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+        return RG_OK;
+    }
+};
+
+struct PathWorkImpl {
+    bool tables = false;
+    Buf<int> fpoff, fprow, fpslot, rpoff, rprow, rpslot;
+    Buf<ReadState> state;
+    Buf<int> roll, mf, wr, thr, flayer, rlayer;
+    Buf<uint32_t> fdirs, rdirs;
+    Buf<Cand> fcand, rcand;
+    Buf<unsigned> nf, nr, ridx;
+    unsigned cand_cap = 0;
+    std::vector<hipEvent_t> ev;
+    ~PathWorkImpl() { for (auto e : ev) (void)hipEventDestroy(e); }
+};
 PathWork::~PathWork() { delete impl; }
-int path_driver_run(const HostGraph&, const PathGraphDev&, const rg_params&, PathWork&, const uint8_t*, const long long*,
-                    const uint8_t*, int, int, DevRecord*, uint8_t*, long long, unsigned long long*, hipStream_t,
-                    std::vector<std::pair<std::string, std::pair<double, long long>>>&) {
-    return fail(RG_ERR_ARG, "pathwise modes are not built into this library yet");
+
+namespace {
+
+struct Timer {
+    PathWorkImpl* w;
+    hipStream_t s;
+    size_t used = 0;
+    struct Pend { std::string name; size_t e0, e1; };
+    std::vector<Pend> pend;
+    int begin(const char* name) {
+        while (w->ev.size() < used + 2) {
+            hipEvent_t e;
+            HIPCHK(hipEventCreate(&e));
+            w->ev.push_back(e);
+        }
+        HIPCHK(hipEventRecord(w->ev[used], s));
+        pend.push_back(Pend{name, used, used + 1});
+        return RG_OK;
+    }
+    int end() {
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipEventRecord(w->ev[used + 1], s));
+        used += 2;
+        return RG_OK;
+    }
+    int collect(std::vector<std::pair<std::string, std::pair<double, long long>>>& stats) {
+        HIPCHK(hipStreamSynchronize(s));
+        for (auto& p : pend) {
+            float ms = 0;
+            HIPCHK(hipEventElapsedTime(&ms, w->ev[p.e0], w->ev[p.e1]));
+            bool found = false;
+            for (auto& st : stats)
+                if (st.first == p.name) { st.second.first += ms; st.second.second += 1; found = true; }
+            if (!found) stats.push_back({p.name, {ms, 1}});
+        }
+        pend.clear();
+        used = 0;
+        return RG_OK;
+    }
+};
+
+#define TIMED(T, name, call)                    \
+    do {                                        \
+        int rc_ = (T).begin(name);              \
+        if (rc_) return rc_;                    \
+        call;                                   \
+        rc_ = (T).end();                        \
+        if (rc_) return rc_;                    \
+    } while (0)
+
+}  // namespace
+
+int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params& p, PathWork& pw, const uint8_t* d_reads,
+                    const long long* d_off, const uint8_t* d_bad, int nreads, int max_n, DevRecord* d_rec, uint8_t* d_ops,
+                    long long ops_stride, unsigned long long* d_cells, hipStream_t stream,
+                    std::vector<std::pair<std::string, std::pair<double, long long>>>& stats) {
+    if (!pw.impl) pw.impl = new PathWorkImpl();
+    PathWorkImpl& w = *pw.impl;
+    const int mode = p.mode;
+    const int P = h.P, L = h.L;
+    int C = 4;
+    while (C * WAVE < max_n + 1) C *= 2;
+    if (C > 32) return fail(RG_ERR_ARG, "reads longer than 2047 bases are not supported by the pathwise kernels");
+    const int wpad = C * WAVE;
+    const int dir_words = WAVE * (C <= 16 ? 1 : 2);
+    const bool lds = (size_t)P * wpad * sizeof(int) + 64 * sizeof(int) <= 160 * 1024;
+    int rc;
+    if (!w.tables) {
+        // rows of every path in program order, with the direction-word slot of the group holding the path
+        auto build = [&](const std::vector<int32_t>& goff, const std::vector<GroupDesc>& groups, bool fwd,
+                         std::vector<int>& poff, std::vector<int>& prow, std::vector<int>& pslot) {
+            std::vector<std::vector<std::pair<int, int>>> per(P);
+            for (int step = 1; step + 1 < L; ++step) {
+                const int i = fwd ? step : L - 1 - step;
+                for (int gi = goff[i]; gi < goff[i + 1]; ++gi)
+                    for (int k = 0; k < P; ++k)
+                        if ((groups[gi].mask >> k) & 1) per[k].push_back({i, groups[gi].slot});
+            }
+            poff.assign(P + 1, 0);
+            prow.clear();
+            pslot.clear();
+            for (int k = 0; k < P; ++k) {
+                for (auto& e : per[k]) { prow.push_back(e.first); pslot.push_back(e.second); }
+                poff[k + 1] = (int)prow.size();
+            }
+        };
+        std::vector<int> po, pr, ps;
+        build(h.fgoff, h.fgroups, true, po, pr, ps);
+        if ((rc = w.fpoff.upload(po)) || (rc = w.fprow.upload(pr)) || (rc = w.fpslot.upload(ps))) return rc;
+        build(h.rgoff, h.rgroups, false, po, pr, ps);
+        if ((rc = w.rpoff.upload(po)) || (rc = w.rprow.upload(pr)) || (rc = w.rpslot.upload(ps))) return rc;
+        w.tables = true;
+    }
+    const long long layer_stride = (long long)(h.max_path_rows + 2) * wpad;
+    const long long fdirs_stride = (long long)h.fslots * dir_words;
+    const long long rdirs_stride = (long long)h.rslots * dir_words;
+    // reads per chunk: bounded by a memory budget for the per-read work buffers
+    const size_t per_read = (size_t)(fdirs_stride + (mode == RG_MODE_RECOMBINATION ? rdirs_stride : 0)) * 4 +
+                            (size_t)layer_stride * 4 * (mode == RG_MODE_RECOMBINATION ? 2 : 1) +
+                            (lds ? 0 : (size_t)P * wpad * 4) + (size_t)wpad * 12 + sizeof(ReadState);
+    size_t budget = (size_t)96 << 30;
+    {
+        size_t fr = 0, tot = 0;
+        if (hipMemGetInfo(&fr, &tot) == hipSuccess) budget = std::min(budget, fr / 2);
+    }
+    if (w.cand_cap == 0) w.cand_cap = 1u << 15;
+    stats.clear();
+    HIPCHK(hipMemsetAsync(d_cells, 0, sizeof(unsigned long long), stream));
+    Timer T{&w, stream};
+    int done = 0;
+    unsigned long long cells_done = 0;
+    while (done < nreads) {
+        const size_t per_read_all = per_read + (mode == RG_MODE_RECOMBINATION ? (size_t)w.cand_cap * (2 * sizeof(Cand) + 4) : 0);
+        int chunk = (int)std::min<size_t>((size_t)(nreads - done), std::max<size_t>(1, budget / per_read_all));
+        chunk = std::min(chunk, 8192);
+        if ((rc = w.state.alloc(chunk)) || (rc = w.fdirs.alloc((size_t)chunk * fdirs_stride)) ||
+            (rc = w.flayer.alloc((size_t)chunk * layer_stride)))
+            return rc;
+        if (!lds && (rc = w.roll.alloc((size_t)chunk * P * wpad))) return rc;
+        if (mode == RG_MODE_RECOMBINATION) {
+            if ((rc = w.rdirs.alloc((size_t)chunk * rdirs_stride)) || (rc = w.rlayer.alloc((size_t)chunk * layer_stride)) ||
+                (rc = w.mf.alloc((size_t)chunk * wpad)) || (rc = w.wr.alloc((size_t)chunk * wpad)) ||
+                (rc = w.thr.alloc((size_t)chunk * wpad)) || (rc = w.fcand.alloc((size_t)chunk * w.cand_cap)) ||
+                (rc = w.rcand.alloc((size_t)chunk * w.cand_cap)) || (rc = w.ridx.alloc((size_t)chunk * w.cand_cap)) ||
+                (rc = w.nf.alloc(chunk)) || (rc = w.nr.alloc(chunk)))
+                return rc;
+        }
+        const uint8_t* bad = d_bad + done;
+        const long long* off = d_off + done;
+        HIPCHK(hipMemsetAsync(w.state.p, 0, sizeof(ReadState) * chunk, stream));
+        SweepArgs sa;
+        memset(&sa, 0, sizeof sa);
+        sa.g = gd;
+        for (int i = 0; i < 36; ++i) sa.sc.t[i] = p.scores[i];
+        sa.reads = d_reads; sa.read_off = off; sa.bad = bad; sa.state = w.state.p; sa.roll = w.roll.p;
+        sa.rbw = p.rec_band_width; sa.cand_cap = w.cand_cap; sa.dir_words = dir_words; sa.cells = d_cells;
+        SeedArgs se{gd, w.state.p, chunk, mode};
+        if (mode == RG_MODE_PATHWISE) {
+            SweepArgs f = sa;
+            f.rev = 0; f.track_best = 0; f.dirs = w.fdirs.p; f.dirs_stride = fdirs_stride; f.count_cells = 1;
+            TIMED(T, "k_sweep_fwd", launch_sweep(f, chunk, C, lds, stream));
+            TIMED(T, "k_seed", launch_seed(se, stream));
+        } else {
+            SweepArgs f1 = sa;
+            f1.rev = 0; f1.track_best = 1; f1.colmax_out = w.mf.p; f1.count_cells = 0;
+            TIMED(T, "k_sweep_fwd_colmax", launch_sweep(f1, chunk, C, lds, stream));
+            TIMED(T, "k_seed", launch_seed(se, stream));
+            ThrArgs t1{w.state.p, w.mf.p, w.thr.p, wpad, p.base_rec_cost};
+            TIMED(T, "k_threshold", launch_threshold(t1, chunk, stream));
+            SweepArgs r = sa;
+            r.rev = 1; r.track_best = 1; r.thr = w.thr.p; r.colmax_out = w.wr.p; r.cand = w.rcand.p; r.ncand_out = w.nr.p;
+            r.dirs = w.rdirs.p; r.dirs_stride = rdirs_stride; r.count_cells = 1;
+            TIMED(T, "k_sweep_rev", launch_sweep(r, chunk, C, lds, stream));
+            ThrArgs t2{w.state.p, w.wr.p, w.thr.p, wpad, p.base_rec_cost};
+            TIMED(T, "k_threshold", launch_threshold(t2, chunk, stream));
+            SweepArgs f2 = sa;
+            f2.rev = 0; f2.track_best = 1; f2.thr = w.thr.p; f2.cand = w.fcand.p; f2.ncand_out = w.nf.p;
+            f2.dirs = w.fdirs.p; f2.dirs_stride = fdirs_stride; f2.count_cells = 1;
+            TIMED(T, "k_sweep_fwd", launch_sweep(f2, chunk, C, lds, stream));
+            SearchArgs sr{gd, w.state.p, w.fcand.p, w.rcand.p, w.nf.p, w.nr.p, w.ridx.p, w.cand_cap, wpad, p.base_rec_cost,
+                          p.multi_rec_cost};
+            TIMED(T, "k_search", launch_search(sr, chunk, stream));
+            // candidate-list overflow: regrow and redo this chunk
+            if ((rc = T.collect(stats))) return rc;
+            std::vector<unsigned> hn(chunk), hr(chunk);
+            HIPCHK(hipMemcpy(hn.data(), w.nf.p, sizeof(unsigned) * chunk, hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpy(hr.data(), w.nr.p, sizeof(unsigned) * chunk, hipMemcpyDeviceToHost));
+            unsigned need = 0;
+            for (int i = 0; i < chunk; ++i) need = std::max(need, std::max(hn[i], hr[i]));
+            if (need > w.cand_cap) {
+                const unsigned long long full = (unsigned long long)L * wpad;
+                if (w.cand_cap >= full) return fail(RG_ERR_CAPACITY, "candidate list overflow at full size");
+                unsigned long long nc = w.cand_cap;
+                while (nc < need) nc *= 2;
+                w.cand_cap = (unsigned)std::min<unsigned long long>(nc, full);
+                HIPCHK(hipMemcpy(d_cells, &cells_done, sizeof cells_done, hipMemcpyHostToDevice));
+                continue;
+            }
+        }
+        LayerArgs la;
+        memset(&la, 0, sizeof la);
+        la.g = gd; la.sc = sa.sc; la.reads = d_reads; la.read_off = off; la.state = w.state.p; la.dir_words = dir_words;
+        la.layer_stride = layer_stride; la.fpoff = w.fpoff.p; la.fprow = w.fprow.p; la.fpslot = w.fpslot.p;
+        la.rpoff = w.rpoff.p; la.rprow = w.rprow.p; la.rpslot = w.rpslot.p;
+        la.rev = 0; la.dirs = w.fdirs.p; la.dirs_stride = fdirs_stride; la.layer = w.flayer.p;
+        TIMED(T, "k_layer_fwd", launch_layer(la, chunk, C, stream));
+        if (mode == RG_MODE_RECOMBINATION) {
+            la.rev = 1; la.dirs = w.rdirs.p; la.dirs_stride = rdirs_stride; la.layer = w.rlayer.p;
+            TIMED(T, "k_layer_rev", launch_layer(la, chunk, C, stream));
+        }
+        TraceArgs ta;
+        memset(&ta, 0, sizeof ta);
+        ta.g = gd; ta.sc = sa.sc; ta.reads = d_reads; ta.read_off = off; ta.state = w.state.p; ta.rec = d_rec + done;
+        ta.ops = d_ops + (long long)done * ops_stride; ta.ops_stride = ops_stride; ta.flayer = w.flayer.p;
+        ta.rlayer = w.rlayer.p; ta.layer_stride = layer_stride; ta.fpoff = w.fpoff.p; ta.fprow = w.fprow.p;
+        ta.rpoff = w.rpoff.p; ta.rprow = w.rprow.p; ta.nreads = chunk; ta.mode = mode;
+        TIMED(T, "k_trace", launch_trace(ta, C, stream));
+        if ((rc = T.collect(stats))) return rc;
+        HIPCHK(hipMemcpy(&cells_done, d_cells, sizeof cells_done, hipMemcpyDeviceToHost));
+        done += chunk;
+    }
+    return RG_OK;
 }
-void launch_m2(const struct PoaArgs&, hipStream_t) {}
-void launch_m0_scalar(const struct PoaArgs&, hipStream_t) {}
+
 }  // namespace rg

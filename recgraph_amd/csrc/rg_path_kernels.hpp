@@ -1,0 +1,118 @@
+// Argument blocks of the pathwise kernels (rg_pathwise.hip) shared with the driver.
+#pragma once
+#include "rg_path_args.hpp"
+
+namespace rg {
+
+// per-read scalar state carried between the kernels of one batch
+struct ReadState {
+    uint32_t status;
+    int s0;            // best no-recombination score (seed of the search) / m4 best score
+    int seed_path;
+    int end_row;       // sink row of the chosen path
+    int fwd_path, rev_path, fen, rsn, rec_col, displacement;
+    float fscore;
+    int pad;
+    int sink_val[64];  // A[sink row][n][k]
+};
+
+// one entry of the recombination candidate lists: best member of (row, col) that can still matter
+struct Cand {
+    int row, col, val, path;
+};
+
+struct SweepArgs {
+    PathGraphDev g;
+    DevScores sc;
+    const uint8_t* reads;
+    const long long* read_off;
+    const uint8_t* bad;
+    ReadState* state;
+    int* roll;                 // [reads][P][wpad] rolling rows when they do not fit LDS
+    int rev;                   // 0 forward sweep, 1 reverse sweep
+    int track_best;            // maintain the best member per (row, col) (m8)
+    const int* thr;            // [reads][wpad] emission thresholds by real column, or null
+    float rbw;                 // -B: columns outside the recombination band never emit
+    int* colmax_out;           // [reads][wpad] per-column maximum of the best members, or null
+    Cand* cand;                // [reads][cand_cap] or null
+    unsigned cand_cap;
+    unsigned* ncand_out;
+    uint32_t* dirs;            // [reads][dirs_stride] direction words or null
+    long long dirs_stride;
+    int dir_words;             // u32 words per (row, group) slot
+    unsigned long long* cells;
+    int count_cells;
+    int oob;                   // unused (computed per read from rbw)
+};
+
+struct SeedArgs {
+    PathGraphDev g;
+    ReadState* state;
+    int nreads;
+    int mode;
+};
+
+struct ThrArgs {
+    const ReadState* state;
+    const int* colmax;
+    int* thr;
+    int wpad;
+    int brc;
+};
+
+struct SearchArgs {
+    PathGraphDev g;
+    ReadState* state;
+    const Cand* fcand;
+    const Cand* rcand;
+    const unsigned* nf;
+    const unsigned* nr;
+    unsigned* ridx;
+    unsigned cand_cap;
+    int wpad;
+    int brc;
+    float mrc;
+};
+
+struct LayerArgs {
+    PathGraphDev g;
+    DevScores sc;
+    const uint8_t* reads;
+    const long long* read_off;
+    const ReadState* state;
+    int rev;
+    const uint32_t* dirs;
+    long long dirs_stride;
+    int dir_words;
+    int* layer;                // [reads][layer_stride]
+    long long layer_stride;
+    const int* fpoff; const int* fprow; const int* fpslot;   // rows of every path, forward order
+    const int* rpoff; const int* rprow; const int* rpslot;   // rows of every path, reverse order
+};
+
+struct TraceArgs {
+    PathGraphDev g;
+    DevScores sc;
+    const uint8_t* reads;
+    const long long* read_off;
+    ReadState* state;
+    DevRecord* rec;
+    uint8_t* ops;
+    long long ops_stride;
+    const int* flayer;
+    const int* rlayer;
+    long long layer_stride;
+    const int* fpoff; const int* fprow;
+    const int* rpoff; const int* rprow;
+    int nreads;
+    int mode;
+};
+
+void launch_sweep(const SweepArgs& a, int nreads, int C, bool lds, hipStream_t s);
+void launch_seed(const SeedArgs& a, hipStream_t s);
+void launch_threshold(const ThrArgs& a, int nreads, hipStream_t s);
+void launch_search(const SearchArgs& a, int nreads, hipStream_t s);
+void launch_layer(const LayerArgs& a, int nreads, int C, hipStream_t s);
+void launch_trace(const TraceArgs& a, int C, hipStream_t s);
+
+}  // namespace rg

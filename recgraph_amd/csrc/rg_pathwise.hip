@@ -1,0 +1,709 @@
+// Pathwise DP kernels for gfx950 (-m 4 and -m 8): sweep, recombination search, layer rebuild,
+// traceback.  Semantics: SURVEY Appendix A.4-A.6 (absolute-score form of
+// pathwise_alignment.rs:5-340 and pathwise_alignment_recombination.rs:129-873).
+//
+// Mapping (one wavefront per read, no inter-wave synchronisation):
+//   * lane t owns the C consecutive DP columns t*C .. t*C+C-1 (C = ceil(columns/64));
+//   * every path keeps ONE rolling row of absolute scores, stored as [q][lane] (q = column inside the
+//     lane's chunk) so that the 64 lanes of a load/store touch 64 consecutive words: conflict-free in
+//     LDS, fully coalesced in HBM.  Rows live in LDS when P*64*C*4 bytes fit (kLds), else in HBM;
+//   * per (row, edge group): the group's alpha path runs the max-plus recurrence as a lane-local
+//     serial scan + one wave-level prefix-max (the "left" dependency), giving a 2-bit direction per
+//     column; every member path then follows those directions with its own values.  Runs of L are
+//     resolved with a fill-forward (lane-local) + one cross-lane fetch from the nearest lane that
+//     holds a non-L column;
+//   * the reverse sweep is the same code on mirrored columns c' = n - j.
+// Direction words (2 bits/column, one u32 per lane for C = 16) are the only per-cell data written
+// to HBM; the recombination search consumes a compact candidate list instead of the two
+// L x (n+1) x P matrices of the reference.
+#include "rg_path_kernels.hpp"
+
+namespace rg {
+
+constexpr int NEG = INT32_MIN / 4;
+
+template <bool kLds>
+struct Rows {
+    int* base;  // HBM rows of this read (kLds == false)
+    __device__ __forceinline__ int ld(int k, int idx, int wpad) const;
+    __device__ __forceinline__ void st(int k, int idx, int wpad, int v) const;
+};
+extern __shared__ __attribute__((aligned(16))) int g_lds[];
+template <>
+__device__ __forceinline__ int Rows<true>::ld(int k, int idx, int wpad) const { return g_lds[k * wpad + idx]; }
+template <>
+__device__ __forceinline__ void Rows<true>::st(int k, int idx, int wpad, int v) const { g_lds[k * wpad + idx] = v; }
+template <>
+__device__ __forceinline__ int Rows<false>::ld(int k, int idx, int wpad) const { return base[(long long)k * wpad + idx]; }
+template <>
+__device__ __forceinline__ void Rows<false>::st(int k, int idx, int wpad, int v) const { base[(long long)k * wpad + idx] = v; }
+
+__device__ __forceinline__ int wave_excl_max(int v, int lane) {
+    int inc = wave_incl_max(v, lane);
+    int e = __shfl_up(inc, 1, WAVE);
+    return lane == 0 ? NEG : e;
+}
+
+// One DP sweep over the whole graph for one read.
+template <int C, bool kLds>
+__global__ __launch_bounds__(64) void k_sweep(SweepArgs a) {
+    const int rd = blockIdx.x;
+    const int lane = threadIdx.x;
+    const PathGraphDev& g = a.g;
+    const int P = g.P, L = g.L;
+    const int wpad = C * WAVE;
+    ReadState* rs = a.state + rd;
+    const long long ro = a.read_off[rd];
+    const int n = (int)(a.read_off[rd + 1] - ro);
+    if (a.bad[rd] || n + 1 > wpad) {
+        if (lane == 0 && !a.rev) { rs->status = a.bad[rd] ? ST_BAD_BASE : ST_WOULD_PANIC; }
+        return;
+    }
+    const uint8_t* read = a.reads + ro - 1;  // read[1..n]
+    const bool rev = a.rev;
+    const int ncols = rev ? n : n + 1;  // mirrored columns of the reverse sweep: c' = n - j, j = n..1
+    const int GAP = 5;
+    // score table in LDS (after the rolling rows when they live there)
+    int* sct = g_lds + (kLds ? P * wpad : 0);
+    if (lane < 36) sct[lane] = a.sc.t[lane];
+    __syncthreads();
+
+    Rows<kLds> rows{kLds ? nullptr : a.roll + (long long)rd * P * wpad};
+    // per-column constants of this lane
+    int er[C];       // read base facing column c (forward: read[c]; reverse: r_seq[j] = read[j+1], j = n - c)
+    int GP[C];       // prefix sums of the read-gap cost up to column c
+    int thr[C];      // emission threshold per column (NEG = never)
+    bool act[C];
+    // recombination band (pathwise_alignment_recombination.rs:805-808)
+    const int oob = max((int)((float)(n + 1) * (1.0f - a.rbw) / 2.0f), 1);
+    {
+        int run = 0;
+#pragma unroll
+        for (int q = 0; q < C; ++q) {
+            const int c = lane * C + q;
+            act[q] = c < ncols;
+            int code = 4;
+            if (c >= 1 && c < ncols) code = rev ? read[n - c + 1] : read[c];
+            er[q] = code;
+            const int gc = (c >= 1 && c < ncols) ? sct[code * 6 + GAP] : 0;
+            run += gc;
+            GP[q] = run;
+        }
+        const int pre = wave_incl_sum(run, lane) - run;
+#pragma unroll
+        for (int q = 0; q < C; ++q) GP[q] += pre;
+#pragma unroll
+        for (int q = 0; q < C; ++q) {
+            const int c = lane * C + q;
+            const int j = rev ? n - c : c;
+            thr[q] = INT32_MAX;
+            if (a.thr && act[q] && j >= oob && j < n + 1 - oob) thr[q] = a.thr[(long long)rd * wpad + j];
+        }
+    }
+    // start rows: row 0 (forward) / row L-1 (reverse) is the gap-only row, identical for every path
+    for (int k = 0; k < P; ++k) {
+#pragma unroll
+        for (int q = 0; q < C; ++q) rows.st(k, q * WAVE + lane, wpad, act[q] ? GP[q] : NEG);
+    }
+    __syncthreads();
+
+    int colmax[C];
+#pragma unroll
+    for (int q = 0; q < C; ++q) colmax[q] = NEG;
+    unsigned ncand = 0;
+    unsigned long long cells = 0;
+    Cand* cand = a.cand ? a.cand + (long long)rd * a.cand_cap : nullptr;
+    const int* goff = rev ? g.rgoff : g.fgoff;
+    const GroupDesc* groups = rev ? g.rgroups : g.fgroups;
+    uint32_t* dirs = a.dirs ? a.dirs + (long long)rd * a.dirs_stride : nullptr;
+
+    for (int step = 1; step + 1 < L; ++step) {
+        const int i = rev ? L - 1 - step : step;
+        const int li = g.lnz[i];
+        const int g_i = sct[li * 6 + GAP];
+        int s[C];
+#pragma unroll
+        for (int q = 0; q < C; ++q) s[q] = sct[li * 6 + er[q]];
+        int bestv[C], bestk[C];
+#pragma unroll
+        for (int q = 0; q < C; ++q) { bestv[q] = NEG; bestk[q] = -1; }
+
+        for (int gi = goff[i]; gi < goff[i + 1]; ++gi) {
+            const GroupDesc gd = groups[gi];
+            const int ga = (int)gd.ga;
+            // ---- group alpha: recurrence + directions ----
+            int old[C];
+#pragma unroll
+            for (int q = 0; q < C; ++q) old[q] = rows.ld(ga, q * WAVE + lane, wpad);
+            int prevcol = __shfl_up(old[C - 1], 1, WAVE);
+            unsigned dmask = 0, lmask = 0;  // bit q: direction D / L of column q
+            int x[C];                        // candidate minus GP
+            int runmax = NEG;
+            int exl[C];
+#pragma unroll
+            for (int q = 0; q < C; ++q) {
+                const int c = lane * C + q;
+                const int om1 = q == 0 ? prevcol : old[q - 1];
+                int du;
+                if (c == 0) { du = old[q] + g_i; }  // border column: gap in the graph only
+                else {
+                    const int d = om1 + s[q], u = old[q] + g_i;
+                    if (d >= u) { du = d; dmask |= 1u << q; } else du = u;   // priority D > U
+                }
+                if (!act[q]) du = NEG;
+                x[q] = du - GP[q];
+                exl[q] = runmax;
+                runmax = max(runmax, x[q]);
+            }
+            const int carry = wave_excl_max(runmax, lane);
+            int nonl_last = NEG;  // y (= value - GP) at this lane's last non-L column
+            bool any_nonl = false;
+            int newv[C];
+#pragma unroll
+            for (int q = 0; q < C; ++q) {
+                const int pm = max(carry, exl[q]);
+                const bool isl = pm > x[q];          // L only when strictly better (priority D > U > L)
+                if (isl) lmask |= 1u << q;
+                const int y = isl ? pm : x[q];
+                if (!isl) { nonl_last = x[q]; any_nonl = true; }
+                newv[q] = y + GP[q];
+            }
+            // nearest lane to the left that owns a non-L column (fill-forward source for member paths)
+            int src = wave_incl_max(any_nonl ? lane : -1, lane);
+            src = __shfl_up(src, 1, WAVE);
+            if (lane == 0) src = 0;
+            (void)nonl_last;
+            // store alpha row, track best-of-row
+#pragma unroll
+            for (int q = 0; q < C; ++q) {
+                rows.st(ga, q * WAVE + lane, wpad, act[q] ? newv[q] : NEG);
+                if (newv[q] > bestv[q] || (newv[q] == bestv[q] && ga > bestk[q])) { bestv[q] = newv[q]; bestk[q] = ga; }
+            }
+            if (dirs) {
+                // 2 bits per column: 1 = D, 2 = U, 3 = L
+                static_assert(C <= 16 || C == 32, "direction packing");
+                if (C <= 16) {
+                    uint32_t wv = 0;
+#pragma unroll
+                    for (int q = 0; q < C; ++q) {
+                        const uint32_t dcode = (lmask >> q) & 1 ? 3u : ((dmask >> q) & 1 ? 1u : 2u);
+                        wv |= dcode << (2 * q);
+                    }
+                    dirs[(long long)gd.slot * a.dir_words + lane] = wv;
+                } else {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        uint32_t wv = 0;
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) {
+                            const int qq = h * 16 + q;
+                            const uint32_t dcode = (lmask >> qq) & 1 ? 3u : ((dmask >> qq) & 1 ? 1u : 2u);
+                            wv |= dcode << (2 * q);
+                        }
+                        dirs[(long long)gd.slot * a.dir_words + h * WAVE + lane] = wv;
+                    }
+                }
+            }
+            // ---- other members follow the alpha's directions with their own values ----
+            unsigned long long rest = gd.mask & ~(1ull << ga);
+            cells += (unsigned long long)__popcll(gd.mask);
+            while (rest) {
+                const int k = __builtin_ctzll(rest);
+                rest &= rest - 1;
+                int ok[C];
+#pragma unroll
+                for (int q = 0; q < C; ++q) ok[q] = rows.ld(k, q * WAVE + lane, wpad);
+                const int pk = __shfl_up(ok[C - 1], 1, WAVE);
+                int y[C];
+                int last = NEG;
+#pragma unroll
+                for (int q = 0; q < C; ++q) {
+                    const int om1 = q == 0 ? pk : ok[q - 1];
+                    const int base = ((dmask >> q) & 1) ? om1 + s[q] : ok[q] + g_i;
+                    y[q] = base - GP[q];
+                    if (!((lmask >> q) & 1)) last = y[q];
+                }
+                const int cin = __shfl(last, src, WAVE);  // y of the last non-L column before this lane
+                int cur = cin;
+#pragma unroll
+                for (int q = 0; q < C; ++q) {
+                    if ((lmask >> q) & 1) y[q] = cur; else cur = y[q];
+                    const int v = act[q] ? y[q] + GP[q] : NEG;
+                    rows.st(k, q * WAVE + lane, wpad, v);
+                    if (v > bestv[q] || (v == bestv[q] && k > bestk[q])) { bestv[q] = v; bestk[q] = k; }
+                }
+            }
+            // no barrier: every lane only ever re-reads the row words it wrote itself
+        }
+        // ---- best member of the row per column: feeds the recombination search ----
+        if (a.track_best) {
+            const int knm = g.knm[i];
+            unsigned emask = 0;
+#pragma unroll
+            for (int q = 0; q < C; ++q) {
+                // argmax over ALL P entries where non-members hold 0: usable only if the winner is a member
+                const bool valid = act[q] && bestk[q] >= 0 && (knm < 0 || bestv[q] > 0 || (bestv[q] == 0 && bestk[q] > knm));
+                if (valid) {
+                    colmax[q] = max(colmax[q], bestv[q]);
+                    if (bestv[q] >= thr[q]) emask |= 1u << q;
+                }
+            }
+            if (cand && __any(emask != 0)) {
+                const int cnt = __popc(emask);
+                const int incl = wave_incl_sum(cnt, lane);
+                const int total = __shfl(incl, WAVE - 1, WAVE);
+                unsigned pos = ncand + (unsigned)(incl - cnt);
+#pragma unroll
+                for (int q = 0; q < C; ++q) {
+                    if ((emask >> q) & 1) {
+                        if (pos < a.cand_cap) {
+                            const int c = lane * C + q;
+                            Cand cd;
+                            cd.row = i; cd.col = rev ? n - c : c; cd.val = bestv[q]; cd.path = bestk[q];
+                            cand[pos] = cd;
+                        }
+                        ++pos;
+                    }
+                }
+                ncand += (unsigned)total;
+            }
+        }
+    }
+
+    // ---- outputs ----
+    if (a.colmax_out) {
+#pragma unroll
+        for (int q = 0; q < C; ++q) {
+            const int c = lane * C + q;
+            if (act[q]) a.colmax_out[(long long)rd * wpad + (rev ? n - c : c)] = colmax[q];
+        }
+    }
+    if (a.ncand_out && lane == 0) a.ncand_out[rd] = ncand;
+    __syncthreads();
+    if (!rev) {
+        // value of every path at its sink row, column n (lane/slot that owns column n)
+        const int cn = n, ql = cn % C, ln = cn / C;
+        for (int k = lane; k < P; k += WAVE) rs->sink_val[k] = rows.ld(k, ql * WAVE + ln, wpad);
+        if (lane == 0 && a.count_cells) atomicAdd(a.cells, cells * (unsigned long long)(n + 1));
+    } else if (lane == 0 && a.count_cells) {
+        atomicAdd(a.cells, cells * (unsigned long long)(n + 1));
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// After the forward sweep: seed / best path (pathwise_alignment.rs:305-325,
+// pathwise_alignment_recombination.rs:775-803).  One thread per read.
+__global__ void k_seed(SeedArgs a) {
+    const int rd = blockIdx.x * blockDim.x + threadIdx.x;
+    if (rd >= a.nreads) return;
+    ReadState* rs = a.state + rd;
+    if (rs->status & (ST_BAD_BASE | ST_WOULD_PANIC)) return;
+    const PathGraphDev& g = a.g;
+    const int L = g.L, P = g.P;
+    if (a.mode == RG_MODE_PATHWISE) {
+        // results[k] = A[sink(k)][n][k] for paths registered at F, 0 otherwise; max of (score, path id)
+        int best = 0, bp = 0, bend = 0;
+        bool first = true;
+        for (int k = 0; k < P; ++k) {
+            int v = 0, end = 0;
+            for (int e = g.eoff[L - 1]; e < g.eoff[L]; ++e)
+                if ((g.emask[e] >> k) & 1) { v = rs->sink_val[k]; end = g.epred[e]; }
+            if (first || v >= best) { best = v; bp = k; bend = end; first = false; }
+        }
+        rs->s0 = best; rs->seed_path = bp; rs->end_row = bend; rs->fwd_path = bp; rs->rev_path = bp;
+    } else {
+        // strict '<' over F's predecessors (stored order) then paths ascending: lowest id on ties
+        bool have = false; int mx = 0, bp = 0;
+        for (int e = g.eoff[L - 1]; e < g.eoff[L]; ++e)
+            for (int k = 0; k < P; ++k)
+                if ((g.emask[e] >> k) & 1) {
+                    const int v = rs->sink_val[k];
+                    if (!have || mx < v) { mx = v; bp = k; have = true; }
+                }
+        int end = 0;
+        for (int e = g.eoff[L - 1]; e < g.eoff[L]; ++e) if ((g.emask[e] >> bp) & 1) end = g.epred[e];
+        rs->s0 = mx; rs->seed_path = bp; rs->end_row = end; rs->fwd_path = bp; rs->rev_path = bp;
+        if (!have) rs->status |= ST_WOULD_PANIC;
+    }
+}
+
+// thr[j] = S0 + R - colmax[j]: a cell can be part of a winning / tying recombination only if
+// value + (best partner of the column) - R >= S0 (f32 rounding is monotone)
+__global__ void k_threshold(ThrArgs a) {
+    const int rd = blockIdx.y;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= a.wpad) return;
+    const ReadState* rs = a.state + rd;
+    const long long o = (long long)rd * a.wpad + j;
+    const int cm = a.colmax[o];
+    a.thr[o] = cm <= NEG ? INT32_MAX : rs->s0 + a.brc - cm;
+}
+
+// ---------------------------------------------------------------------------------
+// Recombination search over the candidate lists (pathwise_alignment_recombination.rs:804-864).
+// The sequential scan of the reference, lexicographic in (column, forward row, reverse row), keeps
+// "the first candidate with the maximum value for which `cond` holds, else the first candidate with
+// that value; the no-recombination seed is the earliest, cond = false" (SURVEY A.5 item 5): a total
+// order, so the scan is evaluated as a parallel reduction with key (score, cond, -position).
+struct SearchKey {
+    float score;
+    int cond;
+    long long order;  // smaller = earlier in the reference's scan; seed = -1
+    int fi, ri;       // candidate indices
+};
+__device__ __forceinline__ bool key_better(const SearchKey& a, const SearchKey& b) {
+    if (a.score != b.score) return a.score > b.score;
+    if (a.cond != b.cond) return a.cond > b.cond;
+    return a.order < b.order;
+}
+
+__global__ __launch_bounds__(64) void k_search(SearchArgs a) {
+    const int rd = blockIdx.x;
+    const int lane = threadIdx.x;
+    ReadState* rs = a.state + rd;
+    if (rs->status & (ST_BAD_BASE | ST_WOULD_PANIC)) return;
+    const PathGraphDev& g = a.g;
+    const long long L = g.L;
+    const Cand* fc = a.fcand + (long long)rd * a.cand_cap;
+    const Cand* rc = a.rcand + (long long)rd * a.cand_cap;
+    const unsigned nf = a.nf[rd], nr = a.nr[rd];
+    if (nf > a.cand_cap || nr > a.cand_cap) {
+        if (lane == 0) rs->status |= ST_OVERFLOW;
+        return;
+    }
+    const int wpad = a.wpad;
+    // bucket the reverse candidates by column (counting sort through LDS histogram + HBM index list)
+    extern __shared__ int sh[];
+    int* hist = sh;            // wpad + 1
+    for (int j = lane; j <= wpad; j += WAVE) hist[j] = 0;
+    __syncthreads();
+    for (unsigned t = lane; t < nr; t += WAVE) atomicAdd(&hist[rc[t].col + 1], 1);
+    __syncthreads();
+    // exclusive scan of hist (serial per wave chunk; wpad <= 2048)
+    {
+        int carry = 0;
+        for (int base = 0; base <= wpad; base += WAVE) {
+            const int j = base + lane;
+            const int v = j <= wpad ? hist[j] : 0;
+            const int inc = wave_incl_sum(v, lane) + carry;
+            if (j <= wpad) hist[j] = inc;
+            carry = __shfl(inc, WAVE - 1, WAVE);
+        }
+    }
+    __syncthreads();
+    // hist[j] = number of reverse candidates with col < j  => bucket of column j is [hist[j], hist[j+1])
+    unsigned* ridx = a.ridx + (long long)rd * a.cand_cap;
+    int* fill = sh + (wpad + 1);  // wpad + 1 cursors
+    for (int j = lane; j <= wpad; j += WAVE) fill[j] = 0;
+    __syncthreads();
+    for (unsigned t = lane; t < nr; t += WAVE) {
+        const int c = rc[t].col;
+        const int p = atomicAdd(&fill[c], 1);
+        ridx[hist[c] + p] = t;
+    }
+    __syncthreads();
+    __threadfence_block();
+
+    const float brc_f = (float)a.brc;
+    SearchKey best;
+    best.score = (float)rs->s0; best.cond = 0; best.order = -1; best.fi = -1; best.ri = -1;
+    // lanes take forward candidates; each scans the reverse bucket of its column
+    for (unsigned base = 0; base < nf; base += WAVE) {
+        const unsigned t = base + lane;
+        if (t < nf) {
+            const Cand f = fc[t];
+            const int b0 = hist[f.col], b1 = hist[f.col + 1];
+            const unsigned long long idf = g.node_id[f.row];
+            const int cond_f = g.seglast[f.row];
+            for (int u = b0; u < b1; ++u) {
+                const unsigned ri = ridx[u];
+                const Cand r = rc[ri];
+                // integer bound first: (m + w) - R >= S0 is necessary for any update
+                if (f.val + r.val - a.brc < rs->s0) continue;
+                if (g.node_id[r.row] == idf) continue;
+                if (f.path == r.path) continue;
+                const int disp = abs(g.dfs[f.row] - g.dfs[r.row]) + abs(g.dfe[f.row] - g.dfe[r.row]);
+                // three separately rounded f32 operations, no contraction (:840-842)
+                const float prod = __fmul_rn(a.mrc, (float)disp);
+                const float penalty = __fadd_rn(brc_f, prod);
+                const float sc = __fsub_rn((float)(f.val + r.val), penalty);
+                SearchKey k;
+                k.score = sc;
+                k.cond = cond_f && g.segfirst[r.row];
+                k.order = ((long long)f.col * L + f.row) * L + r.row;
+                k.fi = (int)t; k.ri = (int)ri;
+                if (key_better(k, best)) best = k;
+            }
+        }
+    }
+    // wave reduction of the key
+    for (int d = WAVE / 2; d >= 1; d >>= 1) {
+        SearchKey o;
+        o.score = __shfl_xor(best.score, d, WAVE);
+        o.cond = __shfl_xor(best.cond, d, WAVE);
+        o.order = __shfl_xor(best.order, d, WAVE);
+        o.fi = __shfl_xor(best.fi, d, WAVE);
+        o.ri = __shfl_xor(best.ri, d, WAVE);
+        if (key_better(o, best)) best = o;
+    }
+    if (lane == 0) {
+        if (best.fi < 0) {
+            rs->fwd_path = rs->seed_path; rs->rev_path = rs->seed_path; rs->fen = 0; rs->rsn = 0; rs->rec_col = 0;
+            rs->fscore = (float)rs->s0; rs->displacement = 0;
+        } else {
+            const Cand f = fc[best.fi], r = rc[best.ri];
+            rs->fwd_path = f.path; rs->rev_path = r.path; rs->fen = f.row; rs->rsn = r.row; rs->rec_col = f.col;
+            rs->fscore = best.score;
+            rs->displacement = abs(g.dfs[f.row] - g.dfs[r.row]) + abs(g.dfe[f.row] - g.dfe[r.row]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// Rebuild the absolute layer of one path from the direction words (rows of that path only).
+// layer[idx] for idx = 0 (start row) .. number of path rows, stored [q][lane] like the rolling rows.
+template <int C>
+__global__ __launch_bounds__(64) void k_layer(LayerArgs a) {
+    const int rd = blockIdx.x;
+    const int lane = threadIdx.x;
+    const PathGraphDev& g = a.g;
+    const ReadState* rs = a.state + rd;
+    if (rs->status & (ST_BAD_BASE | ST_WOULD_PANIC | ST_OVERFLOW)) return;
+    const bool rev = a.rev;
+    const int path = rev ? rs->rev_path : rs->fwd_path;
+    if (rev && rs->fwd_path == rs->rev_path) return;  // no recombination: reverse layer not needed
+    const int wpad = C * WAVE;
+    const long long ro = a.read_off[rd];
+    const int n = (int)(a.read_off[rd + 1] - ro);
+    const uint8_t* read = a.reads + ro - 1;
+    const int ncols = rev ? n : n + 1;
+    const int GAP = 5;
+    __shared__ int sct[36];
+    if (lane < 36) sct[lane] = a.sc.t[lane];
+    __syncthreads();
+    int er[C], GP[C];
+    bool act[C];
+    {
+        int run = 0;
+#pragma unroll
+        for (int q = 0; q < C; ++q) {
+            const int c = lane * C + q;
+            act[q] = c < ncols;
+            int code = 4;
+            if (c >= 1 && c < ncols) code = rev ? read[n - c + 1] : read[c];
+            er[q] = code;
+            run += (c >= 1 && c < ncols) ? sct[code * 6 + GAP] : 0;
+            GP[q] = run;
+        }
+        const int pre = wave_incl_sum(run, lane) - run;
+#pragma unroll
+        for (int q = 0; q < C; ++q) GP[q] += pre;
+    }
+    int* layer = a.layer + (long long)rd * a.layer_stride;
+    int cur[C];
+#pragma unroll
+    for (int q = 0; q < C; ++q) { cur[q] = act[q] ? GP[q] : NEG; layer[q * WAVE + lane] = cur[q]; }
+    const int* prow = rev ? a.rprow : a.fprow;
+    const int* pslot = rev ? a.rpslot : a.fpslot;
+    const int* poff = rev ? a.rpoff : a.fpoff;
+    const uint32_t* dirs = a.dirs + (long long)rd * a.dirs_stride;
+    const int nrows = poff[path + 1] - poff[path];
+    for (int t = 0; t < nrows; ++t) {
+        const int i = prow[poff[path] + t];
+        const int slot = pslot[poff[path] + t];
+        const int li = g.lnz[i];
+        const int g_i = sct[li * 6 + GAP];
+        unsigned dmask = 0, lmask = 0;
+        if (C <= 16) {
+            const uint32_t wv = dirs[(long long)slot * a.dir_words + lane];
+#pragma unroll
+            for (int q = 0; q < C; ++q) {
+                const uint32_t dc = (wv >> (2 * q)) & 3u;
+                if (dc == 1u) dmask |= 1u << q;
+                if (dc == 3u) lmask |= 1u << q;
+            }
+        } else {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const uint32_t wv = dirs[(long long)slot * a.dir_words + h * WAVE + lane];
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const uint32_t dc = (wv >> (2 * q)) & 3u;
+                    if (dc == 1u) dmask |= 1u << (h * 16 + q);
+                    if (dc == 3u) lmask |= 1u << (h * 16 + q);
+                }
+            }
+        }
+        unsigned actmask = 0;
+#pragma unroll
+        for (int q = 0; q < C; ++q) if (act[q]) actmask |= 1u << q;
+        const bool any_nonl = ((~lmask) & actmask) != 0;
+        int src = wave_incl_max(any_nonl ? lane : -1, lane);
+        src = __shfl_up(src, 1, WAVE);
+        if (lane == 0) src = 0;
+        const int pk = __shfl_up(cur[C - 1], 1, WAVE);
+        int y[C];
+        int last = NEG;
+#pragma unroll
+        for (int q = 0; q < C; ++q) {
+            const int om1 = q == 0 ? pk : cur[q - 1];
+            const int base = ((dmask >> q) & 1) ? om1 + sct[li * 6 + er[q]] : cur[q] + g_i;
+            y[q] = base - GP[q];
+            if (!((lmask >> q) & 1) && act[q]) last = y[q];
+        }
+        const int cin = __shfl(last, src, WAVE);
+        int run = cin;
+#pragma unroll
+        for (int q = 0; q < C; ++q) {
+            if ((lmask >> q) & 1) y[q] = run; else run = y[q];
+            cur[q] = act[q] ? y[q] + GP[q] : NEG;
+            layer[(long long)(t + 1) * wpad + q * WAVE + lane] = cur[q];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// Traceback on the rebuilt layers (pathwise_alignment_output.rs:32-138, recombination_output.rs:
+// 391-470, 480-557, 659-736).  One lane per read walks; ops only (rows are re-derived on the host).
+template <int C>
+__global__ __launch_bounds__(64) void k_trace(TraceArgs a) {
+    const int rd = blockIdx.x * blockDim.x + threadIdx.x;
+    if (rd >= a.nreads) return;
+    const PathGraphDev& g = a.g;
+    ReadState* rs = a.state + rd;
+    DevRecord* rec = a.rec + rd;
+    if (rs->status & (ST_BAD_BASE | ST_WOULD_PANIC | ST_OVERFLOW)) {
+        rec->status = rs->status; rec->n_ops = 0; rec->n_fwd_ops = 0; rec->score = 0;
+        return;
+    }
+    const int wpad = C * WAVE;
+    const long long ro = a.read_off[rd];
+    const int n = (int)(a.read_off[rd + 1] - ro);
+    const uint8_t* read = a.reads + ro - 1;
+    const int GAP = 5;
+    const int L = g.L;
+    uint8_t* ops = a.ops + (long long)rd * a.ops_stride;
+    int nops = 0;
+    const bool recomb = a.mode == RG_MODE_RECOMBINATION && rs->fwd_path != rs->rev_path;
+    auto at = [&](const int* layer, int idx, int c) { return layer[(long long)idx * wpad + (c % C) * WAVE + c / C]; };
+    const int* fl = a.flayer + (long long)rd * a.layer_stride;
+    // ---- forward walk from (row, j) back to the source on path fp ----
+    const int fp = rs->fwd_path;
+    const int fbeg = a.fpoff[fp], fnr = a.fpoff[fp + 1] - fbeg;
+    int start_row = recomb ? rs->fen : rs->end_row;
+    int j = recomb ? rs->rec_col : n;
+    // index of start_row among the rows of path fp (binary search; rows ascending)
+    int lo = 0, hi = fnr - 1, idx = -1;
+    while (lo <= hi) { int mid = (lo + hi) >> 1; int r = a.fprow[fbeg + mid]; if (r == start_row) { idx = mid; break; } if (r < start_row) lo = mid + 1; else hi = mid - 1; }
+    if (idx < 0) { rec->status = ST_WOULD_PANIC; rec->n_ops = 0; return; }
+    int t = idx + 1;  // layer index of the current row (0 = row 0)
+    const int score = at(fl, t, j);
+    while (t > 0 && j > 0) {
+        const int i = a.fprow[fbeg + t - 1];
+        const int li = g.lnz[i];
+        const int d = at(fl, t - 1, j - 1) + a.sc.t[li * 6 + read[j]];
+        const int u = at(fl, t - 1, j) + a.sc.t[li * 6 + GAP];
+        const int l = at(fl, t, j - 1) + a.sc.t[GAP * 6 + read[j]];   // key ('-', seq[j])
+        const int mx = max(max(d, u), l);
+        if (mx == d) { ops[nops++] = OP_D; t -= 1; j -= 1; }
+        else if (mx == u) { ops[nops++] = OP_U; t -= 1; }
+        else { ops[nops++] = OP_L; j -= 1; }
+    }
+    while (j > 0) { ops[nops++] = OP_L; j -= 1; }
+    while (t > 0) { ops[nops++] = OP_U; t -= 1; }
+    const int nfwd = nops;
+    if (recomb) {
+        // ---- reverse walk from (rsn, rec_col) forward to the sink on path rp ----
+        const int rp = rs->rev_path;
+        const int* rl = a.rlayer + (long long)rd * a.layer_stride;
+        const int rbeg = a.rpoff[rp], rnr = a.rpoff[rp + 1] - rbeg;
+        // rows of the reverse program are descending
+        int lo2 = 0, hi2 = rnr - 1, ridx = -1;
+        while (lo2 <= hi2) { int mid = (lo2 + hi2) >> 1; int r = a.rprow[rbeg + mid]; if (r == rs->rsn) { ridx = mid; break; } if (r > rs->rsn) lo2 = mid + 1; else hi2 = mid - 1; }
+        if (ridx < 0) { rec->status = ST_WOULD_PANIC; rec->n_ops = 0; return; }
+        int tt = ridx + 1;          // layer index (0 = row L-1)
+        int jj = rs->rec_col;       // real column; mirrored column c' = n - jj
+        // row L-1 of w stays delta-encoded in the reference (absolute_scores skips it): path 0 keeps its
+        // absolute value, every other path reads 0 (pathwise_alignment_recombination.rs:748)
+        auto wat = [&](int lidx, int col) -> int {
+            if (lidx == 0) return rp == 0 ? at(rl, 0, n - col) : 0;
+            return at(rl, lidx, n - col);
+        };
+        while (tt > 0 && jj < n) {
+            const int i = a.rprow[rbeg + tt - 1];
+            const int li = g.lnz[i];
+            const int rc = read[jj + 1];                       // r_seq[jj]
+            const int d = wat(tt - 1, jj + 1) + a.sc.t[li * 6 + rc];
+            const int u = wat(tt - 1, jj) + a.sc.t[li * 6 + GAP];
+            const int l = wat(tt, jj + 1) + a.sc.t[GAP * 6 + rc];
+            const int mx = max(max(d, u), l);
+            if (mx == d) { ops[nops++] = OP_D; tt -= 1; jj += 1; }
+            else if (mx == u) { ops[nops++] = OP_U; tt -= 1; }
+            else { ops[nops++] = OP_L; jj += 1; }
+        }
+        while (jj < n) { ops[nops++] = OP_L | OP_CONT; jj += 1; }
+        while (tt > 0) { ops[nops++] = OP_U | OP_CONT; tt -= 1; }
+        (void)L;
+    }
+    rec->status = rs->status;
+    rec->score = score;
+    rec->fscore = rs->fscore;
+    rec->end_row = start_row;
+    rec->end_col = n;
+    rec->stop_row = 0; rec->stop_col = 0;
+    rec->best_path = fp;
+    rec->rev_path = recomb ? rs->rev_path : fp;
+    rec->fen = rs->fen; rec->rsn = rs->rsn; rec->rec_col = rs->rec_col; rec->displacement = rs->displacement;
+    rec->n_ops = nops; rec->n_fwd_ops = nfwd;
+}
+
+// ---------------------------------------------------------------------------------
+// launchers
+template <int C>
+static void launch_sweep_c(const SweepArgs& a, int nreads, bool lds, hipStream_t s) {
+    const size_t sct_bytes = 64 * sizeof(int);
+    if (lds) {
+        const size_t bytes = (size_t)a.g.P * C * WAVE * sizeof(int) + sct_bytes;
+        (void)hipFuncSetAttribute((const void*)k_sweep<C, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        hipLaunchKernelGGL((k_sweep<C, true>), dim3(nreads), dim3(64), bytes, s, a);
+    } else {
+        hipLaunchKernelGGL((k_sweep<C, false>), dim3(nreads), dim3(64), sct_bytes, s, a);
+    }
+}
+void launch_sweep(const SweepArgs& a, int nreads, int C, bool lds, hipStream_t s) {
+    switch (C) {
+        case 4: launch_sweep_c<4>(a, nreads, lds, s); break;
+        case 8: launch_sweep_c<8>(a, nreads, lds, s); break;
+        case 16: launch_sweep_c<16>(a, nreads, lds, s); break;
+        default: launch_sweep_c<32>(a, nreads, lds, s); break;
+    }
+}
+void launch_seed(const SeedArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(k_seed, dim3((a.nreads + 63) / 64), dim3(64), 0, s, a);
+}
+void launch_threshold(const ThrArgs& a, int nreads, hipStream_t s) {
+    hipLaunchKernelGGL(k_threshold, dim3((a.wpad + 255) / 256, nreads), dim3(256), 0, s, a);
+}
+void launch_search(const SearchArgs& a, int nreads, hipStream_t s) {
+    const size_t bytes = (size_t)(2 * (a.wpad + 1)) * sizeof(int);
+    hipLaunchKernelGGL(k_search, dim3(nreads), dim3(64), bytes, s, a);
+}
+void launch_layer(const LayerArgs& a, int nreads, int C, hipStream_t s) {
+    switch (C) {
+        case 4: hipLaunchKernelGGL((k_layer<4>), dim3(nreads), dim3(64), 0, s, a); break;
+        case 8: hipLaunchKernelGGL((k_layer<8>), dim3(nreads), dim3(64), 0, s, a); break;
+        case 16: hipLaunchKernelGGL((k_layer<16>), dim3(nreads), dim3(64), 0, s, a); break;
+        default: hipLaunchKernelGGL((k_layer<32>), dim3(nreads), dim3(64), 0, s, a); break;
+    }
+}
+void launch_trace(const TraceArgs& a, int C, hipStream_t s) {
+    const dim3 grid((a.nreads + 63) / 64), blk(64);
+    switch (C) {
+        case 4: hipLaunchKernelGGL((k_trace<4>), grid, blk, 0, s, a); break;
+        case 8: hipLaunchKernelGGL((k_trace<8>), grid, blk, 0, s, a); break;
+        case 16: hipLaunchKernelGGL((k_trace<16>), grid, blk, 0, s, a); break;
+        default: hipLaunchKernelGGL((k_trace<32>), grid, blk, 0, s, a); break;
+    }
+}
+
+}  // namespace rg

@@ -1,0 +1,69 @@
+"""-m 4 / -m 8 parity on the GPU: HIP pipeline (through the C ABI) vs the oracle, byte-for-byte."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+DIAMOND = ("H\tVN:Z:1.0\nS\t1\tA\nS\t2\tT\nS\t3\tC\nS\t4\tG\nL\t1\t+\t2\t+\t0M\nL\t1\t+\t3\t+\t0M\nL\t2\t+\t4\t+\t0M\n"
+           "L\t3\t+\t4\t+\t0M\nP\tp0\t1+,2+,4+\t*\nP\tp1\t1+,3+,4+\t*\n")
+TWO_BUBBLES = ("S\t1\tA\nS\t2\tT\nS\t3\tC\nS\t4\tG\nS\t5\tA\nS\t6\tC\nS\t7\tT\n" +
+               "".join(f"L\t{a}\t+\t{b}\t+\t0M\n" for a, b in [(1, 2), (1, 3), (2, 4), (3, 4), (4, 5), (4, 6), (5, 7), (6, 7)]) +
+               "P\tp0\t1+,2+,4+,5+,7+\t*\nP\tp1\t1+,3+,4+,6+,7+\t*\n")
+
+
+def _check(oracle, gfa, reads, mode, omode, names=None, **kw):
+    from recgraph_amd import api
+    og = oracle.Graph.from_gfa_text(gfa)
+    g = api.Graph.from_gfa_text(gfa)
+    names = names or ["r%d" % i for i in range(len(reads))]
+    texts, status = api.align_batch(g, reads, names, mode=mode, **kw)
+    okw = {k: v for k, v in kw.items() if k in ("R", "r", "B")}
+    bad = []
+    for i, rd in enumerate(reads):
+        exp = og.align(omode, rd, name=names[i], idx=i + 1, **okw)[0]
+        if texts[i] != exp:
+            bad.append((i, rd[:40], texts[i][-300:], exp[-300:]))
+    assert not bad, (len(bad), bad[:2])
+    return texts
+
+
+def test_hand_derived_vectors(oracle):
+    from recgraph_amd import api
+    t = _check(oracle, DIAMOND, ["ATG"], api.MODE_PATHWISE, oracle.M4, names=["name"])
+    assert t[0] == "name\t3\t0\t2\t+\t>1>2>4\t3\t0\t2\t0\t*\t*\t3M, best path: 0, score: 6\tATG\n"
+    t = _check(oracle, TWO_BUBBLES, ["ATGCT"], api.MODE_PATHWISE, oracle.M4, names=["name"])
+    assert t[0] == "name\t5\t0\t4\t+\t>1>3>4>6>7\t5\t0\t4\t0\t*\t*\t1M1X3M, best path: 1, score: 4\tACGCT\n"
+    t = _check(oracle, TWO_BUBBLES, ["ATGCT"], api.MODE_RECOMBINATION, oracle.M8, names=["name"])
+    assert t[0] == ("name\t5\t0\t4\t+\t>1>2>4>6>7\t5\t0\t4\t0\t*\t*\t5M, recombination path 0 1, nodes 2[0] 4[0], "
+                    "score: 5.8, displacement: 2\tATGCT\t1\n")
+
+
+def test_small_graphs_vs_literal(oracle):
+    """Tiny graphs against the LITERAL (delta-encoded, unpruned O(L^2 n) search) restatement."""
+    from recgraph_amd import api
+    rng = np.random.default_rng(3)
+    for gfa in (DIAMOND, TWO_BUBBLES):
+        reads = ["".join("ACGT"[int(x)] for x in rng.integers(0, 4, size=int(rng.integers(1, 9)))) for _ in range(40)]
+        reads += ["A", "ATG", "ACG", "ATGAT", "ACGCT", "ATGCT", "TTTTTTTT", "N", "ANG"]
+        _check(oracle, gfa, reads, api.MODE_PATHWISE, oracle.M4)
+        _check(oracle, gfa, reads, api.MODE_RECOMBINATION, oracle.M8)
+        _check(oracle, gfa, reads, api.MODE_RECOMBINATION, oracle.M8, R=0, r=0.0)
+        _check(oracle, gfa, reads, api.MODE_RECOMBINATION, oracle.M8, R=1, r=0.5, B=0.6)
+
+
+def test_example_data(oracle, example_gfa, example_reads):
+    from recgraph_amd import api
+    names, reads = example_reads
+    _check(oracle, example_gfa, reads, api.MODE_PATHWISE, oracle.M4_ABS, names=names)
+    _check(oracle, example_gfa, reads, api.MODE_RECOMBINATION, oracle.M8_ABS, names=names)
+    _check(oracle, example_gfa, reads[:4], api.MODE_RECOMBINATION, oracle.M8_PRUNED, names=names[:4])
+
+
+def test_synthetic_haplotype_graph(oracle):
+    from recgraph_amd import api, synth
+    g = synth.haplotype_graph(1500, 8, path_len=300, seed=11)
+    reads = synth.haplotype_reads(g, 48, length=300, seed=12, mosaic_frac=0.5)
+    reads += [g.path_sequence(0)[:300], g.path_sequence(3)[:150] + g.path_sequence(5)[150:300], "ACGT" * 10]
+    _check(oracle, g.gfa(), reads, api.MODE_PATHWISE, oracle.M4_ABS)
+    _check(oracle, g.gfa(), reads, api.MODE_RECOMBINATION, oracle.M8_ABS)
+    _check(oracle, g.gfa(), reads[:6], api.MODE_RECOMBINATION, oracle.M8_PRUNED)
