@@ -1,0 +1,167 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the RecGraph DP hot path on MI355X.
+
+Workload (BASELINE.json configs[4], the configuration the north-star target is quoted on):
+-m 8 recombination alignment (R=4 r=0.1 B=1) of synthetic 1 kbp reads against a fixed synthetic
+~10 k-row / 32-path graph.  A "step" is one pass of the hot path (three DP sweeps, search, layer rebuild,
+traceback on the device, record fetch and GAF formatting on the host) over one batch of reads already
+resident in HBM.  Reads shard across ranks (one process per GPU, no data-path collective); the GAF text
+of every rank is gathered to rank 0 once at the end over RCCL.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+BYTES_PER_CELL_UPDATE = {0: 12, 2: 32, 4: 8, 8: 12}   # SURVEY §8d algorithmic bytes per unit of work
+HBM_PEAK_GBS = 8000.0                                 # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", default="C5", choices=["C2", "C4", "C5"])
+    ap.add_argument("--batch", type=int, default=0, help="reads per step per GPU (default: per config)")
+    ap.add_argument("--cpu-reads", type=int, default=-1, help="reads of the cpu_baseline sample (0 = skip)")
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    import torch.distributed as dist
+    dist_on = world > 1
+    if dist_on:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    from recgraph_amd import _lib, api, synth
+    _lib.check(_lib.load().rg_set_device(local_rank if torch.cuda.device_count() > local_rank else 0))
+
+    cfg = synth.CONFIGS[args.config]
+    mode = cfg["mode"]
+    batch = args.batch or {"C2": 10000, "C4": 4096, "C5": 4096}[args.config]
+    # every rank works on its own shard of the synthetic read set (seeded by rank): weak scaling
+    sg, _, _ = synth.make_config(args.config, n_reads=1)
+    num = int(args.config[1])
+    if args.config == "C2":
+        reads = synth.substring_reads(sg, batch, cfg["n"], seed=5678 + num + 1000 * rank)
+    else:
+        reads = synth.haplotype_reads(sg, batch, cfg["n"], seed=5678 + num + 1000 * rank,
+                                      mosaic_frac=0.5 if args.config == "C5" else 0.0)
+    gfa = sg.gfa()
+    graph = api.Graph.from_gfa_text(gfa)
+    params = api.make_params(mode)
+    b = api.Batch(graph, reads, params)            # reads uploaded: resident in HBM from here on
+    nthreads = max(1, min(16, (os.cpu_count() or 8) // max(1, min(world, 8))))
+
+    def step():
+        b.run()
+        b.fetch()
+        return b.format_all(None, 1, nthreads)
+
+    for _ in range(args.warmup):
+        text = step()
+
+    def sync():
+        torch.cuda.synchronize()
+        if dist_on:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    kstats = {}
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        text = step()
+        for k, (ms, n) in b.kernel_stats().items():
+            a = kstats.setdefault(k, [0.0, 0])
+            a[0] += ms
+            a[1] += n
+    gathered_bytes = len(text)
+    if dist_on:
+        # final gather of the GAF records (text) to rank 0 over RCCL/xGMI
+        t = torch.frombuffer(bytearray(text), dtype=torch.uint8).cuda()
+        ln = torch.tensor([t.numel()], device="cuda", dtype=torch.int64)
+        lens = [torch.zeros_like(ln) for _ in range(world)]
+        dist.all_gather(lens, ln)
+        mx = int(max(int(x.item()) for x in lens))
+        pad = torch.zeros(mx, dtype=torch.uint8, device="cuda")
+        pad[: t.numel()] = t
+        outs = [torch.zeros_like(pad) for _ in range(world)] if rank == 0 else None
+        dist.gather(pad, outs, dst=0)
+        if rank == 0:
+            gathered_bytes = int(sum(int(x.item()) for x in lens))
+    sync()
+    dt = time.perf_counter() - t0
+    if dist_on:
+        tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    cells_step = b.cell_updates
+    if rank == 0:
+        total_reads = batch * args.steps * world
+        dom = max(kstats.items(), key=lambda kv: kv[1][0]) if kstats else None
+        sweeps = {k: v for k, v in kstats.items() if k.startswith("k_sweep") or k.startswith("k_m0") or k.startswith("k_m2")}
+        roof = None
+        if sweeps:
+            # dominant kernel family: the DP sweep.  Every launch sweeps the whole graph once for the batch.
+            ms = sum(v[0] for v in sweeps.values())
+            launches = sum(v[1] for v in sweeps.values())
+            per_launch_units = cells_step / (2 if mode == 8 else 1)      # cell-updates one sweep launch processes
+            avg_s = ms / launches / 1e3
+            achieved = per_launch_units * BYTES_PER_CELL_UPDATE[mode] / avg_s / 1e9
+            traffic = None
+            tj = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.config)
+            if os.path.exists(tj):
+                try:
+                    traffic = json.load(open(tj)).get("hbm_bytes_per_launch")
+                except Exception:
+                    traffic = None
+            roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "kernel": "k_sweep",
+                    "avg_launch_ms": round(ms / launches, 3), "launches": launches}
+        out = {
+            "metric": "aligned reads/sec (-m 8 recombination, 1 kbp reads, 10k-row/32-path graph)" if args.config == "C5"
+            else "aligned reads/sec (%s)" % args.config,
+            "value": round(total_reads / dt, 2), "unit": "reads/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+            "config": {"workload": "BASELINE.json configs[%d] (%s): -m %d, %d bp reads, graph rows=%d paths=%d, batch=%d reads/GPU/step"
+                       % (num - 1, args.config, mode, cfg["n"], graph.rows, graph.paths_number, batch),
+                       "parallelism": "read-shard x%d" % world},
+            "cell_updates_per_s": round(cells_step * args.steps * world / dt, 1),
+            "kernel_ms_per_step": {k: round(v[0] / args.steps, 3) for k, v in kstats.items()},
+            "gaf_bytes_gathered": gathered_bytes,
+            "roofline": roof,
+        }
+        cpu = None
+        if not args.no_cpu and world == 1 and args.cpu_reads != 0:
+            from oracle import oracle as O
+            og = O.Graph.from_gfa_text(gfa)
+            cores = os.cpu_count() or 1
+            omode = {0: O.M0_SIMD, 2: O.M2, 4: O.M4_ABS, 8: O.M8_ABS}[mode]
+            nr = args.cpu_reads if args.cpu_reads > 0 else {0: 4000, 2: 2000, 4: 6 * cores, 8: 3 * cores}[mode]
+            nr = min(nr, len(reads))
+            secs, cells, _ = og.bench(omode, reads[:nr], nthreads=cores)
+            cpu = {"value": round(nr / secs, 3), "unit": "reads/s", "cores": cores, "kind": "port",
+                   "sample": "%d reads of the same batch, oracle absolute-form restatement with the exact pruned "
+                             "search (the faithful O(L^2 n) search is ~1e11 iterations/read), %d threads, %.1f s"
+                             % (nr, cores, secs)}
+        out["cpu_baseline"] = cpu
+        print(json.dumps(out))
+    if dist_on:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

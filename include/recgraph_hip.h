@@ -119,6 +119,11 @@ int32_t rg_result_score(const rg_batch* b, int64_t i);   /* exec(..).0 of the re
 /* seq_index is seq_name.1 of the reference (0 = score only: empty text). Returns bytes needed (excl. NUL). */
 int64_t rg_result_gaf(const rg_batch* b, int64_t i, const char* name, int64_t seq_index, char* buf, int64_t cap);
 
+/* Formats every read of the batch (as rg_result_gaf would, name i = names[i] or "read<i>" when names is
+ * NULL, seq_index = seq_index_base + i) into one buffer using `nthreads` host threads; returns bytes needed. */
+int64_t rg_batch_format_all(const rg_batch* b, const char* const* names, int64_t seq_index_base, char* buf,
+                            int64_t cap, int32_t nthreads);
+
 /* Measurement hooks for bench.py: DP cell-updates of the last run (SURVEY §8d unit of work) and
  * per-kernel device time measured with HIP events on the stream the kernels were launched on. */
 uint64_t rg_batch_cell_updates(const rg_batch* b);

@@ -36,7 +36,7 @@ def build_library(force=False):
 SYMBOLS = ["rg_params_default", "rg_scores_match_mis", "rg_graph_from_gfa", "rg_graph_create_lnz",
            "rg_graph_create_path", "rg_graph_destroy", "rg_graph_rows", "rg_graph_paths", "rg_graph_dump",
            "rg_batch_create", "rg_batch_run", "rg_batch_fetch", "rg_batch_destroy", "rg_batch_size",
-           "rg_result_status", "rg_result_score", "rg_result_gaf", "rg_batch_cell_updates", "rg_batch_kernel_count",
+           "rg_result_status", "rg_result_score", "rg_result_gaf", "rg_batch_format_all", "rg_batch_cell_updates", "rg_batch_kernel_count",
            "rg_batch_kernel_name", "rg_batch_kernel_ms", "rg_batch_kernel_launches", "rg_align_batch", "rg_last_error",
            "rg_device_count", "rg_set_device"]
 
@@ -77,6 +77,8 @@ def load():
     l.rg_result_score.argtypes = [vp, i64]
     l.rg_result_gaf.argtypes = [vp, i64, C.c_char_p, i64, C.c_char_p, i64]
     l.rg_result_gaf.restype = i64
+    l.rg_batch_format_all.argtypes = [vp, P(C.c_char_p), i64, C.c_char_p, i64, i32]
+    l.rg_batch_format_all.restype = i64
     l.rg_batch_cell_updates.argtypes = [vp]
     l.rg_batch_cell_updates.restype = u64
     l.rg_batch_kernel_count.argtypes = [vp]

@@ -244,6 +244,17 @@ class Batch:
         lib.rg_result_gaf(self._h, i, nb, seq_index, buf, n + 1)
         return buf.value.decode()
 
+    def format_all(self, names=None, seq_index_base=1, nthreads=8):
+        """All GAF text of the batch in one buffer (C++ host threads)."""
+        lib = _lib.load()
+        arr = None
+        if names is not None:
+            arr = (C.c_char_p * self.n)(*[x.encode() for x in names])
+        need = lib.rg_batch_format_all(self._h, arr, seq_index_base, None, 0, nthreads)
+        buf = C.create_string_buffer(need + 1)
+        lib.rg_batch_format_all(self._h, arr, seq_index_base, buf, need + 1, nthreads)
+        return buf.raw[:need]
+
     @property
     def cell_updates(self):
         return _lib.load().rg_batch_cell_updates(self._h)

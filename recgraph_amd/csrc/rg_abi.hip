@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstring>
 #include <memory>
+#include <thread>
 
 #include "rg_host.hpp"
 #include "rg_path_args.hpp"
@@ -456,6 +457,38 @@ int64_t rg_result_gaf(const rg_batch* b, int64_t i, const char* name, int64_t se
     }
     if (buf && (int64_t)out.size() + 1 <= cap) memcpy(buf, out.c_str(), out.size() + 1);
     return (int64_t)out.size();
+}
+
+int64_t rg_batch_format_all(const rg_batch* b, const char* const* names, int64_t seq_index_base, char* buf, int64_t cap,
+                            int32_t nthreads) {
+    if (!b || !b->fetched) return fail(RG_ERR_ARG, "result not available");
+    const int64_t n = b->nreads;
+    std::vector<std::string> parts((size_t)n);
+    if (nthreads < 1) nthreads = 1;
+    auto work = [&](int t) {
+        std::vector<char> tmp(1 << 16);
+        for (int64_t i = t; i < n; i += nthreads) {
+            std::string nm = names ? std::string(names[i]) : "read" + std::to_string(i);
+            int64_t need = rg_result_gaf(b, i, nm.c_str(), seq_index_base + i, tmp.data(), (int64_t)tmp.size());
+            if (need + 1 > (int64_t)tmp.size()) {
+                tmp.resize((size_t)need + 16);
+                rg_result_gaf(b, i, nm.c_str(), seq_index_base + i, tmp.data(), (int64_t)tmp.size());
+            }
+            parts[(size_t)i].assign(tmp.data(), (size_t)need);
+        }
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < nthreads; ++t) th.emplace_back(work, t);
+    work(0);
+    for (auto& t : th) t.join();
+    int64_t total = 0;
+    for (auto& s : parts) total += (int64_t)s.size();
+    if (buf && total + 1 <= cap) {
+        char* o = buf;
+        for (auto& s : parts) { memcpy(o, s.data(), s.size()); o += s.size(); }
+        *o = 0;
+    }
+    return total;
 }
 
 uint64_t rg_batch_cell_updates(const rg_batch* b) { return b ? b->cells : 0; }

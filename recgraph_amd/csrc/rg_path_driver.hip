@@ -5,6 +5,8 @@
 //   -m 8:  sweep(F1: column maxima) -> seed -> thr -> sweep(R: dirs, candidates, column maxima)
 //          -> thr -> sweep(F2: dirs, candidates) -> search -> layer(F) -> layer(R) -> trace
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "rg_path_kernels.hpp"
@@ -42,11 +44,11 @@ struct PathWorkImpl {
     bool tables = false;
     Buf<int> fpoff, fprow, fpslot, rpoff, rprow, rpslot;
     Buf<ReadState> state;
-    Buf<int> roll, mf, wr, thr, flayer, rlayer;
+    Buf<int> roll, mf, wr, mfarg, wrarg, thr, flayer, rlayer;
     Buf<uint32_t> fdirs, rdirs;
     Buf<Cand> fcand, rcand;
     Buf<unsigned> nf, nr, ridx;
-    unsigned cand_cap = 0;
+    unsigned fcap = 0, rcap = 0;
     std::vector<hipEvent_t> ev;
     ~PathWorkImpl() { for (auto e : ev) (void)hipEventDestroy(e); }
 };
@@ -116,7 +118,10 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
     if (C > 32) return fail(RG_ERR_ARG, "reads longer than 2047 bases are not supported by the pathwise kernels");
     const int wpad = C * WAVE;
     const int dir_words = WAVE * (C <= 16 ? 1 : 2);
-    const bool lds = (size_t)P * wpad * sizeof(int) + 64 * sizeof(int) <= 160 * 1024;
+    // Rolling rows: in HBM (L2 / Infinity-Cache resident, many waves per CU) by default; the LDS variant
+    // (one wave per CU at P = 32, n = 1000) measured 3.3x slower on MI355X (profiles/r01_notes.md).
+    bool lds = false;
+    if (getenv("RG_ROWS_IN_LDS")) lds = (size_t)P * wpad * sizeof(int) + 64 * sizeof(int) <= 160 * 1024;
     int rc;
     if (!w.tables) {
         // rows of every path in program order, with the direction-word slot of the group holding the path
@@ -150,22 +155,24 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
     // reads per chunk: bounded by a memory budget for the per-read work buffers
     const size_t per_read = (size_t)(fdirs_stride + (mode == RG_MODE_RECOMBINATION ? rdirs_stride : 0)) * 4 +
                             (size_t)layer_stride * 4 * (mode == RG_MODE_RECOMBINATION ? 2 : 1) +
-                            (lds ? 0 : (size_t)P * wpad * 4) + (size_t)wpad * 12 + sizeof(ReadState);
+                            (lds ? 0 : (size_t)P * wpad * 4) + (size_t)wpad * 20 + sizeof(ReadState);
     size_t budget = (size_t)96 << 30;
     {
         size_t fr = 0, tot = 0;
-        if (hipMemGetInfo(&fr, &tot) == hipSuccess) budget = std::min(budget, fr / 2);
+        if (hipMemGetInfo(&fr, &tot) == hipSuccess) budget = fr / 4 * 3;
     }
-    if (w.cand_cap == 0) w.cand_cap = 1u << 15;
+    if (w.fcap == 0) { w.fcap = 1u << 15; w.rcap = 1u << 19; }
     stats.clear();
     HIPCHK(hipMemsetAsync(d_cells, 0, sizeof(unsigned long long), stream));
     Timer T{&w, stream};
     int done = 0;
     unsigned long long cells_done = 0;
     while (done < nreads) {
-        const size_t per_read_all = per_read + (mode == RG_MODE_RECOMBINATION ? (size_t)w.cand_cap * (2 * sizeof(Cand) + 4) : 0);
-        int chunk = (int)std::min<size_t>((size_t)(nreads - done), std::max<size_t>(1, budget / per_read_all));
-        chunk = std::min(chunk, 8192);
+        const size_t per_read_all = per_read + (mode == RG_MODE_RECOMBINATION ? ((size_t)w.fcap * sizeof(Cand) + (size_t)w.rcap * (sizeof(Cand) + 4)) : 0);
+        int maxchunk = (int)std::min<size_t>(8192, std::max<size_t>(1, budget / per_read_all));
+        const int left = nreads - done;
+        const int nchunks = (left + maxchunk - 1) / maxchunk;
+        int chunk = (left + nchunks - 1) / nchunks;   // even chunks: no short tail launch
         if ((rc = w.state.alloc(chunk)) || (rc = w.fdirs.alloc((size_t)chunk * fdirs_stride)) ||
             (rc = w.flayer.alloc((size_t)chunk * layer_stride)))
             return rc;
@@ -173,8 +180,9 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
         if (mode == RG_MODE_RECOMBINATION) {
             if ((rc = w.rdirs.alloc((size_t)chunk * rdirs_stride)) || (rc = w.rlayer.alloc((size_t)chunk * layer_stride)) ||
                 (rc = w.mf.alloc((size_t)chunk * wpad)) || (rc = w.wr.alloc((size_t)chunk * wpad)) ||
-                (rc = w.thr.alloc((size_t)chunk * wpad)) || (rc = w.fcand.alloc((size_t)chunk * w.cand_cap)) ||
-                (rc = w.rcand.alloc((size_t)chunk * w.cand_cap)) || (rc = w.ridx.alloc((size_t)chunk * w.cand_cap)) ||
+                (rc = w.mfarg.alloc((size_t)chunk * wpad)) || (rc = w.wrarg.alloc((size_t)chunk * wpad)) ||
+                (rc = w.thr.alloc((size_t)chunk * wpad)) || (rc = w.fcand.alloc((size_t)chunk * w.fcap)) ||
+                (rc = w.rcand.alloc((size_t)chunk * w.rcap)) || (rc = w.ridx.alloc((size_t)chunk * w.rcap)) ||
                 (rc = w.nf.alloc(chunk)) || (rc = w.nr.alloc(chunk)))
                 return rc;
         }
@@ -186,7 +194,7 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
         sa.g = gd;
         for (int i = 0; i < 36; ++i) sa.sc.t[i] = p.scores[i];
         sa.reads = d_reads; sa.read_off = off; sa.bad = bad; sa.state = w.state.p; sa.roll = w.roll.p;
-        sa.rbw = p.rec_band_width; sa.cand_cap = w.cand_cap; sa.dir_words = dir_words; sa.cells = d_cells;
+        sa.rbw = p.rec_band_width; sa.cand_cap = 0; sa.dir_words = dir_words; sa.cells = d_cells;
         SeedArgs se{gd, w.state.p, chunk, mode};
         if (mode == RG_MODE_PATHWISE) {
             SweepArgs f = sa;
@@ -195,22 +203,25 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
             TIMED(T, "k_seed", launch_seed(se, stream));
         } else {
             SweepArgs f1 = sa;
-            f1.rev = 0; f1.track_best = 1; f1.colmax_out = w.mf.p; f1.count_cells = 0;
+            f1.rev = 0; f1.track_best = 1; f1.colmax_out = w.mf.p; f1.colarg_out = w.mfarg.p; f1.count_cells = 0;
             TIMED(T, "k_sweep_fwd_colmax", launch_sweep(f1, chunk, C, lds, stream));
             TIMED(T, "k_seed", launch_seed(se, stream));
-            ThrArgs t1{w.state.p, w.mf.p, w.thr.p, wpad, p.base_rec_cost};
+            ThrArgs t1{w.state.p, w.mf.p, w.thr.p, wpad, p.base_rec_cost, 0};
             TIMED(T, "k_threshold", launch_threshold(t1, chunk, stream));
             SweepArgs r = sa;
-            r.rev = 1; r.track_best = 1; r.thr = w.thr.p; r.colmax_out = w.wr.p; r.cand = w.rcand.p; r.ncand_out = w.nr.p;
+            r.rev = 1; r.track_best = 1; r.thr = w.thr.p; r.colmax_out = w.wr.p; r.colarg_out = w.wrarg.p; r.cand = w.rcand.p; r.cand_cap = w.rcap; r.ncand_out = w.nr.p;
             r.dirs = w.rdirs.p; r.dirs_stride = rdirs_stride; r.count_cells = 1;
             TIMED(T, "k_sweep_rev", launch_sweep(r, chunk, C, lds, stream));
-            ThrArgs t2{w.state.p, w.wr.p, w.thr.p, wpad, p.base_rec_cost};
+            BoundArgs ba{gd, w.state.p, off, w.mf.p, w.mfarg.p, w.wr.p, w.wrarg.p, wpad, p.base_rec_cost, p.multi_rec_cost,
+                         p.rec_band_width};
+            TIMED(T, "k_bound", launch_bound(ba, chunk, stream));
+            ThrArgs t2{w.state.p, w.wr.p, w.thr.p, wpad, p.base_rec_cost, 1};
             TIMED(T, "k_threshold", launch_threshold(t2, chunk, stream));
             SweepArgs f2 = sa;
-            f2.rev = 0; f2.track_best = 1; f2.thr = w.thr.p; f2.cand = w.fcand.p; f2.ncand_out = w.nf.p;
+            f2.rev = 0; f2.track_best = 1; f2.thr = w.thr.p; f2.cand = w.fcand.p; f2.cand_cap = w.fcap; f2.ncand_out = w.nf.p;
             f2.dirs = w.fdirs.p; f2.dirs_stride = fdirs_stride; f2.count_cells = 1;
             TIMED(T, "k_sweep_fwd", launch_sweep(f2, chunk, C, lds, stream));
-            SearchArgs sr{gd, w.state.p, w.fcand.p, w.rcand.p, w.nf.p, w.nr.p, w.ridx.p, w.cand_cap, wpad, p.base_rec_cost,
+            SearchArgs sr{gd, w.state.p, w.fcand.p, w.rcand.p, w.nf.p, w.nr.p, w.ridx.p, w.fcap, w.rcap, wpad, p.base_rec_cost,
                           p.multi_rec_cost};
             TIMED(T, "k_search", launch_search(sr, chunk, stream));
             // candidate-list overflow: regrow and redo this chunk
@@ -218,14 +229,20 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
             std::vector<unsigned> hn(chunk), hr(chunk);
             HIPCHK(hipMemcpy(hn.data(), w.nf.p, sizeof(unsigned) * chunk, hipMemcpyDeviceToHost));
             HIPCHK(hipMemcpy(hr.data(), w.nr.p, sizeof(unsigned) * chunk, hipMemcpyDeviceToHost));
-            unsigned need = 0;
-            for (int i = 0; i < chunk; ++i) need = std::max(need, std::max(hn[i], hr[i]));
-            if (need > w.cand_cap) {
+            unsigned needf = 0, needr = 0;
+            for (int i = 0; i < chunk; ++i) { needf = std::max(needf, hn[i]); needr = std::max(needr, hr[i]); }
+            if (getenv("RG_DEBUG")) {
+                unsigned long long sf = 0, sr = 0;
+                for (int i = 0; i < chunk; ++i) { sf += hn[i]; sr += hr[i]; }
+                fprintf(stderr, "[rg] chunk %d reads: fwd cand mean %.1f max %u, rev cand mean %.1f max %u\n", chunk,
+                        (double)sf / chunk, needf, (double)sr / chunk, needr);
+            }
+            if (needf > w.fcap || needr > w.rcap) {
                 const unsigned long long full = (unsigned long long)L * wpad;
-                if (w.cand_cap >= full) return fail(RG_ERR_CAPACITY, "candidate list overflow at full size");
-                unsigned long long nc = w.cand_cap;
-                while (nc < need) nc *= 2;
-                w.cand_cap = (unsigned)std::min<unsigned long long>(nc, full);
+                if ((needf > w.fcap && w.fcap >= full) || (needr > w.rcap && w.rcap >= full))
+                    return fail(RG_ERR_CAPACITY, "candidate list overflow at full size");
+                while (w.fcap < needf) w.fcap = (unsigned)std::min<unsigned long long>(2ull * w.fcap, full);
+                while (w.rcap < needr) w.rcap = (unsigned)std::min<unsigned long long>(2ull * w.rcap, full);
                 HIPCHK(hipMemcpy(d_cells, &cells_done, sizeof cells_done, hipMemcpyHostToDevice));
                 continue;
             }

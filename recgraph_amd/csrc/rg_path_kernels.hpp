@@ -12,7 +12,7 @@ struct ReadState {
     int end_row;       // sink row of the chosen path
     int fwd_path, rev_path, fen, rsn, rec_col, displacement;
     float fscore;
-    int pad;
+    int bound;         // integer lower bound of the final search maximum (>= s0), tightens the pruning
     int sink_val[64];  // A[sink row][n][k]
 };
 
@@ -34,8 +34,9 @@ struct SweepArgs {
     const int* thr;            // [reads][wpad] emission thresholds by real column, or null
     float rbw;                 // -B: columns outside the recombination band never emit
     int* colmax_out;           // [reads][wpad] per-column maximum of the best members, or null
+    int* colarg_out;           // [reads][wpad] (row << 8 | path) of a cell attaining that maximum
     Cand* cand;                // [reads][cand_cap] or null
-    unsigned cand_cap;
+    unsigned cand_cap;         // capacity of the list this sweep appends to
     unsigned* ncand_out;
     uint32_t* dirs;            // [reads][dirs_stride] direction words or null
     long long dirs_stride;
@@ -58,6 +59,19 @@ struct ThrArgs {
     int* thr;
     int wpad;
     int brc;
+    int use_bound;             // 0: S0, 1: the tighter bound of k_bound
+};
+
+struct BoundArgs {
+    PathGraphDev g;
+    ReadState* state;
+    const long long* read_off;
+    const int* mf; const int* mfarg;
+    const int* wr; const int* wrarg;
+    int wpad;
+    int brc;
+    float mrc;
+    float rbw;
 };
 
 struct SearchArgs {
@@ -68,7 +82,7 @@ struct SearchArgs {
     const unsigned* nf;
     const unsigned* nr;
     unsigned* ridx;
-    unsigned cand_cap;
+    unsigned fcap, rcap;
     int wpad;
     int brc;
     float mrc;
@@ -111,6 +125,7 @@ struct TraceArgs {
 void launch_sweep(const SweepArgs& a, int nreads, int C, bool lds, hipStream_t s);
 void launch_seed(const SeedArgs& a, hipStream_t s);
 void launch_threshold(const ThrArgs& a, int nreads, hipStream_t s);
+void launch_bound(const BoundArgs& a, int nreads, hipStream_t s);
 void launch_search(const SearchArgs& a, int nreads, hipStream_t s);
 void launch_layer(const LayerArgs& a, int nreads, int C, hipStream_t s);
 void launch_trace(const TraceArgs& a, int C, hipStream_t s);

@@ -107,9 +107,9 @@ __global__ __launch_bounds__(64) void k_sweep(SweepArgs a) {
     }
     __syncthreads();
 
-    int colmax[C];
+    int colmax[C], colarg[C];
 #pragma unroll
-    for (int q = 0; q < C; ++q) colmax[q] = NEG;
+    for (int q = 0; q < C; ++q) { colmax[q] = NEG; colarg[q] = 0; }
     unsigned ncand = 0;
     unsigned long long cells = 0;
     Cand* cand = a.cand ? a.cand + (long long)rd * a.cand_cap : nullptr;
@@ -244,7 +244,7 @@ __global__ __launch_bounds__(64) void k_sweep(SweepArgs a) {
                 // argmax over ALL P entries where non-members hold 0: usable only if the winner is a member
                 const bool valid = act[q] && bestk[q] >= 0 && (knm < 0 || bestv[q] > 0 || (bestv[q] == 0 && bestk[q] > knm));
                 if (valid) {
-                    colmax[q] = max(colmax[q], bestv[q]);
+                    if (bestv[q] > colmax[q]) { colmax[q] = bestv[q]; colarg[q] = (i << 8) | bestk[q]; }
                     if (bestv[q] >= thr[q]) emask |= 1u << q;
                 }
             }
@@ -275,7 +275,10 @@ __global__ __launch_bounds__(64) void k_sweep(SweepArgs a) {
 #pragma unroll
         for (int q = 0; q < C; ++q) {
             const int c = lane * C + q;
-            if (act[q]) a.colmax_out[(long long)rd * wpad + (rev ? n - c : c)] = colmax[q];
+            if (act[q]) {
+                a.colmax_out[(long long)rd * wpad + (rev ? n - c : c)] = colmax[q];
+                if (a.colarg_out) a.colarg_out[(long long)rd * wpad + (rev ? n - c : c)] = colarg[q];
+            }
         }
     }
     if (a.ncand_out && lane == 0) a.ncand_out[rd] = ncand;
@@ -310,7 +313,7 @@ __global__ void k_seed(SeedArgs a) {
                 if ((g.emask[e] >> k) & 1) { v = rs->sink_val[k]; end = g.epred[e]; }
             if (first || v >= best) { best = v; bp = k; bend = end; first = false; }
         }
-        rs->s0 = best; rs->seed_path = bp; rs->end_row = bend; rs->fwd_path = bp; rs->rev_path = bp;
+        rs->s0 = best; rs->bound = best; rs->seed_path = bp; rs->end_row = bend; rs->fwd_path = bp; rs->rev_path = bp;
     } else {
         // strict '<' over F's predecessors (stored order) then paths ascending: lowest id on ties
         bool have = false; int mx = 0, bp = 0;
@@ -322,7 +325,7 @@ __global__ void k_seed(SeedArgs a) {
                 }
         int end = 0;
         for (int e = g.eoff[L - 1]; e < g.eoff[L]; ++e) if ((g.emask[e] >> bp) & 1) end = g.epred[e];
-        rs->s0 = mx; rs->seed_path = bp; rs->end_row = end; rs->fwd_path = bp; rs->rev_path = bp;
+        rs->s0 = mx; rs->bound = mx; rs->seed_path = bp; rs->end_row = end; rs->fwd_path = bp; rs->rev_path = bp;
         if (!have) rs->status |= ST_WOULD_PANIC;
     }
 }
@@ -336,7 +339,34 @@ __global__ void k_threshold(ThrArgs a) {
     const ReadState* rs = a.state + rd;
     const long long o = (long long)rd * a.wpad + j;
     const int cm = a.colmax[o];
-    a.thr[o] = cm <= NEG ? INT32_MAX : rs->s0 + a.brc - cm;
+    a.thr[o] = cm <= NEG ? INT32_MAX : (a.use_bound ? rs->bound : rs->s0) + a.brc - cm;
+}
+
+// Lower bound of the search maximum: the exact score of the pair (best forward cell, best reverse cell)
+// of every column, when that pair is admissible.  Any real candidate's score is a valid bound; pairs
+// whose integer part (m + w - R) is below it can neither win nor tie.
+__global__ __launch_bounds__(64) void k_bound(BoundArgs a) {
+    const int rd = blockIdx.x;
+    const int lane = threadIdx.x;
+    ReadState* rs = a.state + rd;
+    if (rs->status & (ST_BAD_BASE | ST_WOULD_PANIC)) return;
+    const PathGraphDev& g = a.g;
+    const int n = (int)(a.read_off[rd + 1] - a.read_off[rd]);
+    const int oob = max((int)((float)(n + 1) * (1.0f - a.rbw) / 2.0f), 1);
+    float best = (float)rs->s0;
+    for (int j = oob + lane; j < n + 1 - oob; j += WAVE) {
+        const long long o = (long long)rd * a.wpad + j;
+        const int m = a.mf[o], w = a.wr[o];
+        if (m <= NEG || w <= NEG) continue;
+        const int fa = a.mfarg[o], ra = a.wrarg[o];
+        const int fi = fa >> 8, fk = fa & 255, ri = ra >> 8, rk = ra & 255;
+        if (fk == rk || g.node_id[fi] == g.node_id[ri]) continue;
+        const int disp = abs(g.dfs[fi] - g.dfs[ri]) + abs(g.dfe[fi] - g.dfe[ri]);
+        const float sc = __fsub_rn((float)(m + w), __fadd_rn((float)a.brc, __fmul_rn(a.mrc, (float)disp)));
+        best = fmaxf(best, sc);
+    }
+    for (int d = WAVE / 2; d >= 1; d >>= 1) best = fmaxf(best, __shfl_xor(best, d, WAVE));
+    if (lane == 0) rs->bound = max(rs->s0, (int)ceilf(best));
 }
 
 // ---------------------------------------------------------------------------------
@@ -364,10 +394,10 @@ __global__ __launch_bounds__(64) void k_search(SearchArgs a) {
     if (rs->status & (ST_BAD_BASE | ST_WOULD_PANIC)) return;
     const PathGraphDev& g = a.g;
     const long long L = g.L;
-    const Cand* fc = a.fcand + (long long)rd * a.cand_cap;
-    const Cand* rc = a.rcand + (long long)rd * a.cand_cap;
+    const Cand* fc = a.fcand + (long long)rd * a.fcap;
+    const Cand* rc = a.rcand + (long long)rd * a.rcap;
     const unsigned nf = a.nf[rd], nr = a.nr[rd];
-    if (nf > a.cand_cap || nr > a.cand_cap) {
+    if (nf > a.fcap || nr > a.rcap) {
         if (lane == 0) rs->status |= ST_OVERFLOW;
         return;
     }
@@ -392,7 +422,7 @@ __global__ __launch_bounds__(64) void k_search(SearchArgs a) {
     }
     __syncthreads();
     // hist[j] = number of reverse candidates with col < j  => bucket of column j is [hist[j], hist[j+1])
-    unsigned* ridx = a.ridx + (long long)rd * a.cand_cap;
+    unsigned* ridx = a.ridx + (long long)rd * a.rcap;
     int* fill = sh + (wpad + 1);  // wpad + 1 cursors
     for (int j = lane; j <= wpad; j += WAVE) fill[j] = 0;
     __syncthreads();
@@ -405,6 +435,7 @@ __global__ __launch_bounds__(64) void k_search(SearchArgs a) {
     __threadfence_block();
 
     const float brc_f = (float)a.brc;
+    const int bound = rs->bound;
     SearchKey best;
     best.score = (float)rs->s0; best.cond = 0; best.order = -1; best.fi = -1; best.ri = -1;
     // lanes take forward candidates; each scans the reverse bucket of its column
@@ -418,8 +449,8 @@ __global__ __launch_bounds__(64) void k_search(SearchArgs a) {
             for (int u = b0; u < b1; ++u) {
                 const unsigned ri = ridx[u];
                 const Cand r = rc[ri];
-                // integer bound first: (m + w) - R >= S0 is necessary for any update
-                if (f.val + r.val - a.brc < rs->s0) continue;
+                // integer bound first: (m + w) - R >= bound is necessary to win or tie
+                if (f.val + r.val - a.brc < bound) continue;
                 if (g.node_id[r.row] == idf) continue;
                 if (f.path == r.path) continue;
                 const int disp = abs(g.dfs[f.row] - g.dfs[r.row]) + abs(g.dfe[f.row] - g.dfe[r.row]);
@@ -683,6 +714,9 @@ void launch_seed(const SeedArgs& a, hipStream_t s) {
 }
 void launch_threshold(const ThrArgs& a, int nreads, hipStream_t s) {
     hipLaunchKernelGGL(k_threshold, dim3((a.wpad + 255) / 256, nreads), dim3(256), 0, s, a);
+}
+void launch_bound(const BoundArgs& a, int nreads, hipStream_t s) {
+    hipLaunchKernelGGL(k_bound, dim3(nreads), dim3(64), 0, s, a);
 }
 void launch_search(const SearchArgs& a, int nreads, hipStream_t s) {
     const size_t bytes = (size_t)(2 * (a.wpad + 1)) * sizeof(int);
