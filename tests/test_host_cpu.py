@@ -1,0 +1,114 @@
+"""CPU: host-side logic of the product (no GPU compute): the C-ABI library loads and exports every
+symbol include/recgraph_hip.h declares, graph flattening equals the oracle's arrays, score matrices and
+defaults follow the reference, and batch calls fail loudly without a HIP device."""
+import ctypes as C
+import json
+import os
+import re
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+VEC = json.load(open(os.path.join(HERE, "golden", "reference_unit_vectors.json")))
+
+
+@pytest.fixture(scope="module")
+def rg():
+    from recgraph_amd import _lib
+    _lib.build_library()
+    import recgraph_amd
+    return recgraph_amd
+
+
+def test_library_exports_every_declared_symbol(rg):
+    from recgraph_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "recgraph_hip.h")).read()
+    declared = set(re.findall(r"\b(rg_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations found"
+    lib = C.CDLL(_lib.library_path())
+    for sym in sorted(declared):
+        assert hasattr(lib, sym), sym
+    assert declared == set(_lib.SYMBOLS)
+
+
+def test_flattening_matches_oracle(rg, oracle, example_gfa):
+    from recgraph_amd import api, synth
+    texts = [example_gfa, synth.linear_graph(400, seed=3).gfa(), synth.haplotype_graph(900, 7, path_len=150, seed=4).gfa()]
+    texts += [v["gfa"] for v in VEC["path_graph"]]
+    for t in texts:
+        g, og = api.Graph.from_gfa_text(t), oracle.Graph.from_gfa_text(t)
+        for which in (0, 1, 2, 3, 4, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19):
+            assert g.dump(which) == og.dump(which), which
+
+
+@pytest.mark.parametrize("v", VEC["graph_struct"] + VEC["path_graph"], ids=lambda v: v["ref"])
+def test_reference_graph_unit_vectors(rg, v):
+    from recgraph_amd import api
+    g = api.Graph.from_gfa_text(v["gfa"])
+    if "lnz" in v:
+        assert g.dump(0) == v["lnz"]
+    if "paths_number" in v:
+        assert g.paths_number == v["paths_number"]
+        rows = g.dump(13).strip(";").split(";")
+        for row, bits in v["paths_nodes"].items():
+            assert rows[int(row)] == bits
+    if "preds" in v:
+        preds = dict(x.split(":") for x in g.dump(2).strip(";").split(";"))
+        for k, p in v["preds"].items():
+            assert [int(t) for t in preds[k].split(",")] == p
+
+
+def test_score_matrices_and_defaults(rg):
+    from recgraph_amd import api
+    m = api.create_score_matrix_i32(10, -10)
+    assert m[("A", "A")] == 10 and m[("A", "C")] == -10 and m[("N", "N")] == -10 and ("-", "-") not in m
+    assert m[("A", "-")] == -20                     # any pairing with '-' = 2x (score_matrix.rs:43)
+    f = api.create_score_matrix_f32(2, -4)
+    assert f[("A", "-")] == -4.0                    # f32 variant: gap = x (score_matrix.rs:52-66)
+    h = api.create_score_matrix_i32(matrix_file_path=os.path.join(HERE, "golden", "HOXD70.mtx"))
+    assert h[("A", "A")] == 91 and h[("T", "G")] == -144 and h[("G", "T")] == -114 and h[("A", "-")] == -200
+    p = api.make_params(8)
+    assert (p.gap_open, p.gap_ext, p.base_rec_cost) == (-4, -2, 4)
+    assert abs(p.multi_rec_cost - 0.1) < 1e-7 and p.rec_band_width == 1.0 and p.band_b == 1.0
+
+
+def test_gaf_struct_roundtrip(rg):
+    from recgraph_amd import api
+    line = "name\t5\t0\t4\t+\t>1>2>4>6>7\t5\t0\t4\t0\t*\t*\t5M, recombination path 0 1, nodes 2[0] 4[0], score: 5.8, displacement: 2\tATGCT\t1"
+    g = api.GAFStruct.from_line(line)
+    assert g.path == [1, 2, 4, 6, 7] and g.to_string() == line
+    assert api.GAFStruct().to_string() == "\t0\t0\t0\t \t>0\t0\t0\t0\t0\t\t\t"     # GAFStruct::new() (gaf_output.rs:22-38)
+
+
+def test_bad_inputs_are_status_codes_not_aborts(rg):
+    from recgraph_amd import _lib, api
+    with pytest.raises(_lib.RecGraphError):
+        api.Graph.from_gfa_text("S\tx\tACGT\n")                       # non-numeric segment name
+    with pytest.raises(_lib.RecGraphError):
+        api.Graph.from_gfa_text("S\t1\tA\nS\t2\tC\nL\t1\t-\t2\t+\t0M\n")  # reverse orientation
+    with pytest.raises(_lib.RecGraphError):
+        api.Graph.from_gfa_text("S\t1\tA\nS\t2\tC\nS\t3\tG\nL\t1\t+\t3\t+\t0M\nP\tp\t1+,3+\t*\n" )  # segment 2 on no path
+
+
+def test_no_cpu_fallback(rg, example_gfa):
+    """Without a HIP device the product fails loudly; it never routes through a CPU path."""
+    from recgraph_amd import _lib, api
+    if _lib.load().rg_device_count() > 0:
+        pytest.skip("a GPU is present")
+    g = api.Graph.from_gfa_text(example_gfa)
+    with pytest.raises(_lib.RecGraphError) as e:
+        api.align_batch(g, ["ACGT"], ["r"])
+    assert e.value.code == -3
+
+
+def test_product_never_imports_the_oracle():
+    import subprocess
+    import sys
+    code = "import sys; import recgraph_amd; assert not any(m.startswith('oracle') for m in sys.modules), 'oracle imported'"
+    subprocess.check_call([sys.executable, "-c", code], cwd=ROOT)
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "recgraph_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".hpp", ".h")) or f == "Makefile":
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "oracle/" not in txt and "liboracle" not in txt and "import oracle" not in txt, f
