@@ -202,7 +202,7 @@ int run_poa(rg_batch* b) {
     const HostGraph& h = g->h;
     if (!h.has_lnz) return fail(RG_ERR_ARG, "graph has no LnzGraph view");
     const int mode = b->p.mode;
-    const int planes = mode == RG_MODE_GAP_POA ? 3 : 1;
+    const int planes = mode == RG_MODE_GAP_POA ? 3 : 1;   // m2: m | y | (spare) score planes, w0 | w1 path planes
     Timed T(b);
     for (auto& s : b->stats) { s.ms = 0; s.launches = 0; }
     for (int attempt = 0; attempt < 8; ++attempt) {
@@ -333,7 +333,7 @@ int32_t rg_batch_create(const rg_graph* gc, const rg_params* p, const char* read
     rg_graph* g = const_cast<rg_graph*>(gc);
     const int mode = p->mode;
     if (!(is_poa(mode) || mode == RG_MODE_PATHWISE || mode == RG_MODE_RECOMBINATION)) return fail(RG_ERR_ARG, "unsupported mode");
-    if (mode == RG_MODE_GAP_POA || mode == RG_MODE_GLOBAL_POA_SCALAR) return fail(RG_ERR_ARG, "mode not built into this library yet");
+    if (mode == RG_MODE_GAP_POA && (p->gap_open > 0 || p->gap_ext > 0)) return fail(RG_ERR_ARG, "gap penalties must be <= 0");
     if (is_poa(mode) && !g->h.has_lnz) return fail(RG_ERR_ARG, "graph has no LnzGraph view");
     if (!is_poa(mode) && !g->h.has_path) return fail(RG_ERR_ARG, "graph has no paths (P lines)");
     if (mode == RG_MODE_RECOMBINATION && (p->base_rec_cost < 0 || p->multi_rec_cost < 0))

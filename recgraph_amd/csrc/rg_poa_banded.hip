@@ -1,0 +1,435 @@
+// Band-relative POA kernels for gfx950: -m 2 (gap_global_abpoa::exec, src/gap_global_abpoa.rs:11-250)
+// and the scalar -m 0 (global_abpoa::exec, src/global_abpoa.rs:260-427), with their band check
+// (band_ampl_enough) and traceback walkers (gaf_output.rs:96-381).
+//
+// Same mapping as rg_poa.hip: one wavefront per read, lanes over the band columns of a row, rows
+// sequential.  Storage is band-relative like the reference (cell j of row i <-> absolute column
+// left_i + j); predecessor columns are translated with left_i - left_p and a predecessor only
+// contributes where its band covers the column.
+//
+// The two "left" recurrences are evaluated as wave-level prefix scans:
+//   m0 scalar:  m[j] = max(du[j], m[j-1] + g(read[c]))            (du = max(d, u), L on strict '>')
+//   m2:         x[j] = e + max(x[j-1], m[j-1] + o),  m[j] = max(t[j], x[j]),  t = max(d, y)
+//               => x[j] - e*j = max(boundary, max_{k<j}(t[k] + o - e*k))      (needs o <= 0)
+#include "rg_device.hpp"
+#include "rg_poa_args.hpp"
+
+namespace rg {
+
+namespace {
+
+constexpr int NEGB = INT32_MIN / 4;
+
+__device__ __forceinline__ int scb(const DevScores& sc, int a, int b) { return sc.t[a * 6 + b]; }
+
+// utils.rs:17-72 with simd_version = false
+__device__ void band_plain(unsigned long long ms, unsigned long long me, int r_val, unsigned long long seq_len,
+                           unsigned long long bta, int& left, int& right) {
+    int tmp_bs = min((int)ms, ((int)seq_len - r_val) - (int)bta);
+    unsigned long long band_start = tmp_bs < 0 ? 0ull : (unsigned long long)tmp_bs;
+    unsigned long long r64 = r_val < 0 ? ~0ull : (unsigned long long)r_val;
+    unsigned long long band_end;
+    if (seq_len > r64) {
+        unsigned long long a = me > seq_len - r64 ? me : seq_len - r64;
+        band_end = min(seq_len, a + bta);
+    } else {
+        band_end = min(seq_len, me + bta);
+    }
+    left = (int)band_start;
+    right = (int)band_end;
+}
+
+// direction codes of bitfield_path.rs:3-15 that these modes use
+enum : uint32_t { PD_O = 0, PD_D = 1, PD_d = 2, PD_L = 3, PD_U = 4 };
+
+}  // namespace
+
+// kGap = false: scalar -m 0;  kGap = true: -m 2.
+// Arena planes per read (cap_cells each): m | y (m2) ; path words: w0 = pred<<3 | dir | X<<31, w1 = predY<<1 | Y.
+template <bool kGap>
+__global__ __launch_bounds__(64) void k_poa_banded(PoaArgs a) {
+    const int rd = blockIdx.x;
+    const int lane = threadIdx.x;
+    const DevLnz& g = a.g;
+    const int L = g.L;
+    const long long ro = a.read_off[rd];
+    const int n = (int)(a.read_off[rd + 1] - ro);
+    const uint8_t* read = a.reads + ro - 1;
+    DevRecord* rec = a.rec + rd;
+    const int W = n + 1;
+    if (a.bad[rd]) {
+        if (lane == 0) { rec->status = ST_BAD_BASE; rec->n_ops = 0; rec->score = 0; }
+        return;
+    }
+    const int planes = kGap ? 2 : 1;
+    int* am = a.arena_m + (long long)rd * a.cap_cells * (kGap ? 3 : 1);
+    int* ay = am + a.cap_cells;
+    uint32_t* pw0 = a.arena_pw + (long long)rd * a.cap_cells * (kGap ? 3 : 1);
+    uint32_t* pw1 = pw0 + a.cap_cells;
+    (void)planes;
+    int4* rinfo = a.rinfo + (long long)rd * L;
+    const unsigned long long bta = (unsigned long long)a.bta[rd];
+    const int GAP = 5;
+    const int o = a.gap_open, e = a.gap_ext;
+    long long off = 0;
+    unsigned long long ncells = 0;
+    uint32_t status = 0;
+    bool overflow = false;
+
+    for (int i = 0; i + 1 < L; ++i) {
+        const int pb = g.pred_off[i], pe = g.pred_off[i + 1];
+        const bool nwp = pe > pb;
+        unsigned long long ms = 0, me = 0;
+        if (i > 0) {
+            if (!nwp) { unsigned long long pl = (unsigned long long)rinfo[i - 1].w; ms = pl + 1; me = pl + 1; }
+            else {
+                unsigned long long pl = 0, pr = 0;
+                for (int ee = pb; ee < pe; ++ee) {
+                    unsigned long long cb = (unsigned long long)rinfo[g.pred_rows[ee]].w;
+                    if (ee == pb) { pl = cb; pr = cb; }
+                    if (cb < pl) pl = cb;
+                    if (cb > pr) pr = cb;
+                }
+                ms = pl + 1; me = pr + 1;
+            }
+        }
+        int left, right;
+        band_plain(ms, me, g.r_values[i], (unsigned long long)W, bta, left, right);
+        if (right <= left) { status |= ST_WOULD_PANIC; break; }   // empty row: m[i][best_val_pos] out of range
+        const int width = right - left;
+        if (off + width > a.cap_cells) { overflow = true; break; }
+        const int li = i > 0 ? g.lnz[i] : 4;
+        const int minp = i > 0 ? g.min_pred[i] : 0;
+        // carries of the scans across 64-column chunks
+        int carry_z = NEGB;       // running prefix max (exclusive) of the scan variable
+        int carry_G = 0;          // m0 scalar: prefix sum of gap costs
+        int carry_t = NEGB;       // m2: t of the last column of the previous chunk (for the X flag)
+        int carry_zprev = NEGB;   // m2: exclusive prefix max at the previous chunk's last column
+        long long best_key = ((long long)INT32_MIN) * 4294967296ll;
+        for (int cb = 0; cb < width; cb += WAVE) {
+            const int j = cb + lane;
+            const bool act = j < width;
+            const int c = left + j;
+            const int rc = (act && c >= 1) ? read[c] : 4;
+            // ---- candidates from the predecessor rows ----
+            int d = 0, u = 0, dp = minp, up = minp;
+            bool have_d = false, have_u = false;
+            int uy = 0, uyp = minp;      // m2: best y of covering predecessors
+            bool fixed = false;          // cell fully determined without the left chain
+            int mval = 0;
+            uint32_t w0 = 0, w1 = 0;
+            int tval = NEGB;             // non-left candidate of the cell (max(d,u) / max(d,y))
+            uint32_t tw0 = 0;            // its path word
+            int yval = 0;
+            if (act) {
+                if (i == 0 && j == 0) { fixed = true; mval = 0; w0 = PD_O; }
+                else if (i == 0) {
+                    if (kGap) { fixed = true; mval = o + e * c; yval = mval; w0 = (0u << 3) | PD_L; }
+                    // scalar m0 row 0 is a pure left chain: handled by the scan with tval = NEG
+                } else if (j == 0 && left == 0) {
+                    fixed = true;
+                    if (kGap) { mval = o + e * (minp + 1); w0 = ((uint32_t)minp << 3) | PD_U; }
+                    else {
+                        const int4 rp = rinfo[minp];
+                        mval = am[rp.x] + scb(a.sc, GAP, li);       // m[best_p][0] band-relative (:316)
+                        w0 = ((uint32_t)minp << 3) | PD_U;
+                    }
+                } else {
+                    const int np = nwp ? pe - pb : 1;
+                    for (int q = 0; q < np; ++q) {
+                        const int p = nwp ? g.pred_rows[pb + q] : i - 1;
+                        const int4 rp = rinfo[p];
+                        if (c > rp.y && c <= rp.z) {                 // diagonal: left_p < c <= right_p
+                            const int v = am[rp.x + (c - rp.y) - 1];
+                            if (!have_d || v > d) { d = v; dp = p; }
+                            have_d = true;
+                        }
+                        if (c >= rp.y && c < rp.z) {                 // up: left_p <= c < right_p
+                            if (kGap) {
+                                const int vm = am[rp.x + (c - rp.y)] + o, vy = ay[rp.x + (c - rp.y)];
+                                if (!have_u) { u = vm; up = p; uy = vy; uyp = p; }
+                                if (vm > u) { u = vm; up = p; }
+                                if (vy > uy) { uy = vy; uyp = p; }
+                            } else {
+                                const int v = am[rp.x + (c - rp.y)];
+                                if (!have_u || v > u) { u = v; up = p; }
+                            }
+                            have_u = true;
+                        }
+                    }
+                }
+            }
+            if (!kGap) {
+                // ---------------- scalar m0 (global_abpoa.rs:318-390) ----------------
+                int gc = 0;
+                bool chain = false;           // cell takes part in the left chain
+                int lfb = NEGB;               // left fallback of a band-left cell (:337-339)
+                if (act && !fixed) {
+                    if (i == 0) { chain = true; gc = scb(a.sc, GAP, rc); tval = NEGB; }   // key ('-', base) (:307)
+                    else {
+                        const int dv = have_d ? d + scb(a.sc, li, rc) : scb(a.sc, li, GAP) * (i + left);
+                        const int uv = have_u ? u + scb(a.sc, li, GAP) : scb(a.sc, li, GAP) * (i + left + j);
+                        const int dpp = have_d ? dp : minp, upp = have_u ? up : minp;
+                        if (dv < uv) { tval = uv; tw0 = ((uint32_t)(upp & 0xffff) << 3) | PD_U; }
+                        else { tval = dv; tw0 = ((uint32_t)(dpp & 0xffff) << 3) | (rc != li ? PD_d : PD_D); }
+                        gc = scb(a.sc, rc, GAP);
+                        if (j > 0) chain = true;
+                        else lfb = scb(a.sc, rc, GAP) * (i + left + j);
+                    }
+                }
+                // scan: z = value - G
+                const int G = wave_incl_sum(act ? gc : 0, lane) + carry_G;
+                int v0 = tval;                // value of a cell as a chain SOURCE
+                uint32_t v0w = tw0;
+                if (fixed) { v0 = mval; v0w = w0; }
+                if (act && !fixed && !chain && i > 0) {   // band-left cell with left > 0: l is a constant
+                    if (lfb > tval) { v0 = lfb; v0w = ((uint32_t)(minp & 0xffff) << 3) | PD_L; }
+                }
+                const int y = act ? v0 - G : NEGB;
+                const int zi = wave_incl_max(y, lane);
+                int zprev = __shfl_up(zi, 1, WAVE);
+                zprev = lane == 0 ? carry_z : max(zprev, carry_z);
+                if (act) {
+                    int v = v0;
+                    uint32_t w = v0w;
+                    if (chain && zprev > y) { v = zprev + G; w = ((uint32_t)(i & 0xffff) << 3) | PD_L; }
+                    if (chain && i == 0) { v = zprev + G; w = (0u << 3) | PD_L; }
+                    am[off + j] = v;
+                    pw0[off + j] = w;
+                    mval = v;
+                    if (!fixed && i > 0) ncells += 0;  // counted below per wave
+                }
+                carry_z = max(carry_z, __shfl(zi, WAVE - 1, WAVE));
+                carry_G = __shfl(G, WAVE - 1, WAVE);
+            } else {
+                // ---------------- m2 (gap_global_abpoa.rs:67-196) ----------------
+                const bool fixed0 = act && i > 0 && j == 0 && left == 0;   // first column (:78-92)
+                const bool general = act && i > 0 && !fixed0;
+                int dv = NEGB, up_pred = minp, tcur = NEGB, xb = NEGB;
+                bool fromy = false;
+                if (act && i == 0) { mval = j == 0 ? 0 : o + e * c; yval = mval; w0 = j == 0 ? (uint32_t)PD_O : ((0u << 3) | PD_L); }
+                if (fixed0) { mval = o + e * (minp + 1); xb = mval; w0 = ((uint32_t)(minp & 0xffff) << 3) | PD_U; yval = 0; }
+                if (general) {
+                    if (have_u) {                                   // get_best_u (:296-346)
+                        if (uy > u) { yval = uy + e; up_pred = uyp; fromy = true; }
+                        else { yval = u + e; up_pred = up; }
+                    } else { yval = 2 * o + e * (minp + 1) + e * c; up_pred = minp; }   // (:139)
+                    if (have_d) dv = d + scb(a.sc, li, rc);
+                    tcur = max(dv, yval);
+                    if (j == 0) xb = 2 * o + e * (minp + 1) + e * c;                    // (:117)
+                }
+                // x[j] - e*j = max over k < j of max(t[k] + o, xb[k]) - e*k   (x[j] = e + max(x[j-1], m[j-1] + o), o <= 0)
+                int zsrc = NEGB;
+                if (fixed0 || general) zsrc = max(tcur > NEGB ? tcur + o : NEGB, xb) - e * j;
+                const int zi = wave_incl_max(zsrc, lane);
+                int ze = __shfl_up(zi, 1, WAVE);
+                ze = lane == 0 ? carry_z : max(ze, carry_z);
+                int xval = NEGB;
+                if (fixed0 || general) xval = j == 0 ? xb : ze + e * j;
+                // path_x = 'X' iff x[j-1] > m[j-1] + o, i.e. (o < 0) x[j-1] > t[j-1] + o   (:350-368)
+                int xprev = __shfl_up(xval, 1, WAVE), tprev = __shfl_up(tcur, 1, WAVE);
+                if (lane == 0) { xprev = carry_zprev; tprev = carry_t; }
+                const bool xflag = general && j > 0 && o != 0 && xprev > (tprev > NEGB ? tprev + o : NEGB);
+                if (general) {
+                    const int l = xval, uu = yval;
+                    const uint32_t lpred = (uint32_t)((j > 0 ? i : minp) & 0xffff);
+                    int mv; uint32_t w;
+                    if (have_d) {                                    // (:145-180)
+                        if (dv < l) {
+                            if (l < uu) {
+                                if (up_pred == 0) status |= ST_WOULD_PANIC;     // set_path_cell(_, 'u') panics
+                                mv = uu; w = ((uint32_t)(up_pred & 0xffff) << 3) | PD_U;
+                            } else { mv = l; w = (lpred << 3) | PD_L; }
+                        } else {
+                            if (dv < uu) { mv = uu; w = ((uint32_t)(up_pred & 0xffff) << 3) | PD_U; }
+                            else { mv = dv; w = ((uint32_t)(dp & 0xffff) << 3) | (rc == li ? PD_D : PD_d); }
+                        }
+                    } else {                                         // (:181-194)
+                        if (l < uu) { mv = uu; w = ((uint32_t)(up_pred & 0xffff) << 3) | PD_U; }
+                        else { mv = l; w = (lpred << 3) | PD_L; }
+                    }
+                    mval = mv;
+                    w0 = w | (xflag ? 0x80000000u : 0u);
+                    w1 = fromy ? (((uint32_t)(up_pred & 0xffff) << 1) | 1u) : 0u;
+                }
+                if (act) {
+                    am[off + j] = mval;
+                    ay[off + j] = yval;
+                    pw0[off + j] = w0;
+                    pw1[off + j] = w1;
+                }
+                carry_zprev = __shfl(xval, WAVE - 1, WAVE);     // x of the chunk's last column
+                carry_t = __shfl(tcur, WAVE - 1, WAVE);
+                carry_z = max(carry_z, __shfl(zi, WAVE - 1, WAVE));
+            }
+            // best_scoring_pos: last column attaining the row maximum
+            long long key = act ? ((long long)mval * 4294967296ll + (long long)(unsigned)j) : ((long long)INT32_MIN) * 4294967296ll;
+            key = wave_max_ll(key);
+            if ((int)(key >> 32) >= (int)(best_key >> 32)) best_key = key;
+        }
+        // general cells of this row (reference's unit of work)
+        {
+            int general = 0;
+            if (i > 0) general = width - (left == 0 ? 1 : 0);
+            ncells += (unsigned long long)general;
+        }
+        if (lane == 0) rinfo[i] = make_int4((int)off, left, right, (int)(best_key & 0xffffffffll) + left);
+        off += width;
+        __syncthreads();
+    }
+    // combine status bits raised by any lane
+    for (int dd = WAVE / 2; dd >= 1; dd >>= 1) status |= __shfl_xor(status, dd, WAVE);
+    if (overflow) {
+        if (lane == 0) { rec->status = ST_OVERFLOW; rec->n_ops = 0; }
+        return;
+    }
+    if (status & ST_WOULD_PANIC) {
+        if (lane == 0) { rec->status = status; rec->n_ops = 0; rec->score = 0; }
+        return;
+    }
+    if (lane != 0) return;
+
+    // ---- end node (global_abpoa.rs:397-405, gap_global_abpoa.rs:206-214) ----
+    int last_row = L - 2;
+    int4 rl = rinfo[last_row];
+    int last_col = rl.z - rl.y - 1;
+    int bestv = am[rl.x + last_col];
+    for (int ee = g.pred_off[L - 1]; ee < g.pred_off[L]; ++ee) {
+        const int p = g.pred_rows[ee];
+        const int4 rp = rinfo[p];
+        const int tl = rp.z - rp.y - 1;
+        const int v = am[rp.x + tl];
+        if (v > bestv) { bestv = v; last_row = p; last_col = tl; }
+    }
+    auto word0 = [&](int r, int cidx) -> uint32_t { return pw0[rinfo[r].x + cidx]; };
+    auto word1 = [&](int r, int cidx) -> uint32_t { return pw1[rinfo[r].x + cidx]; };
+    auto widthof = [&](int r) { const int4 q = rinfo[r]; return q.z - q.y; };
+    // j_pos of the reference: column of (row, col) translated into pred's band; false = usize wrap
+    auto jpos = [&](int row, int col, int pred, int& out) -> bool {
+        const int lr = rinfo[row].y, lp = rinfo[pred].y;
+        if (lp < lr) { out = col + (lr - lp); return true; }
+        if (col < lp - lr) return false;
+        out = col - (lp - lr);
+        return true;
+    };
+    // ---- band_ampl_enough (global_abpoa.rs:428-476, gap_global_abpoa.rs:371-455) ----
+    {
+        int i = last_row, j = last_col;
+        bool ok = true;
+        int guard = 0;
+        while (true) {
+            if (++guard > 4 * (L + W)) { status |= ST_WOULD_PANIC; break; }
+            if (i < 0 || i >= L - 1 || j < 0 || j >= widthof(i)) { status |= ST_WOULD_PANIC; break; }
+            const uint32_t w = word0(i, j);
+            const uint32_t dir = w & 7u;
+            if (dir == PD_O) break;
+            const int4 ri = rinfo[i];
+            if (i == 0 || (j == 0 && ri.y == 0)) break;
+            if ((j == 0 && ri.y != 0) || (j == ri.z - ri.y - 1 && ri.z != W)) { ok = false; break; }
+            const int pred = (int)((w >> 3) & 0xffffu);
+            if (dir == PD_D || dir == PD_d) {
+                int jp;
+                if (!jpos(i, j, pred, jp) || jp == 0) { status |= ST_WOULD_PANIC; break; }
+                j = jp - 1; i = pred;
+            } else if (dir == PD_L) {
+                if (kGap && (w >> 31)) { while (j > 0 && j < widthof(i) && (word0(i, j) >> 31)) j -= 1; }
+                else j -= 1;
+            } else if (dir == PD_U) {
+                if (kGap && (word1(i, j) & 1u)) {
+                    bool bad = false;
+                    while (true) {
+                        if (j < 0 || j >= widthof(i)) { bad = true; break; }
+                        const uint32_t y1 = word1(i, j);
+                        if (!(y1 & 1u)) break;
+                        const int p = (int)(y1 >> 1);
+                        int jp;
+                        if (!jpos(i, j, p, jp)) { bad = true; break; }
+                        j = jp; i = p;
+                    }
+                    if (bad) { status |= ST_WOULD_PANIC; break; }
+                } else {
+                    int jp;
+                    if (!jpos(i, j, pred, jp)) { status |= ST_WOULD_PANIC; break; }
+                    j = jp; i = pred;
+                }
+            } else { if (kGap) { ok = false; } else { status |= ST_WOULD_PANIC; } break; }
+        }
+        if (!ok) status |= ST_BAND_WARNING;
+    }
+    // ---- traceback (gaf_output.rs:124-213 / 280-344) ----
+    uint8_t* ops = a.ops + (long long)rd * a.ops_stride;
+    int32_t* orow = a.oprows + (long long)rd * a.ops_stride;
+    int nops = 0;
+    int row = last_row, col = last_col;
+    if (!(status & ST_WOULD_PANIC)) {
+        int guard = 0;
+        while (true) {
+            if (++guard > 4 * (L + W) || nops + 2 >= a.ops_stride) { status |= ST_WOULD_PANIC; break; }
+            if (row < 0 || row >= L - 1 || col < 0 || col >= widthof(row)) { status |= ST_WOULD_PANIC; break; }
+            const uint32_t w = word0(row, col);
+            const uint32_t dir = w & 7u;
+            if (dir == PD_O) break;
+            const int pred = (int)((w >> 3) & 0xffffu);
+            int jp = 0;
+            const bool jp_ok = jpos(row, col, pred, jp);
+            if (dir == PD_D || dir == PD_d) {
+                if (!jp_ok || jp == 0) { status |= ST_WOULD_PANIC; break; }
+                ops[nops] = OP_D | (dir == PD_d ? 0x40 : 0); orow[nops] = pred; ++nops;
+                row = pred; col = jp - 1;
+            } else if (dir == PD_L) {
+                if (kGap && (w >> 31)) {
+                    bool first = true, bad = false;
+                    while (true) {
+                        if (col < 0 || col >= widthof(row)) { bad = true; break; }
+                        if (!(word0(row, col) >> 31)) break;
+                        if (col == 0 || nops + 2 >= a.ops_stride) { bad = true; break; }
+                        ops[nops] = OP_L | (first ? 0 : OP_CONT); orow[nops] = -1; ++nops; first = false;
+                        col -= 1;
+                    }
+                    if (bad) { status |= ST_WOULD_PANIC; break; }
+                } else {
+                    if (col == 0) { status |= ST_WOULD_PANIC; break; }
+                    ops[nops] = OP_L; orow[nops] = -1; ++nops; col -= 1;
+                }
+            } else if (dir == PD_U) {
+                if (kGap && (word1(row, col) & 1u)) {
+                    bool first = true, bad = false;
+                    while (true) {
+                        if (col < 0 || col >= widthof(row)) { bad = true; break; }
+                        const uint32_t y1 = word1(row, col);
+                        if (!(y1 & 1u)) break;
+                        const int p = (int)(y1 >> 1);
+                        int jq;
+                        if (!jpos(row, col, p, jq) || nops + 2 >= a.ops_stride) { bad = true; break; }
+                        ops[nops] = OP_U | (first ? 0 : OP_CONT); orow[nops] = p; ++nops; first = false;
+                        col = jq; row = p;
+                    }
+                    if (bad) { status |= ST_WOULD_PANIC; break; }
+                } else {
+                    if (!jp_ok) { status |= ST_WOULD_PANIC; break; }
+                    ops[nops] = OP_U; orow[nops] = pred; ++nops;
+                    row = pred; col = jp;
+                }
+            } else { status |= ST_WOULD_PANIC; break; }
+        }
+    }
+    rec->status = status;
+    rec->score = bestv;
+    rec->fscore = (float)bestv;
+    rec->end_row = last_row;
+    rec->end_col = last_col + rinfo[last_row].y;   // query_end = last_col + left(last_row)
+    rec->stop_row = row;
+    rec->stop_col = col;                           // query_start = band-relative col where the walk stopped
+    rec->n_ops = (status & ST_WOULD_PANIC) ? 0 : nops;
+    rec->n_fwd_ops = 0;
+    atomicAdd(a.cells, ncells);
+}
+
+void launch_m2(const PoaArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL((k_poa_banded<true>), dim3(a.nreads), dim3(64), 0, s, a);
+}
+void launch_m0_scalar(const PoaArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL((k_poa_banded<false>), dim3(a.nreads), dim3(64), 0, s, a);
+}
+
+}  // namespace rg
