@@ -124,7 +124,10 @@ def main():
             tj = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.config)
             if os.path.exists(tj):
                 try:
-                    traffic = json.load(open(tj)).get("hbm_bytes_per_launch")
+                    tr = json.load(open(tj))
+                    # measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on the same kernel;
+                    # scaled from the profiled batch to this run's batch (traffic is per read)
+                    traffic = round(tr["hbm_bytes_per_read_per_launch"] * batch)
                 except Exception:
                     traffic = None
             roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
