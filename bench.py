@@ -87,20 +87,10 @@ def main():
             a = kstats.setdefault(k, [0.0, 0])
             a[0] += ms
             a[1] += n
-    gathered_bytes = len(text)
-    if dist_on:
-        # final gather of the GAF records (text) to rank 0 over RCCL/xGMI
-        t = torch.frombuffer(bytearray(text), dtype=torch.uint8).cuda()
-        ln = torch.tensor([t.numel()], device="cuda", dtype=torch.int64)
-        lens = [torch.zeros_like(ln) for _ in range(world)]
-        dist.all_gather(lens, ln)
-        mx = int(max(int(x.item()) for x in lens))
-        pad = torch.zeros(mx, dtype=torch.uint8, device="cuda")
-        pad[: t.numel()] = t
-        outs = [torch.zeros_like(pad) for _ in range(world)] if rank == 0 else None
-        dist.gather(pad, outs, dst=0)
-        if rank == 0:
-            gathered_bytes = int(sum(int(x.item()) for x in lens))
+    # final gather of the GAF records (text) to rank 0 over RCCL/xGMI
+    from recgraph_amd.shard import gather_text
+    parts = gather_text(text, rank, world, device="cuda" if dist_on else "cpu")
+    gathered_bytes = sum(len(x) for x in parts) if parts is not None else 0
     sync()
     dt = time.perf_counter() - t0
     if dist_on:
