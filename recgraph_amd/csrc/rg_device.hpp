@@ -57,6 +57,35 @@ __device__ __forceinline__ int wave_incl_max(int v, int lane) {
     }
     return v;
 }
+// ---- DPP wave-level primitives (gfx9 family: row_shr, row_bcast15/31, wave_shr) ----
+// A ds_bpermute-based __shfl scan costs six dependent LDS-crossbar round trips; the DPP forms below are six
+// dependent VALU instructions.
+template <int kCtrl, int kRowMask>
+__device__ __forceinline__ int dpp_mov(int identity, int v) {
+    return __builtin_amdgcn_update_dpp(identity, v, kCtrl, kRowMask, 0xf, false);
+}
+// value of lane-1 (lane 0 gets `identity`)
+__device__ __forceinline__ int dpp_shr1(int v, int identity) { return dpp_mov<0x138, 0xf>(identity, v); }
+
+__device__ __forceinline__ int dpp_incl_max(int v, int identity) {
+    v = max(v, dpp_mov<0x111, 0xf>(identity, v));   // row_shr:1
+    v = max(v, dpp_mov<0x112, 0xf>(identity, v));   // row_shr:2
+    v = max(v, dpp_mov<0x114, 0xf>(identity, v));   // row_shr:4
+    v = max(v, dpp_mov<0x118, 0xf>(identity, v));   // row_shr:8
+    v = max(v, dpp_mov<0x142, 0xa>(identity, v));   // row_bcast:15 into rows 1 and 3
+    v = max(v, dpp_mov<0x143, 0xc>(identity, v));   // row_bcast:31 into rows 2 and 3
+    return v;
+}
+__device__ __forceinline__ int dpp_incl_sum(int v) {
+    v += dpp_mov<0x111, 0xf>(0, v);
+    v += dpp_mov<0x112, 0xf>(0, v);
+    v += dpp_mov<0x114, 0xf>(0, v);
+    v += dpp_mov<0x118, 0xf>(0, v);
+    v += dpp_mov<0x142, 0xa>(0, v);
+    v += dpp_mov<0x143, 0xc>(0, v);
+    return v;
+}
+
 __device__ __forceinline__ long long wave_max_ll(long long v) {
 #pragma unroll
     for (int d = WAVE / 2; d >= 1; d >>= 1) {

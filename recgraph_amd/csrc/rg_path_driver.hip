@@ -122,6 +122,15 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
     // (one wave per CU at P = 32, n = 1000) measured 3.3x slower on MI355X (profiles/r01_notes.md).
     bool lds = false;
     if (getenv("RG_ROWS_IN_LDS")) lds = (size_t)P * wpad * sizeof(int) + 64 * sizeof(int) <= 160 * 1024;
+    // experimental second-generation sweep (RG_SWEEP_REG=1): rolling rows in registers, paths split over the
+    // waves of a workgroup.  Parity-green but measured slower than k_sweep on MI355X (profiles/r01_notes.md),
+    // so it is not the default.
+    const bool use_reg = C <= 16 && getenv("RG_SWEEP_REG") != nullptr;
+    if (use_reg) lds = true;   // no HBM rolling-row buffer needed
+    auto sweep = [&](const SweepArgs& sa_, int nr) {
+        if (use_reg) launch_sweep_reg(sa_, nr, C, stream);
+        else launch_sweep(sa_, nr, C, lds, stream);
+    };
     int rc;
     if (!w.tables) {
         // rows of every path in program order, with the direction-word slot of the group holding the path
@@ -199,19 +208,19 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
         if (mode == RG_MODE_PATHWISE) {
             SweepArgs f = sa;
             f.rev = 0; f.track_best = 0; f.dirs = w.fdirs.p; f.dirs_stride = fdirs_stride; f.count_cells = 1;
-            TIMED(T, "k_sweep_fwd", launch_sweep(f, chunk, C, lds, stream));
+            TIMED(T, "k_sweep_fwd", sweep(f, chunk));
             TIMED(T, "k_seed", launch_seed(se, stream));
         } else {
             SweepArgs f1 = sa;
             f1.rev = 0; f1.track_best = 1; f1.colmax_out = w.mf.p; f1.colarg_out = w.mfarg.p; f1.count_cells = 0;
-            TIMED(T, "k_sweep_fwd_colmax", launch_sweep(f1, chunk, C, lds, stream));
+            TIMED(T, "k_sweep_fwd_colmax", sweep(f1, chunk));
             TIMED(T, "k_seed", launch_seed(se, stream));
             ThrArgs t1{w.state.p, w.mf.p, w.thr.p, wpad, p.base_rec_cost, 0};
             TIMED(T, "k_threshold", launch_threshold(t1, chunk, stream));
             SweepArgs r = sa;
             r.rev = 1; r.track_best = 1; r.thr = w.thr.p; r.colmax_out = w.wr.p; r.colarg_out = w.wrarg.p; r.cand = w.rcand.p; r.cand_cap = w.rcap; r.ncand_out = w.nr.p;
             r.dirs = w.rdirs.p; r.dirs_stride = rdirs_stride; r.count_cells = 1;
-            TIMED(T, "k_sweep_rev", launch_sweep(r, chunk, C, lds, stream));
+            TIMED(T, "k_sweep_rev", sweep(r, chunk));
             BoundArgs ba{gd, w.state.p, off, w.mf.p, w.mfarg.p, w.wr.p, w.wrarg.p, wpad, p.base_rec_cost, p.multi_rec_cost,
                          p.rec_band_width};
             TIMED(T, "k_bound", launch_bound(ba, chunk, stream));
@@ -220,7 +229,7 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
             SweepArgs f2 = sa;
             f2.rev = 0; f2.track_best = 1; f2.thr = w.thr.p; f2.cand = w.fcand.p; f2.cand_cap = w.fcap; f2.ncand_out = w.nf.p;
             f2.dirs = w.fdirs.p; f2.dirs_stride = fdirs_stride; f2.count_cells = 1;
-            TIMED(T, "k_sweep_fwd", launch_sweep(f2, chunk, C, lds, stream));
+            TIMED(T, "k_sweep_fwd", sweep(f2, chunk));
             SearchArgs sr{gd, w.state.p, w.fcand.p, w.rcand.p, w.nf.p, w.nr.p, w.ridx.p, w.fcap, w.rcap, wpad, p.base_rec_cost,
                           p.multi_rec_cost};
             TIMED(T, "k_search", launch_search(sr, chunk, stream));

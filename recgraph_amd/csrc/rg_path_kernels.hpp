@@ -123,6 +123,7 @@ struct TraceArgs {
 };
 
 void launch_sweep(const SweepArgs& a, int nreads, int C, bool lds, hipStream_t s);
+void launch_sweep_reg(const SweepArgs& a, int nreads, int C, hipStream_t s);
 void launch_seed(const SeedArgs& a, hipStream_t s);
 void launch_threshold(const ThrArgs& a, int nreads, hipStream_t s);
 void launch_bound(const BoundArgs& a, int nreads, hipStream_t s);

@@ -21,6 +21,9 @@
 namespace rg {
 
 constexpr int NEG = INT32_MIN / 4;
+#ifndef RG_SWEEP_WAVES
+#define RG_SWEEP_WAVES 2
+#endif
 
 template <bool kLds>
 struct Rows {
@@ -39,14 +42,13 @@ template <>
 __device__ __forceinline__ void Rows<false>::st(int k, int idx, int wpad, int v) const { base[(long long)k * wpad + idx] = v; }
 
 __device__ __forceinline__ int wave_excl_max(int v, int lane) {
-    int inc = wave_incl_max(v, lane);
-    int e = __shfl_up(inc, 1, WAVE);
-    return lane == 0 ? NEG : e;
+    (void)lane;
+    return dpp_shr1(dpp_incl_max(v, NEG), NEG);
 }
 
 // One DP sweep over the whole graph for one read.
 template <int C, bool kLds>
-__global__ __launch_bounds__(64) void k_sweep(SweepArgs a) {
+__global__ __launch_bounds__(64, RG_SWEEP_WAVES) void k_sweep(SweepArgs a) {
     const int rd = blockIdx.x;
     const int lane = threadIdx.x;
     const PathGraphDev& g = a.g;
@@ -135,7 +137,7 @@ __global__ __launch_bounds__(64) void k_sweep(SweepArgs a) {
             int old[C];
 #pragma unroll
             for (int q = 0; q < C; ++q) old[q] = rows.ld(ga, q * WAVE + lane, wpad);
-            int prevcol = __shfl_up(old[C - 1], 1, WAVE);
+            int prevcol = dpp_shr1(old[C - 1], NEG);
             unsigned dmask = 0, lmask = 0;  // bit q: direction D / L of column q
             int x[C];                        // candidate minus GP
             int runmax = NEG;
@@ -169,9 +171,7 @@ __global__ __launch_bounds__(64) void k_sweep(SweepArgs a) {
                 newv[q] = y + GP[q];
             }
             // nearest lane to the left that owns a non-L column (fill-forward source for member paths)
-            int src = wave_incl_max(any_nonl ? lane : -1, lane);
-            src = __shfl_up(src, 1, WAVE);
-            if (lane == 0) src = 0;
+            const int src = dpp_shr1(dpp_incl_max(any_nonl ? lane : -1, -1), 0);
             (void)nonl_last;
             // store alpha row, track best-of-row
 #pragma unroll
@@ -213,7 +213,7 @@ __global__ __launch_bounds__(64) void k_sweep(SweepArgs a) {
                 int ok[C];
 #pragma unroll
                 for (int q = 0; q < C; ++q) ok[q] = rows.ld(k, q * WAVE + lane, wpad);
-                const int pk = __shfl_up(ok[C - 1], 1, WAVE);
+                const int pk = dpp_shr1(ok[C - 1], NEG);
                 int y[C];
                 int last = NEG;
 #pragma unroll
@@ -569,10 +569,8 @@ __global__ __launch_bounds__(64) void k_layer(LayerArgs a) {
 #pragma unroll
         for (int q = 0; q < C; ++q) if (act[q]) actmask |= 1u << q;
         const bool any_nonl = ((~lmask) & actmask) != 0;
-        int src = wave_incl_max(any_nonl ? lane : -1, lane);
-        src = __shfl_up(src, 1, WAVE);
-        if (lane == 0) src = 0;
-        const int pk = __shfl_up(cur[C - 1], 1, WAVE);
+        const int src = dpp_shr1(dpp_incl_max(any_nonl ? lane : -1, -1), 0);
+        const int pk = dpp_shr1(cur[C - 1], NEG);
         int y[C];
         int last = NEG;
 #pragma unroll
