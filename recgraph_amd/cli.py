@@ -1,0 +1,86 @@
+"""Command line front-end mirroring the mode dispatch of the reference's ``src/main.rs`` for the modes on
+the accelerated path (``-m 0, 2, 4, 8``): same positional arguments, flag names and defaults
+(``src/args_parser.rs:3-147``), GAF on stdout (or appended to ``-o``), ``Done in N.`` on stderr.
+
+    python -m recgraph_amd.cli reads.fa graph.gfa -m 8 -R 4 -r 0.1 -B 1
+"""
+import argparse
+import sys
+import time
+
+
+def get_sequences(path):
+    """sequences::get_sequences (sequences.rs:5-45): names = header minus '>', bases upper-cased, '-' -> 'N'
+    (the '$' prefix is added inside the library)."""
+    seqs, names, cur = [], [], []
+    with open(path) as f:
+        for line in f:
+            line = line.rstrip("\n").rstrip("\r")
+            if line.startswith(">"):
+                names.append(line[1:])
+                if cur:
+                    seqs.append("".join(cur))
+                cur = []
+            elif line:
+                cur.append("".join("N" if c == "-" else c.upper() for c in line))
+    if cur:
+        seqs.append("".join(cur))
+    if len(seqs) != len(names):
+        raise SystemExit("wrong fasta file format")      # sequences.rs:41-43
+    return seqs, names
+
+
+def build_parser():
+    p = argparse.ArgumentParser(prog="recgraph-hip", description="RecGraph DP hot path on MI355X")
+    p.add_argument("sequence_path")
+    p.add_argument("graph_path")
+    p.add_argument("-o", "--out_file", default="standard output")
+    p.add_argument("-m", "--aln-mode", type=int, default=0, dest="alignment_mode")
+    p.add_argument("-M", "--match", type=int, default=2, dest="match_score")
+    p.add_argument("-X", "--mismatch", type=int, default=4, dest="mismatch_score")
+    p.add_argument("-t", "--matrix", default="none")
+    p.add_argument("-O", "--gap-open", type=int, default=4)
+    p.add_argument("-E", "--gap-ext", type=int, default=2, dest="gap_extension")
+    p.add_argument("-r", "--multi-rec-cost", type=float, default=0.1)
+    p.add_argument("-R", "--base-rec-cost", type=int, default=4)
+    p.add_argument("-B", "--rec-band-width", type=float, default=1.0)
+    p.add_argument("-s", "--amb-strand", default="false", choices=["true", "false"])
+    p.add_argument("-b", "--extra-b", type=int, default=1)
+    p.add_argument("-f", "--extra-f", type=float, default=0.01)
+    p.add_argument("--scalar", action="store_true", help="-m 0 with the non-AVX2 path of the reference")
+    return p
+
+
+def main(argv=None):
+    t0 = time.time()
+    a = build_parser().parse_args(argv)
+    from . import api
+    if a.alignment_mode not in (0, 2, 4, 8):
+        raise SystemExit("Alignment mode must be one of 0, 2, 4, 8 on the accelerated path")   # main.rs:315-317
+    if a.amb_strand == "true":
+        raise SystemExit("-s true (reverse strand retry) is outside the accelerated path")
+    if a.matrix in ("none",):
+        scores = api.create_score_matrix_i32(a.match_score, -a.mismatch_score)   # args_parser.rs:155
+    else:
+        scores = api.create_score_matrix_i32(matrix_file_path=a.matrix if a.matrix.endswith(".mtx") else a.matrix + ".mtx")
+    seqs, names = get_sequences(a.sequence_path)
+    g = api.Graph.from_gfa(a.graph_path)
+    mode = {0: api.MODE_GLOBAL_POA_SCALAR if a.scalar else api.MODE_GLOBAL_POA, 2: api.MODE_GAP_POA,
+            4: api.MODE_PATHWISE, 8: api.MODE_RECOMBINATION}[a.alignment_mode]
+    texts, status = api.align_batch(g, seqs, names, mode=mode, score_matrix=scores, o=-a.gap_open, e=-a.gap_extension,
+                                    b=float(a.extra_b), f=a.extra_f, R=a.base_rec_cost, r=a.multi_rec_cost,
+                                    B=a.rec_band_width)
+    for i, st in enumerate(status):
+        if st & (api.READ_WOULD_PANIC | api.READ_BAD_BASE):
+            raise SystemExit("read %d (%s): the reference panics on this input" % (i, names[i]))
+    out = "".join(texts)
+    if a.out_file == "standard output":
+        sys.stdout.write(out)
+    else:
+        with open(a.out_file, "w") as f:      # one write of all records (the reference re-opens per read, utils.rs:200-219)
+            f.write(out)
+    sys.stderr.write("Done in %d.\n" % int(time.time() - t0))    # main.rs:319-323
+
+
+if __name__ == "__main__":
+    main()
