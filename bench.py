@@ -28,7 +28,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", default="C5", choices=["C2", "C4", "C5"])
+    ap.add_argument("--config", default="C5", choices=["C2", "C3", "C4", "C5"])
     ap.add_argument("--batch", type=int, default=0, help="reads per step per GPU (default: per config)")
     ap.add_argument("--cpu-reads", type=int, default=-1, help="reads of the cpu_baseline sample (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true")
@@ -49,11 +49,11 @@ def main():
 
     cfg = synth.CONFIGS[args.config]
     mode = cfg["mode"]
-    batch = args.batch or {"C2": 10000, "C4": 4096, "C5": 4096}[args.config]
+    batch = args.batch or {"C2": 10000, "C3": 10000, "C4": 4096, "C5": 4096}[args.config]
     # every rank works on its own shard of the synthetic read set (seeded by rank): weak scaling
     sg, _, _ = synth.make_config(args.config, n_reads=1)
     num = int(args.config[1])
-    if args.config == "C2":
+    if args.config in ("C2", "C3"):
         reads = synth.substring_reads(sg, batch, cfg["n"], seed=5678 + num + 1000 * rank)
     else:
         reads = synth.haplotype_reads(sg, batch, cfg["n"], seed=5678 + num + 1000 * rank,

@@ -48,6 +48,7 @@ struct PathWorkImpl {
     Buf<uint32_t> fdirs, rdirs;
     Buf<Cand> fcand, rcand;
     Buf<unsigned> nf, nr, ridx;
+    Buf<int> lb;
     unsigned fcap = 0, rcap = 0;
     std::vector<hipEvent_t> ev;
     ~PathWorkImpl() { for (auto e : ev) (void)hipEventDestroy(e); }
@@ -170,7 +171,16 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
         size_t fr = 0, tot = 0;
         if (hipMemGetInfo(&fr, &tot) == hipSuccess) budget = fr / 4 * 3;
     }
-    if (w.fcap == 0) { w.fcap = 1u << 15; w.rcap = 1u << 19; }
+    // -m 8 pipeline: two sweeps (forward with a loose threshold from the exact path-0 score, then reverse) when
+    // every gap entry is <= 0 (then w[.][j] <= (n - j) * max match); three sweeps otherwise / on request
+    int maxmatch = 0;
+    bool gaps_nonpos = true;
+    for (int x = 0; x < 5; ++x) {
+        gaps_nonpos = gaps_nonpos && p.scores[x * 6 + 5] <= 0 && p.scores[5 * 6 + x] <= 0;
+        for (int y = 0; y < 5; ++y) maxmatch = std::max(maxmatch, p.scores[x * 6 + y]);
+    }
+    const bool two_sweep = mode == RG_MODE_RECOMBINATION && gaps_nonpos && !use_reg && !getenv("RG_THREE_SWEEPS");
+    if (w.fcap == 0) { w.fcap = two_sweep ? 1u << 20 : 1u << 15; w.rcap = 1u << 19; }
     stats.clear();
     HIPCHK(hipMemsetAsync(d_cells, 0, sizeof(unsigned long long), stream));
     Timer T{&w, stream};
@@ -192,7 +202,7 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
                 (rc = w.mfarg.alloc((size_t)chunk * wpad)) || (rc = w.wrarg.alloc((size_t)chunk * wpad)) ||
                 (rc = w.thr.alloc((size_t)chunk * wpad)) || (rc = w.fcand.alloc((size_t)chunk * w.fcap)) ||
                 (rc = w.rcand.alloc((size_t)chunk * w.rcap)) || (rc = w.ridx.alloc((size_t)chunk * w.rcap)) ||
-                (rc = w.nf.alloc(chunk)) || (rc = w.nr.alloc(chunk)))
+                (rc = w.nf.alloc(chunk)) || (rc = w.nr.alloc(chunk)) || (rc = w.lb.alloc(chunk)))
                 return rc;
         }
         const uint8_t* bad = d_bad + done;
@@ -211,10 +221,21 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
             TIMED(T, "k_sweep_fwd", sweep(f, chunk));
             TIMED(T, "k_seed", launch_seed(se, stream));
         } else {
-            SweepArgs f1 = sa;
-            f1.rev = 0; f1.track_best = 1; f1.colmax_out = w.mf.p; f1.colarg_out = w.mfarg.p; f1.count_cells = 0;
-            TIMED(T, "k_sweep_fwd_colmax", sweep(f1, chunk));
-            TIMED(T, "k_seed", launch_seed(se, stream));
+            if (two_sweep) {
+                Opt0Args oa{gd, sa.sc, d_reads, off, bad, w.fpoff.p, w.fprow.p, w.lb.p};
+                TIMED(T, "k_opt0", launch_opt0(oa, chunk, C, stream));
+                SweepArgs f = sa;
+                f.rev = 0; f.track_best = 1; f.lb = w.lb.p; f.brc = p.base_rec_cost; f.maxmatch = maxmatch;
+                f.colmax_out = w.mf.p; f.colarg_out = w.mfarg.p; f.cand = w.fcand.p; f.cand_cap = w.fcap; f.ncand_out = w.nf.p;
+                f.dirs = w.fdirs.p; f.dirs_stride = fdirs_stride; f.count_cells = 1;
+                TIMED(T, "k_sweep_fwd", sweep(f, chunk));
+                TIMED(T, "k_seed", launch_seed(se, stream));
+            } else {
+                SweepArgs f1 = sa;
+                f1.rev = 0; f1.track_best = 1; f1.colmax_out = w.mf.p; f1.colarg_out = w.mfarg.p; f1.count_cells = 0;
+                TIMED(T, "k_sweep_fwd_colmax", sweep(f1, chunk));
+                TIMED(T, "k_seed", launch_seed(se, stream));
+            }
             ThrArgs t1{w.state.p, w.mf.p, w.thr.p, wpad, p.base_rec_cost, 0};
             TIMED(T, "k_threshold", launch_threshold(t1, chunk, stream));
             SweepArgs r = sa;
@@ -224,13 +245,15 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
             BoundArgs ba{gd, w.state.p, off, w.mf.p, w.mfarg.p, w.wr.p, w.wrarg.p, wpad, p.base_rec_cost, p.multi_rec_cost,
                          p.rec_band_width};
             TIMED(T, "k_bound", launch_bound(ba, chunk, stream));
-            ThrArgs t2{w.state.p, w.wr.p, w.thr.p, wpad, p.base_rec_cost, 1};
-            TIMED(T, "k_threshold", launch_threshold(t2, chunk, stream));
-            SweepArgs f2 = sa;
-            f2.rev = 0; f2.track_best = 1; f2.thr = w.thr.p; f2.cand = w.fcand.p; f2.cand_cap = w.fcap; f2.ncand_out = w.nf.p;
-            f2.dirs = w.fdirs.p; f2.dirs_stride = fdirs_stride; f2.count_cells = 1;
-            TIMED(T, "k_sweep_fwd", sweep(f2, chunk));
-            SearchArgs sr{gd, w.state.p, w.fcand.p, w.rcand.p, w.nf.p, w.nr.p, w.ridx.p, w.fcap, w.rcap, wpad, p.base_rec_cost,
+            if (!two_sweep) {
+                ThrArgs t2{w.state.p, w.wr.p, w.thr.p, wpad, p.base_rec_cost, 1};
+                TIMED(T, "k_threshold", launch_threshold(t2, chunk, stream));
+                SweepArgs f2 = sa;
+                f2.rev = 0; f2.track_best = 1; f2.thr = w.thr.p; f2.cand = w.fcand.p; f2.cand_cap = w.fcap; f2.ncand_out = w.nf.p;
+                f2.dirs = w.fdirs.p; f2.dirs_stride = fdirs_stride; f2.count_cells = 1;
+                TIMED(T, "k_sweep_fwd", sweep(f2, chunk));
+            }
+            SearchArgs sr{gd, w.state.p, w.fcand.p, w.rcand.p, w.nf.p, w.nr.p, w.ridx.p, w.fcap, w.rcap, w.wr.p, wpad, p.base_rec_cost,
                           p.multi_rec_cost};
             TIMED(T, "k_search", launch_search(sr, chunk, stream));
             // candidate-list overflow: regrow and redo this chunk

@@ -32,6 +32,9 @@ struct SweepArgs {
     int rev;                   // 0 forward sweep, 1 reverse sweep
     int track_best;            // maintain the best member per (row, col) (m8)
     const int* thr;            // [reads][wpad] emission thresholds by real column, or null
+    const int* lb;             // per read lower bound of S0: when set (forward sweep only) the threshold of column
+                               // j is lb + brc - (n - j) * maxmatch (no reverse information needed)
+    int brc, maxmatch;
     float rbw;                 // -B: columns outside the recombination band never emit
     int* colmax_out;           // [reads][wpad] per-column maximum of the best members, or null
     int* colarg_out;           // [reads][wpad] (row << 8 | path) of a cell attaining that maximum
@@ -74,6 +77,16 @@ struct BoundArgs {
     float rbw;
 };
 
+struct Opt0Args {
+    PathGraphDev g;
+    DevScores sc;
+    const uint8_t* reads;
+    const long long* read_off;
+    const uint8_t* bad;
+    const int* fpoff; const int* fprow;
+    int* lb;                   // out: exact global alignment score of the read against path 0
+};
+
 struct SearchArgs {
     PathGraphDev g;
     ReadState* state;
@@ -83,6 +96,8 @@ struct SearchArgs {
     const unsigned* nr;
     unsigned* ridx;
     unsigned fcap, rcap;
+    const int* wr;             // [reads][wpad] reverse column maxima: forward candidates are re-filtered with the
+                               // final bound before pairing (they may have been emitted with the loose lb threshold)
     int wpad;
     int brc;
     float mrc;
@@ -125,6 +140,7 @@ struct TraceArgs {
 void launch_sweep(const SweepArgs& a, int nreads, int C, bool lds, hipStream_t s);
 void launch_sweep_reg(const SweepArgs& a, int nreads, int C, hipStream_t s);
 void launch_seed(const SeedArgs& a, hipStream_t s);
+void launch_opt0(const Opt0Args& a, int nreads, int C, hipStream_t s);
 void launch_threshold(const ThrArgs& a, int nreads, hipStream_t s);
 void launch_bound(const BoundArgs& a, int nreads, hipStream_t s);
 void launch_search(const SearchArgs& a, int nreads, hipStream_t s);

@@ -99,7 +99,10 @@ __global__ __launch_bounds__(64, RG_SWEEP_WAVES) void k_sweep(SweepArgs a) {
             const int c = lane * C + q;
             const int j = rev ? n - c : c;
             thr[q] = INT32_MAX;
-            if (a.thr && act[q] && j >= oob && j < n + 1 - oob) thr[q] = a.thr[(long long)rd * wpad + j];
+            if (act[q] && j >= oob && j < n + 1 - oob) {
+                if (a.thr) thr[q] = a.thr[(long long)rd * wpad + j];
+                else if (a.lb) thr[q] = a.lb[rd] + a.brc - (n - j) * a.maxmatch;   // w[.][j] <= (n - j) * maxmatch
+            }
         }
     }
     // start rows: row 0 (forward) / row L-1 (reverse) is the gap-only row, identical for every path
@@ -126,9 +129,10 @@ __global__ __launch_bounds__(64, RG_SWEEP_WAVES) void k_sweep(SweepArgs a) {
         int s[C];
 #pragma unroll
         for (int q = 0; q < C; ++q) s[q] = sct[li * 6 + er[q]];
-        int bestv[C], bestk[C];
+        // best member of the row per column as one packed key (value * 64 + path id): a single max per cell
+        int bkey[C];
 #pragma unroll
-        for (int q = 0; q < C; ++q) { bestv[q] = NEG; bestk[q] = -1; }
+        for (int q = 0; q < C; ++q) bkey[q] = INT32_MIN;
 
         for (int gi = goff[i]; gi < goff[i + 1]; ++gi) {
             const GroupDesc gd = groups[gi];
@@ -177,7 +181,7 @@ __global__ __launch_bounds__(64, RG_SWEEP_WAVES) void k_sweep(SweepArgs a) {
 #pragma unroll
             for (int q = 0; q < C; ++q) {
                 rows.st(ga, q * WAVE + lane, wpad, act[q] ? newv[q] : NEG);
-                if (newv[q] > bestv[q] || (newv[q] == bestv[q] && ga > bestk[q])) { bestv[q] = newv[q]; bestk[q] = ga; }
+                if (a.track_best && act[q]) bkey[q] = max(bkey[q], newv[q] * 64 + ga);
             }
             if (dirs) {
                 // 2 bits per column: 1 = D, 2 = U, 3 = L
@@ -230,7 +234,7 @@ __global__ __launch_bounds__(64, RG_SWEEP_WAVES) void k_sweep(SweepArgs a) {
                     if ((lmask >> q) & 1) y[q] = cur; else cur = y[q];
                     const int v = act[q] ? y[q] + GP[q] : NEG;
                     rows.st(k, q * WAVE + lane, wpad, v);
-                    if (v > bestv[q] || (v == bestv[q] && k > bestk[q])) { bestv[q] = v; bestk[q] = k; }
+                    if (a.track_best && act[q]) bkey[q] = max(bkey[q], v * 64 + k);
                 }
             }
             // no barrier: every lane only ever re-reads the row words it wrote itself
@@ -242,10 +246,11 @@ __global__ __launch_bounds__(64, RG_SWEEP_WAVES) void k_sweep(SweepArgs a) {
 #pragma unroll
             for (int q = 0; q < C; ++q) {
                 // argmax over ALL P entries where non-members hold 0: usable only if the winner is a member
-                const bool valid = act[q] && bestk[q] >= 0 && (knm < 0 || bestv[q] > 0 || (bestv[q] == 0 && bestk[q] > knm));
+                const int bv = bkey[q] >> 6, bk = bkey[q] & 63;
+                const bool valid = act[q] && bkey[q] != INT32_MIN && (knm < 0 || bv > 0 || (bv == 0 && bk > knm));
                 if (valid) {
-                    if (bestv[q] > colmax[q]) { colmax[q] = bestv[q]; colarg[q] = (i << 8) | bestk[q]; }
-                    if (bestv[q] >= thr[q]) emask |= 1u << q;
+                    if (bv > colmax[q]) { colmax[q] = bv; colarg[q] = (i << 8) | bk; }
+                    if (bv >= thr[q]) emask |= 1u << q;
                 }
             }
             if (cand && __any(emask != 0)) {
@@ -259,7 +264,7 @@ __global__ __launch_bounds__(64, RG_SWEEP_WAVES) void k_sweep(SweepArgs a) {
                         if (pos < a.cand_cap) {
                             const int c = lane * C + q;
                             Cand cd;
-                            cd.row = i; cd.col = rev ? n - c : c; cd.val = bestv[q]; cd.path = bestk[q];
+                            cd.row = i; cd.col = rev ? n - c : c; cd.val = bkey[q] >> 6; cd.path = bkey[q] & 63;
                             cand[pos] = cd;
                         }
                         ++pos;
@@ -294,6 +299,73 @@ __global__ __launch_bounds__(64, RG_SWEEP_WAVES) void k_sweep(SweepArgs a) {
 }
 
 // ---------------------------------------------------------------------------------
+// Exact global alignment score of the read against path 0.  Path 0 has the lowest id, so it is the alpha of
+// every group it belongs to: its layer is a plain NW recurrence and A[sink][n][0] <= S0 (the seed of the
+// recombination search).  One wave per read, rows of path 0 only (1/P of a sweep).
+template <int C>
+__global__ __launch_bounds__(64) void k_opt0(Opt0Args a) {
+    const int rd = blockIdx.x;
+    const int lane = threadIdx.x;
+    const PathGraphDev& g = a.g;
+    const long long ro = a.read_off[rd];
+    const int n = (int)(a.read_off[rd + 1] - ro);
+    if (a.bad[rd] || n + 1 > C * WAVE) { if (lane == 0) a.lb[rd] = INT32_MIN / 2; return; }
+    const uint8_t* read = a.reads + ro - 1;
+    const int ncols = n + 1, GAP = 5;
+    __shared__ int sct[36];
+    if (lane < 36) sct[lane] = a.sc.t[lane];
+    __syncthreads();
+    int er[C], GP[C], row[C];
+    {
+        int run = 0;
+#pragma unroll
+        for (int q = 0; q < C; ++q) {
+            const int c = lane * C + q;
+            int code = 4;
+            if (c >= 1 && c < ncols) code = read[c];
+            er[q] = code;
+            run += (c >= 1 && c < ncols) ? sct[code * 6 + GAP] : 0;
+            GP[q] = run;
+        }
+        const int pre = dpp_incl_sum(run) - run;
+#pragma unroll
+        for (int q = 0; q < C; ++q) { GP[q] += pre; row[q] = lane * C + q < ncols ? GP[q] : NEG; }
+    }
+    const int beg = a.fpoff[0], cnt = a.fpoff[1] - beg;
+    for (int t = 0; t < cnt; ++t) {
+        const int i = a.fprow[beg + t];
+        const int li = g.lnz[i];
+        const int g_i = sct[li * 6 + GAP];
+        int prev_old = dpp_shr1(row[C - 1], NEG);
+        int runmax = NEG;
+#pragma unroll
+        for (int q = 0; q < C; ++q) {
+            const int c = lane * C + q;
+            const int old = row[q];
+            const int d = prev_old + sct[li * 6 + er[q]], u = old + g_i;
+            int du = (c != 0 && d >= u) ? d : u;
+            du = c < ncols ? du : NEG;
+            prev_old = old;
+            row[q] = du - GP[q];
+            runmax = max(runmax, row[q]);
+        }
+        int run = dpp_shr1(dpp_incl_max(runmax, NEG), NEG);
+#pragma unroll
+        for (int q = 0; q < C; ++q) {
+            const int c = lane * C + q;
+            const int x = row[q];
+            const int y = max(run, x);
+            row[q] = c < ncols ? y + GP[q] : NEG;
+            run = y;
+        }
+    }
+    const int ln = n / C, ql = n % C;
+    int v = NEG;
+#pragma unroll
+    for (int q = 0; q < C; ++q) if (q == ql) v = row[q];
+    if (lane == ln) a.lb[rd] = v;
+}
+
 // After the forward sweep: seed / best path (pathwise_alignment.rs:305-325,
 // pathwise_alignment_recombination.rs:775-803).  One thread per read.
 __global__ void k_seed(SeedArgs a) {
@@ -443,6 +515,9 @@ __global__ __launch_bounds__(64) void k_search(SearchArgs a) {
         const unsigned t = base + lane;
         if (t < nf) {
             const Cand f = fc[t];
+            // forward candidates may come from the loose lower-bound threshold: keep only those that can reach
+            // the final bound with the best reverse partner of their column
+            if (f.val + a.wr[(long long)rd * wpad + f.col] - a.brc < bound) continue;
             const int b0 = hist[f.col], b1 = hist[f.col + 1];
             const unsigned long long idf = g.node_id[f.row];
             const int cond_f = g.seglast[f.row];
@@ -709,6 +784,14 @@ void launch_sweep(const SweepArgs& a, int nreads, int C, bool lds, hipStream_t s
 }
 void launch_seed(const SeedArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(k_seed, dim3((a.nreads + 63) / 64), dim3(64), 0, s, a);
+}
+void launch_opt0(const Opt0Args& a, int nreads, int C, hipStream_t s) {
+    switch (C) {
+        case 4: hipLaunchKernelGGL((k_opt0<4>), dim3(nreads), dim3(64), 0, s, a); break;
+        case 8: hipLaunchKernelGGL((k_opt0<8>), dim3(nreads), dim3(64), 0, s, a); break;
+        case 16: hipLaunchKernelGGL((k_opt0<16>), dim3(nreads), dim3(64), 0, s, a); break;
+        default: hipLaunchKernelGGL((k_opt0<32>), dim3(nreads), dim3(64), 0, s, a); break;
+    }
 }
 void launch_threshold(const ThrArgs& a, int nreads, hipStream_t s) {
     hipLaunchKernelGGL(k_threshold, dim3((a.wpad + 255) / 256, nreads), dim3(256), 0, s, a);
