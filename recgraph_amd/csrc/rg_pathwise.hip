@@ -46,8 +46,76 @@ __device__ __forceinline__ int wave_excl_max(int v, int lane) {
     return dpp_shr1(dpp_incl_max(v, NEG), NEG);
 }
 
+// In-place row operators.  kUni: every read base has the same gap cost (all matrices the reference CLI can
+// build, score_matrix.rs:35-105), so the prefix sum of the read-gap cost up to column c is c * gcost and needs no
+// registers.
+template <int C, bool kUni>
+struct RowOps {
+    static __device__ __forceinline__ int gp(const int (&GP)[kUni ? 1 : C], int gcost, int lane, int q) {
+        if (kUni) return (lane * C + q) * gcost;
+        return GP[kUni ? 0 : q];
+    }
+    // group alpha: max(d, u, l) as a lane-local serial scan + one wave prefix-max; returns the direction masks and
+    // the fill-forward source lane (nearest lane to the left that owns a non-L column)
+    static __device__ __forceinline__ void alpha(int (&row)[C], const int (&s)[C], const int (&GP)[kUni ? 1 : C], int gcost,
+                                                 int g_i, int lane, int ncols, unsigned& dmask, unsigned& lmask, int& src) {
+        int prev_old = dpp_shr1(row[C - 1], NEG);
+        int runmax = NEG;
+        unsigned dm = 0, lm = 0;
+#pragma unroll
+        for (int q = 0; q < C; ++q) {
+            const int c = lane * C + q;
+            const int old = row[q];
+            const int d = prev_old + s[q], u = old + g_i;
+            const bool isd = (q == 0 ? c != 0 : true) && d >= u;   // border column 0: U only; priority D > U
+            int du = isd ? d : u;
+            du = c < ncols ? du : NEG;
+            dm |= (isd ? 1u : 0u) << q;
+            prev_old = old;
+            const int x = du - gp(GP, gcost, lane, q);
+            row[q] = x;
+            runmax = max(runmax, x);
+        }
+        int run = dpp_shr1(dpp_incl_max(runmax, NEG), NEG);
+#pragma unroll
+        for (int q = 0; q < C; ++q) {
+            const int c = lane * C + q;
+            const int x = row[q];
+            lm |= (run > x ? 1u : 0u) << q;                        // L only when strictly better (D > U > L)
+            const int y = max(run, x);
+            row[q] = c < ncols ? y + gp(GP, gcost, lane, q) : NEG;
+            run = y;
+        }
+        const unsigned full = C >= 32 ? 0xffffffffu : ((1u << C) - 1u);
+        src = dpp_shr1(dpp_incl_max((lm & full) != full ? lane : -1, -1), 0);
+        dmask = dm; lmask = lm;
+    }
+    // member: follow the alpha's directions with the path's own values
+    static __device__ __forceinline__ void member(int (&row)[C], const int (&s)[C], const int (&GP)[kUni ? 1 : C], int gcost,
+                                                  int g_i, int lane, int ncols, unsigned dmask, unsigned lmask, int src) {
+        int prev_old = dpp_shr1(row[C - 1], NEG);
+        int last = NEG;
+#pragma unroll
+        for (int q = 0; q < C; ++q) {
+            const int old = row[q];
+            const int base = ((dmask >> q) & 1) ? prev_old + s[q] : old + g_i;
+            prev_old = old;
+            const int y = base - gp(GP, gcost, lane, q);
+            row[q] = y;
+            last = ((lmask >> q) & 1) ? last : y;
+        }
+        int cur = __shfl(last, src, WAVE);                         // y of the last non-L column before this lane
+#pragma unroll
+        for (int q = 0; q < C; ++q) {
+            const int c = lane * C + q;
+            cur = ((lmask >> q) & 1) ? cur : row[q];
+            row[q] = c < ncols ? cur + gp(GP, gcost, lane, q) : NEG;
+        }
+    }
+};
+
 // One DP sweep over the whole graph for one read.
-template <int C, bool kLds>
+template <int C, bool kLds, bool kUni>
 __global__ __launch_bounds__(64, RG_SWEEP_WAVES) void k_sweep(SweepArgs a) {
     const int rd = blockIdx.x;
     const int lane = threadIdx.x;
@@ -56,7 +124,7 @@ __global__ __launch_bounds__(64, RG_SWEEP_WAVES) void k_sweep(SweepArgs a) {
     const int wpad = C * WAVE;
     ReadState* rs = a.state + rd;
     const long long ro = a.read_off[rd];
-    const int n = (int)(a.read_off[rd + 1] - ro);
+    const int n = __builtin_amdgcn_readfirstlane((int)(a.read_off[rd + 1] - ro));
     if (a.bad[rd] || n + 1 > wpad) {
         if (lane == 0 && !a.rev) { rs->status = a.bad[rd] ? ST_BAD_BASE : ST_WOULD_PANIC; }
         return;
@@ -72,43 +140,46 @@ __global__ __launch_bounds__(64, RG_SWEEP_WAVES) void k_sweep(SweepArgs a) {
 
     Rows<kLds> rows{kLds ? nullptr : a.roll + (long long)rd * P * wpad};
     // per-column constants of this lane
-    int er[C];       // read base facing column c (forward: read[c]; reverse: r_seq[j] = read[j+1], j = n - c)
-    int GP[C];       // prefix sums of the read-gap cost up to column c
-    int thr[C];      // emission threshold per column (NEG = never)
-    bool act[C];
+    unsigned long long erp = 0;   // 4 bits per column: read base facing column c (forward read[c]; reverse read[n-c+1])
+    int GP[kUni ? 1 : C];         // prefix sums of the read-gap cost up to column c (general matrices only)
+    const int gcost = sct[GAP];
+    int thr[C];                   // emission threshold per column (INT32_MAX = never)
     // recombination band (pathwise_alignment_recombination.rs:805-808)
     const int oob = max((int)((float)(n + 1) * (1.0f - a.rbw) / 2.0f), 1);
     {
         int run = 0;
+        int gpl[C];
 #pragma unroll
         for (int q = 0; q < C; ++q) {
             const int c = lane * C + q;
-            act[q] = c < ncols;
             int code = 4;
             if (c >= 1 && c < ncols) code = rev ? read[n - c + 1] : read[c];
-            er[q] = code;
-            const int gc = (c >= 1 && c < ncols) ? sct[code * 6 + GAP] : 0;
-            run += gc;
-            GP[q] = run;
+            erp |= (unsigned long long)code << (4 * q);
+            run += (c >= 1 && c < ncols) ? sct[code * 6 + GAP] : 0;
+            gpl[q] = run;
         }
-        const int pre = wave_incl_sum(run, lane) - run;
+        const int pre = dpp_incl_sum(run) - run;
+        if (kUni) GP[0] = 0;
 #pragma unroll
-        for (int q = 0; q < C; ++q) GP[q] += pre;
+        for (int q = 0; q < C; ++q) {
+            gpl[q] += pre;
+            if (!kUni) GP[kUni ? 0 : q] = gpl[q];
+        }
 #pragma unroll
         for (int q = 0; q < C; ++q) {
             const int c = lane * C + q;
             const int j = rev ? n - c : c;
             thr[q] = INT32_MAX;
-            if (act[q] && j >= oob && j < n + 1 - oob) {
+            if (c < ncols && j >= oob && j < n + 1 - oob) {
                 if (a.thr) thr[q] = a.thr[(long long)rd * wpad + j];
                 else if (a.lb) thr[q] = a.lb[rd] + a.brc - (n - j) * a.maxmatch;   // w[.][j] <= (n - j) * maxmatch
             }
         }
-    }
-    // start rows: row 0 (forward) / row L-1 (reverse) is the gap-only row, identical for every path
-    for (int k = 0; k < P; ++k) {
+        // start rows: row 0 (forward) / row L-1 (reverse) is the gap-only row, identical for every path
+        for (int k = 0; k < P; ++k) {
 #pragma unroll
-        for (int q = 0; q < C; ++q) rows.st(k, q * WAVE + lane, wpad, act[q] ? GP[q] : NEG);
+            for (int q = 0; q < C; ++q) rows.st(k, q * WAVE + lane, wpad, (lane * C + q) < ncols ? gpl[q] : NEG);
+        }
     }
     __syncthreads();
 
@@ -121,67 +192,48 @@ __global__ __launch_bounds__(64, RG_SWEEP_WAVES) void k_sweep(SweepArgs a) {
     const int* goff = rev ? g.rgoff : g.fgoff;
     const GroupDesc* groups = rev ? g.rgroups : g.fgroups;
     uint32_t* dirs = a.dirs ? a.dirs + (long long)rd * a.dirs_stride : nullptr;
+    const bool track = a.track_best;
 
     for (int step = 1; step + 1 < L; ++step) {
         const int i = rev ? L - 1 - step : step;
-        const int li = g.lnz[i];
-        const int g_i = sct[li * 6 + GAP];
+        const int li = __builtin_amdgcn_readfirstlane((int)g.lnz[i]);
+        const int g_i = __builtin_amdgcn_readfirstlane(sct[li * 6 + GAP]);
+        const int gbeg = __builtin_amdgcn_readfirstlane(goff[i]), gend = __builtin_amdgcn_readfirstlane(goff[i + 1]);
         int s[C];
 #pragma unroll
-        for (int q = 0; q < C; ++q) s[q] = sct[li * 6 + er[q]];
+        for (int q = 0; q < C; ++q) s[q] = sct[li * 6 + (int)((erp >> (4 * q)) & 7)];
         // best member of the row per column as one packed key (value * 64 + path id): a single max per cell
         int bkey[C];
 #pragma unroll
         for (int q = 0; q < C; ++q) bkey[q] = INT32_MIN;
 
-        for (int gi = goff[i]; gi < goff[i + 1]; ++gi) {
-            const GroupDesc gd = groups[gi];
-            const int ga = (int)gd.ga;
-            // ---- group alpha: recurrence + directions ----
-            int old[C];
+        for (int gi = gbeg; gi < gend; ++gi) {
+            const GroupDesc gdv = groups[gi];
+            const int ga = __builtin_amdgcn_readfirstlane((int)gdv.ga);
+            const int slot = __builtin_amdgcn_readfirstlane(gdv.slot);
+            const unsigned long long gmask =
+                ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(gdv.mask >> 32)) << 32) |
+                (unsigned)__builtin_amdgcn_readfirstlane((int)(gdv.mask & 0xffffffffull));
+            unsigned long long rest = gmask & ~(1ull << ga);
+            cells += (unsigned long long)__popcll(gmask);
+            // ---- loads: alpha row, and the first member's row in flight while the alpha recurrence runs ----
+            int rowa[C], nxt[C];
 #pragma unroll
-            for (int q = 0; q < C; ++q) old[q] = rows.ld(ga, q * WAVE + lane, wpad);
-            int prevcol = dpp_shr1(old[C - 1], NEG);
-            unsigned dmask = 0, lmask = 0;  // bit q: direction D / L of column q
-            int x[C];                        // candidate minus GP
-            int runmax = NEG;
-            int exl[C];
+            for (int q = 0; q < C; ++q) rowa[q] = rows.ld(ga, q * WAVE + lane, wpad);
+            int knext = -1;
+            if (rest) {
+                knext = __builtin_ctzll(rest);
+                rest &= rest - 1;
 #pragma unroll
-            for (int q = 0; q < C; ++q) {
-                const int c = lane * C + q;
-                const int om1 = q == 0 ? prevcol : old[q - 1];
-                int du;
-                if (c == 0) { du = old[q] + g_i; }  // border column: gap in the graph only
-                else {
-                    const int d = om1 + s[q], u = old[q] + g_i;
-                    if (d >= u) { du = d; dmask |= 1u << q; } else du = u;   // priority D > U
-                }
-                if (!act[q]) du = NEG;
-                x[q] = du - GP[q];
-                exl[q] = runmax;
-                runmax = max(runmax, x[q]);
+                for (int q = 0; q < C; ++q) nxt[q] = rows.ld(knext, q * WAVE + lane, wpad);
             }
-            const int carry = wave_excl_max(runmax, lane);
-            int nonl_last = NEG;  // y (= value - GP) at this lane's last non-L column
-            bool any_nonl = false;
-            int newv[C];
+            unsigned dmask, lmask;
+            int src;
+            RowOps<C, kUni>::alpha(rowa, s, GP, gcost, g_i, lane, ncols, dmask, lmask, src);
 #pragma unroll
             for (int q = 0; q < C; ++q) {
-                const int pm = max(carry, exl[q]);
-                const bool isl = pm > x[q];          // L only when strictly better (priority D > U > L)
-                if (isl) lmask |= 1u << q;
-                const int y = isl ? pm : x[q];
-                if (!isl) { nonl_last = x[q]; any_nonl = true; }
-                newv[q] = y + GP[q];
-            }
-            // nearest lane to the left that owns a non-L column (fill-forward source for member paths)
-            const int src = dpp_shr1(dpp_incl_max(any_nonl ? lane : -1, -1), 0);
-            (void)nonl_last;
-            // store alpha row, track best-of-row
-#pragma unroll
-            for (int q = 0; q < C; ++q) {
-                rows.st(ga, q * WAVE + lane, wpad, act[q] ? newv[q] : NEG);
-                if (a.track_best && act[q]) bkey[q] = max(bkey[q], newv[q] * 64 + ga);
+                rows.st(ga, q * WAVE + lane, wpad, rowa[q]);
+                if (track && (lane * C + q) < ncols) bkey[q] = max(bkey[q], rowa[q] * 64 + ga);
             }
             if (dirs) {
                 // 2 bits per column: 1 = D, 2 = U, 3 = L
@@ -193,7 +245,7 @@ __global__ __launch_bounds__(64, RG_SWEEP_WAVES) void k_sweep(SweepArgs a) {
                         const uint32_t dcode = (lmask >> q) & 1 ? 3u : ((dmask >> q) & 1 ? 1u : 2u);
                         wv |= dcode << (2 * q);
                     }
-                    dirs[(long long)gd.slot * a.dir_words + lane] = wv;
+                    dirs[(long long)slot * a.dir_words + lane] = wv;
                 } else {
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
@@ -204,50 +256,40 @@ __global__ __launch_bounds__(64, RG_SWEEP_WAVES) void k_sweep(SweepArgs a) {
                             const uint32_t dcode = (lmask >> qq) & 1 ? 3u : ((dmask >> qq) & 1 ? 1u : 2u);
                             wv |= dcode << (2 * q);
                         }
-                        dirs[(long long)gd.slot * a.dir_words + h * WAVE + lane] = wv;
+                        dirs[(long long)slot * a.dir_words + h * WAVE + lane] = wv;
                     }
                 }
             }
-            // ---- other members follow the alpha's directions with their own values ----
-            unsigned long long rest = gd.mask & ~(1ull << ga);
-            cells += (unsigned long long)__popcll(gd.mask);
-            while (rest) {
-                const int k = __builtin_ctzll(rest);
-                rest &= rest - 1;
-                int ok[C];
+            // ---- other members follow the alpha's directions; the next member's row is always in flight ----
+            while (knext >= 0) {
+                const int k = knext;
+                int cur[C];
 #pragma unroll
-                for (int q = 0; q < C; ++q) ok[q] = rows.ld(k, q * WAVE + lane, wpad);
-                const int pk = dpp_shr1(ok[C - 1], NEG);
-                int y[C];
-                int last = NEG;
+                for (int q = 0; q < C; ++q) cur[q] = nxt[q];
+                if (rest) {
+                    knext = __builtin_ctzll(rest);
+                    rest &= rest - 1;
 #pragma unroll
-                for (int q = 0; q < C; ++q) {
-                    const int om1 = q == 0 ? pk : ok[q - 1];
-                    const int base = ((dmask >> q) & 1) ? om1 + s[q] : ok[q] + g_i;
-                    y[q] = base - GP[q];
-                    if (!((lmask >> q) & 1)) last = y[q];
-                }
-                const int cin = __shfl(last, src, WAVE);  // y of the last non-L column before this lane
-                int cur = cin;
+                    for (int q = 0; q < C; ++q) nxt[q] = rows.ld(knext, q * WAVE + lane, wpad);
+                } else knext = -1;
+                RowOps<C, kUni>::member(cur, s, GP, gcost, g_i, lane, ncols, dmask, lmask, src);
 #pragma unroll
                 for (int q = 0; q < C; ++q) {
-                    if ((lmask >> q) & 1) y[q] = cur; else cur = y[q];
-                    const int v = act[q] ? y[q] + GP[q] : NEG;
-                    rows.st(k, q * WAVE + lane, wpad, v);
-                    if (a.track_best && act[q]) bkey[q] = max(bkey[q], v * 64 + k);
+                    rows.st(k, q * WAVE + lane, wpad, cur[q]);
+                    if (track && (lane * C + q) < ncols) bkey[q] = max(bkey[q], cur[q] * 64 + k);
                 }
             }
             // no barrier: every lane only ever re-reads the row words it wrote itself
         }
         // ---- best member of the row per column: feeds the recombination search ----
-        if (a.track_best) {
-            const int knm = g.knm[i];
+        if (track) {
+            const int knm = __builtin_amdgcn_readfirstlane(g.knm[i]);
             unsigned emask = 0;
 #pragma unroll
             for (int q = 0; q < C; ++q) {
                 // argmax over ALL P entries where non-members hold 0: usable only if the winner is a member
                 const int bv = bkey[q] >> 6, bk = bkey[q] & 63;
-                const bool valid = act[q] && bkey[q] != INT32_MIN && (knm < 0 || bv > 0 || (bv == 0 && bk > knm));
+                const bool valid = bkey[q] != INT32_MIN && (knm < 0 || bv > 0 || (bv == 0 && bk > knm));
                 if (valid) {
                     if (bv > colmax[q]) { colmax[q] = bv; colarg[q] = (i << 8) | bk; }
                     if (bv >= thr[q]) emask |= 1u << q;
@@ -255,7 +297,7 @@ __global__ __launch_bounds__(64, RG_SWEEP_WAVES) void k_sweep(SweepArgs a) {
             }
             if (cand && __any(emask != 0)) {
                 const int cnt = __popc(emask);
-                const int incl = wave_incl_sum(cnt, lane);
+                const int incl = dpp_incl_sum(cnt);
                 const int total = __shfl(incl, WAVE - 1, WAVE);
                 unsigned pos = ncand + (unsigned)(incl - cnt);
 #pragma unroll
@@ -280,7 +322,7 @@ __global__ __launch_bounds__(64, RG_SWEEP_WAVES) void k_sweep(SweepArgs a) {
 #pragma unroll
         for (int q = 0; q < C; ++q) {
             const int c = lane * C + q;
-            if (act[q]) {
+            if (c < ncols) {
                 a.colmax_out[(long long)rd * wpad + (rev ? n - c : c)] = colmax[q];
                 if (a.colarg_out) a.colarg_out[(long long)rd * wpad + (rev ? n - c : c)] = colarg[q];
             }
@@ -292,10 +334,8 @@ __global__ __launch_bounds__(64, RG_SWEEP_WAVES) void k_sweep(SweepArgs a) {
         // value of every path at its sink row, column n (lane/slot that owns column n)
         const int cn = n, ql = cn % C, ln = cn / C;
         for (int k = lane; k < P; k += WAVE) rs->sink_val[k] = rows.ld(k, ql * WAVE + ln, wpad);
-        if (lane == 0 && a.count_cells) atomicAdd(a.cells, cells * (unsigned long long)(n + 1));
-    } else if (lane == 0 && a.count_cells) {
-        atomicAdd(a.cells, cells * (unsigned long long)(n + 1));
     }
+    if (lane == 0 && a.count_cells) atomicAdd(a.cells, cells * (unsigned long long)(n + 1));
 }
 
 // ---------------------------------------------------------------------------------
@@ -763,16 +803,24 @@ __global__ __launch_bounds__(64) void k_trace(TraceArgs a) {
 
 // ---------------------------------------------------------------------------------
 // launchers
-template <int C>
-static void launch_sweep_c(const SweepArgs& a, int nreads, bool lds, hipStream_t s) {
+template <int C, bool kUni>
+static void launch_sweep_cu(const SweepArgs& a, int nreads, bool lds, hipStream_t s) {
     const size_t sct_bytes = 64 * sizeof(int);
     if (lds) {
         const size_t bytes = (size_t)a.g.P * C * WAVE * sizeof(int) + sct_bytes;
-        (void)hipFuncSetAttribute((const void*)k_sweep<C, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-        hipLaunchKernelGGL((k_sweep<C, true>), dim3(nreads), dim3(64), bytes, s, a);
+        (void)hipFuncSetAttribute((const void*)k_sweep<C, true, kUni>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        hipLaunchKernelGGL((k_sweep<C, true, kUni>), dim3(nreads), dim3(64), bytes, s, a);
     } else {
-        hipLaunchKernelGGL((k_sweep<C, false>), dim3(nreads), dim3(64), sct_bytes, s, a);
+        hipLaunchKernelGGL((k_sweep<C, false, kUni>), dim3(nreads), dim3(64), sct_bytes, s, a);
     }
+}
+template <int C>
+static void launch_sweep_c(const SweepArgs& a, int nreads, bool lds, hipStream_t s) {
+    // uniform read-gap cost: every (base, '-') entry equal (reads hold ACGTN only)
+    bool uni = true;
+    for (int b = 1; b < 5; ++b) uni = uni && a.sc.t[b * 6 + 5] == a.sc.t[5];
+    if (uni) launch_sweep_cu<C, true>(a, nreads, lds, s);
+    else launch_sweep_cu<C, false>(a, nreads, lds, s);
 }
 void launch_sweep(const SweepArgs& a, int nreads, int C, bool lds, hipStream_t s) {
     switch (C) {
