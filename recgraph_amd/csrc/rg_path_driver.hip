@@ -49,6 +49,8 @@ struct PathWorkImpl {
     Buf<Cand> fcand, rcand;
     Buf<unsigned> nf, nr, ridx;
     Buf<int> lb;
+    Buf<int4> fsteps, rsteps;
+    int nfsteps = 0, nrsteps = 0;
     unsigned fcap = 0, rcap = 0;
     std::vector<hipEvent_t> ev;
     ~PathWorkImpl() { for (auto e : ev) (void)hipEventDestroy(e); }
@@ -157,6 +159,35 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
         if ((rc = w.fpoff.upload(po)) || (rc = w.fprow.upload(pr)) || (rc = w.fpslot.upload(ps))) return rc;
         build(h.rgoff, h.rgroups, false, po, pr, ps);
         if ((rc = w.rpoff.upload(po)) || (rc = w.rprow.upload(pr)) || (rc = w.rpslot.upload(ps))) return rc;
+        // step tables of the sweeps (record layout documented in k_sweep)
+        if (L >= (1 << 20) || h.fslots >= (1 << 24) || h.rslots >= (1 << 24)) return fail(RG_ERR_GRAPH, "graph too large for the sweep step table");
+        auto steps = [&](const std::vector<int32_t>& goff, const std::vector<GroupDesc>& groups, bool fwd, std::vector<int4>& out) {
+            out.clear();
+            for (int step = 1; step + 1 < L; ++step) {
+                const int i = fwd ? step : L - 1 - step;
+                const bool inner = fwd ? (h.node_id[i] == h.node_id[i - 1] && i > 1) : (h.node_id[i] == h.node_id[i + 1]);
+                const int li = (int)std::string("ACGTN").find(h.lnz[i]);
+                for (int gi = goff[i]; gi < goff[i + 1]; ++gi) {
+                    int flags = 0;
+                    if (gi == goff[i]) flags |= 1;
+                    if (gi + 1 == goff[i + 1]) flags |= 2;
+                    if (inner && goff[i + 1] - goff[i] == 1) flags |= 4;
+                    int4 r;
+                    r.x = (int)((unsigned)i | ((unsigned)li << 20) | ((unsigned)flags << 23) | (groups[gi].ga << 26));
+                    r.y = (int)((unsigned)groups[gi].slot | ((unsigned)(h.knm[i] + 1) << 24));
+                    r.z = (int)(unsigned)(groups[gi].mask & 0xffffffffull);
+                    r.w = (int)(unsigned)(groups[gi].mask >> 32);
+                    out.push_back(r);
+                }
+            }
+        };
+        std::vector<int4> st;
+        steps(h.fgoff, h.fgroups, true, st);
+        if ((rc = w.fsteps.upload(st))) return rc;
+        w.nfsteps = (int)st.size();
+        steps(h.rgoff, h.rgroups, false, st);
+        if ((rc = w.rsteps.upload(st))) return rc;
+        w.nrsteps = (int)st.size();
         w.tables = true;
     }
     const long long layer_stride = (long long)(h.max_path_rows + 2) * wpad;
@@ -213,6 +244,7 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
         sa.g = gd;
         for (int i = 0; i < 36; ++i) sa.sc.t[i] = p.scores[i];
         sa.reads = d_reads; sa.read_off = off; sa.bad = bad; sa.state = w.state.p; sa.roll = w.roll.p;
+        sa.fsteps = w.fsteps.p; sa.rsteps = w.rsteps.p; sa.nfsteps = w.nfsteps; sa.nrsteps = w.nrsteps;
         sa.rbw = p.rec_band_width; sa.cand_cap = 0; sa.dir_words = dir_words; sa.cells = d_cells;
         SeedArgs se{gd, w.state.p, chunk, mode};
         if (mode == RG_MODE_PATHWISE) {

@@ -32,6 +32,9 @@ struct SweepArgs {
     int rev;                   // 0 forward sweep, 1 reverse sweep
     int track_best;            // maintain the best member per (row, col) (m8)
     const int* thr;            // [reads][wpad] emission thresholds by real column, or null
+    const int4* fsteps;        // step tables (one record per (row, edge group), sweep order), see k_sweep
+    const int4* rsteps;
+    int nfsteps, nrsteps;
     const int* lb;             // per read lower bound of S0: when set (forward sweep only) the threshold of column
                                // j is lb + brc - (n - j) * maxmatch (no reverse information needed)
     int brc, maxmatch;

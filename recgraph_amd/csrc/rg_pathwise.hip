@@ -24,6 +24,9 @@ constexpr int NEG = INT32_MIN / 4;
 #ifndef RG_SWEEP_WAVES
 #define RG_SWEEP_WAVES 2
 #endif
+#ifndef RG_SWEEP_KMAX
+#define RG_SWEEP_KMAX 0
+#endif
 
 template <bool kLds>
 struct Rows {
@@ -189,34 +192,177 @@ __global__ __launch_bounds__(64, RG_SWEEP_WAVES) void k_sweep(SweepArgs a) {
     unsigned ncand = 0;
     unsigned long long cells = 0;
     Cand* cand = a.cand ? a.cand + (long long)rd * a.cand_cap : nullptr;
-    const int* goff = rev ? g.rgoff : g.fgoff;
-    const GroupDesc* groups = rev ? g.rgroups : g.fgroups;
     uint32_t* dirs = a.dirs ? a.dirs + (long long)rd * a.dirs_stride : nullptr;
     const bool track = a.track_best;
 
-    for (int step = 1; step + 1 < L; ++step) {
-        const int i = rev ? L - 1 - step : step;
-        const int li = __builtin_amdgcn_readfirstlane((int)g.lnz[i]);
-        const int g_i = __builtin_amdgcn_readfirstlane(sct[li * 6 + GAP]);
-        const int gbeg = __builtin_amdgcn_readfirstlane(goff[i]), gend = __builtin_amdgcn_readfirstlane(goff[i + 1]);
-        int s[C];
+    // per-row epilogue: best member per column -> column maxima, candidate emission (search modes only)
+    auto row_end = [&](int i, int knm, const int (&bkey)[C]) {
+        unsigned emask = 0;
 #pragma unroll
-        for (int q = 0; q < C; ++q) s[q] = sct[li * 6 + (int)((erp >> (4 * q)) & 7)];
-        // best member of the row per column as one packed key (value * 64 + path id): a single max per cell
-        int bkey[C];
+        for (int q = 0; q < C; ++q) {
+            // argmax over ALL P entries where non-members hold 0: usable only if the winner is a member
+            const int bv = bkey[q] >> 6, bk = bkey[q] & 63;
+            const bool valid = bkey[q] != INT32_MIN && (knm < 0 || bv > 0 || (bv == 0 && bk > knm));
+            if (valid) {
+                if (bv > colmax[q]) { colmax[q] = bv; colarg[q] = (i << 8) | bk; }
+                if (bv >= thr[q]) emask |= 1u << q;
+            }
+        }
+        if (cand && __any(emask != 0)) {
+            const int cnt = __popc(emask);
+            const int incl = dpp_incl_sum(cnt);
+            const int total = __shfl(incl, WAVE - 1, WAVE);
+            unsigned pos = ncand + (unsigned)(incl - cnt);
 #pragma unroll
-        for (int q = 0; q < C; ++q) bkey[q] = INT32_MIN;
+            for (int q = 0; q < C; ++q) {
+                if ((emask >> q) & 1) {
+                    if (pos < a.cand_cap) {
+                        const int c = lane * C + q;
+                        Cand cd;
+                        cd.row = i; cd.col = rev ? n - c : c; cd.val = bkey[q] >> 6; cd.path = bkey[q] & 63;
+                        cand[pos] = cd;
+                    }
+                    ++pos;
+                }
+            }
+            ncand += (unsigned)total;
+        }
+    };
+    auto store_dirs = [&](int slot, unsigned dmask, unsigned lmask) {
+        // 2 bits per column: 1 = D, 2 = U, 3 = L
+        static_assert(C <= 16 || C == 32, "direction packing");
+        if (C <= 16) {
+            uint32_t wv = 0;
+#pragma unroll
+            for (int q = 0; q < C; ++q) {
+                const uint32_t dcode = (lmask >> q) & 1 ? 3u : ((dmask >> q) & 1 ? 1u : 2u);
+                wv |= dcode << (2 * q);
+            }
+            dirs[(long long)slot * a.dir_words + lane] = wv;
+        } else {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                uint32_t wv = 0;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const int qq = h * 16 + q;
+                    const uint32_t dcode = (lmask >> qq) & 1 ? 3u : ((dmask >> qq) & 1 ? 1u : 2u);
+                    wv |= dcode << (2 * q);
+                }
+                dirs[(long long)slot * a.dir_words + h * WAVE + lane] = wv;
+            }
+        }
+    };
 
-        for (int gi = gbeg; gi < gend; ++gi) {
-            const GroupDesc gdv = groups[gi];
-            const int ga = __builtin_amdgcn_readfirstlane((int)gdv.ga);
-            const int slot = __builtin_amdgcn_readfirstlane(gdv.slot);
-            const unsigned long long gmask =
-                ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(gdv.mask >> 32)) << 32) |
-                (unsigned)__builtin_amdgcn_readfirstlane((int)(gdv.mask & 0xffffffffull));
+    // The sweep walks a host-built step table (one 16-byte record per (row, edge group), in sweep order) instead
+    // of chasing goff[] -> groups[] -> lnz[] -> knm[] with dependent uniform loads: a wave fetches 64 records with
+    // one coalesced load (next batch in flight) and broadcasts record t with v_readlane.
+    //   x: row (20 bits) | base code (3) << 20 | flags (3) << 23 | group alpha (6) << 26
+    //   y: direction-word slot (24 bits) | (knm + 1) (7) << 24        z, w: member mask
+    constexpr int KMAX = RG_SWEEP_KMAX;   // rows kept in registers across the inner rows of a segment (0 = off)
+    const int4* steps = rev ? a.rsteps : a.fsteps;
+    const int nsteps = rev ? a.nrsteps : a.nfsteps;
+    int4 recs = make_int4(0, 0, 0, 0), recs_next = make_int4(0, 0, 0, 0);
+    if (lane < nsteps) recs = steps[lane];
+    if (WAVE + lane < nsteps) recs_next = steps[WAVE + lane];
+    int t = 0;
+    // fetch record t (uniform) -> SGPRs; advances the double buffer at batch boundaries
+    auto fetch = [&](int tt, int& w0, int& w1, unsigned long long& gmask) {
+        const int idx = tt & (WAVE - 1);
+        if (idx == 0 && tt > 0) {
+            recs = recs_next;
+            const int nb = tt + WAVE + lane;
+            recs_next = nb < nsteps ? steps[nb] : make_int4(0, 0, 0, 0);
+        }
+        w0 = __builtin_amdgcn_readlane(recs.x, idx);
+        w1 = __builtin_amdgcn_readlane(recs.y, idx);
+        gmask = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(recs.w, idx) << 32) |
+                (unsigned)__builtin_amdgcn_readlane(recs.z, idx);
+    };
+    // peek at the flags of record tt without consuming it (same or next batch)
+    auto peek_w0 = [&](int tt) -> int {
+        const int idx = tt & (WAVE - 1);
+        return idx == 0 && tt > 0 ? __builtin_amdgcn_readlane(recs_next.x, 0) : __builtin_amdgcn_readlane(recs.x, idx);
+    };
+    constexpr int F_FIRST = 1, F_LAST = 2, F_INNER = 4;
+
+    int s[C];
+    int bkey[C];
+    while (t < nsteps) {
+        int w0, w1;
+        unsigned long long gmask;
+        fetch(t, w0, w1, gmask);
+        int i = w0 & 0xfffff;
+        int li = (w0 >> 20) & 7;
+        int flags = (w0 >> 23) & 7;
+        int ga = (w0 >> 26) & 63;
+        int slot = w1 & 0xffffff;
+        const int nm = __popcll(gmask);
+        if (KMAX > 0 && (flags & F_INNER) && nm <= KMAX) {
+            // ---- inner rows of a segment with a small group: rows stay in registers for the whole run ----
+            int mk[KMAX > 0 ? KMAX : 1];
+            {
+                unsigned long long tm = gmask;
+#pragma unroll
+                for (int kk = 0; kk < KMAX; ++kk) { mk[kk] = tm ? __builtin_ctzll(tm) : 0; tm = tm ? (tm & (tm - 1)) : 0; }
+            }
+            int r[KMAX > 0 ? KMAX : 1][C];
+#pragma unroll
+            for (int kk = 0; kk < KMAX; ++kk)
+                if (kk < nm) {
+#pragma unroll
+                    for (int q = 0; q < C; ++q) r[kk][q] = rows.ld(mk[kk], q * WAVE + lane, wpad);
+                }
+            while (true) {
+                const int g_i = __builtin_amdgcn_readfirstlane(sct[li * 6 + GAP]);
+#pragma unroll
+                for (int q = 0; q < C; ++q) s[q] = sct[li * 6 + (int)((erp >> (4 * q)) & 7)];
+                unsigned dmask = 0, lmask = 0;
+                int src = 0;
+#pragma unroll
+                for (int kk = 0; kk < KMAX; ++kk)
+                    if (kk < nm && mk[kk] == ga) RowOps<C, kUni>::alpha(r[kk], s, GP, gcost, g_i, lane, ncols, dmask, lmask, src);
+                if (dirs) store_dirs(slot, dmask, lmask);
+#pragma unroll
+                for (int kk = 0; kk < KMAX; ++kk)
+                    if (kk < nm && mk[kk] != ga) RowOps<C, kUni>::member(r[kk], s, GP, gcost, g_i, lane, ncols, dmask, lmask, src);
+                cells += (unsigned long long)nm;
+                if (track) {
+#pragma unroll
+                    for (int q = 0; q < C; ++q) bkey[q] = INT32_MIN;
+#pragma unroll
+                    for (int kk = 0; kk < KMAX; ++kk)
+                        if (kk < nm) {
+#pragma unroll
+                            for (int q = 0; q < C; ++q)
+                                if ((lane * C + q) < ncols) bkey[q] = max(bkey[q], r[kk][q] * 64 + mk[kk]);
+                        }
+                    row_end(i, ((w1 >> 24) & 127) - 1, bkey);
+                }
+                ++t;
+                if (t >= nsteps) break;
+                if (!((peek_w0(t) >> 23) & F_INNER)) break;     // next record starts another segment
+                fetch(t, w0, w1, gmask);
+                i = w0 & 0xfffff; li = (w0 >> 20) & 7; ga = (w0 >> 26) & 63; slot = w1 & 0xffffff;
+            }
+#pragma unroll
+            for (int kk = 0; kk < KMAX; ++kk)
+                if (kk < nm) {
+#pragma unroll
+                    for (int q = 0; q < C; ++q) rows.st(mk[kk], q * WAVE + lane, wpad, r[kk][q]);
+                }
+            continue;
+        }
+        // ---- general (row, group) step ----
+        const int g_i = __builtin_amdgcn_readfirstlane(sct[li * 6 + GAP]);
+        if (flags & F_FIRST) {
+#pragma unroll
+            for (int q = 0; q < C; ++q) { s[q] = sct[li * 6 + (int)((erp >> (4 * q)) & 7)]; bkey[q] = INT32_MIN; }
+        }
+        {
             unsigned long long rest = gmask & ~(1ull << ga);
-            cells += (unsigned long long)__popcll(gmask);
-            // ---- loads: alpha row, and the first member's row in flight while the alpha recurrence runs ----
+            cells += (unsigned long long)nm;
+            // loads: alpha row, and the first member's row in flight while the alpha recurrence runs
             int rowa[C], nxt[C];
 #pragma unroll
             for (int q = 0; q < C; ++q) rowa[q] = rows.ld(ga, q * WAVE + lane, wpad);
@@ -235,32 +381,8 @@ __global__ __launch_bounds__(64, RG_SWEEP_WAVES) void k_sweep(SweepArgs a) {
                 rows.st(ga, q * WAVE + lane, wpad, rowa[q]);
                 if (track && (lane * C + q) < ncols) bkey[q] = max(bkey[q], rowa[q] * 64 + ga);
             }
-            if (dirs) {
-                // 2 bits per column: 1 = D, 2 = U, 3 = L
-                static_assert(C <= 16 || C == 32, "direction packing");
-                if (C <= 16) {
-                    uint32_t wv = 0;
-#pragma unroll
-                    for (int q = 0; q < C; ++q) {
-                        const uint32_t dcode = (lmask >> q) & 1 ? 3u : ((dmask >> q) & 1 ? 1u : 2u);
-                        wv |= dcode << (2 * q);
-                    }
-                    dirs[(long long)slot * a.dir_words + lane] = wv;
-                } else {
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        uint32_t wv = 0;
-#pragma unroll
-                        for (int q = 0; q < 16; ++q) {
-                            const int qq = h * 16 + q;
-                            const uint32_t dcode = (lmask >> qq) & 1 ? 3u : ((dmask >> qq) & 1 ? 1u : 2u);
-                            wv |= dcode << (2 * q);
-                        }
-                        dirs[(long long)slot * a.dir_words + h * WAVE + lane] = wv;
-                    }
-                }
-            }
-            // ---- other members follow the alpha's directions; the next member's row is always in flight ----
+            if (dirs) store_dirs(slot, dmask, lmask);
+            // other members follow the alpha's directions; the next member's row is always in flight
             while (knext >= 0) {
                 const int k = knext;
                 int cur[C];
@@ -281,40 +403,8 @@ __global__ __launch_bounds__(64, RG_SWEEP_WAVES) void k_sweep(SweepArgs a) {
             }
             // no barrier: every lane only ever re-reads the row words it wrote itself
         }
-        // ---- best member of the row per column: feeds the recombination search ----
-        if (track) {
-            const int knm = __builtin_amdgcn_readfirstlane(g.knm[i]);
-            unsigned emask = 0;
-#pragma unroll
-            for (int q = 0; q < C; ++q) {
-                // argmax over ALL P entries where non-members hold 0: usable only if the winner is a member
-                const int bv = bkey[q] >> 6, bk = bkey[q] & 63;
-                const bool valid = bkey[q] != INT32_MIN && (knm < 0 || bv > 0 || (bv == 0 && bk > knm));
-                if (valid) {
-                    if (bv > colmax[q]) { colmax[q] = bv; colarg[q] = (i << 8) | bk; }
-                    if (bv >= thr[q]) emask |= 1u << q;
-                }
-            }
-            if (cand && __any(emask != 0)) {
-                const int cnt = __popc(emask);
-                const int incl = dpp_incl_sum(cnt);
-                const int total = __shfl(incl, WAVE - 1, WAVE);
-                unsigned pos = ncand + (unsigned)(incl - cnt);
-#pragma unroll
-                for (int q = 0; q < C; ++q) {
-                    if ((emask >> q) & 1) {
-                        if (pos < a.cand_cap) {
-                            const int c = lane * C + q;
-                            Cand cd;
-                            cd.row = i; cd.col = rev ? n - c : c; cd.val = bkey[q] >> 6; cd.path = bkey[q] & 63;
-                            cand[pos] = cd;
-                        }
-                        ++pos;
-                    }
-                }
-                ncand += (unsigned)total;
-            }
-        }
+        if (track && (flags & F_LAST)) row_end(i, ((w1 >> 24) & 127) - 1, bkey);
+        ++t;
     }
 
     // ---- outputs ----
