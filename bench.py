@@ -104,10 +104,13 @@ def main():
         sweeps = {k: v for k, v in kstats.items() if k.startswith("k_sweep") or k.startswith("k_m0") or k.startswith("k_m2")}
         roof = None
         if sweeps:
-            # dominant kernel family: the DP sweep.  Every launch sweeps the whole graph once for the batch.
+            # dominant kernel family: the DP sweep.  A launch sweeps the whole graph once for one chunk of the batch;
+            # cell-updates are counted by the forward and reverse launches (not by the optional column-maxima pass)
             ms = sum(v[0] for v in sweeps.values())
             launches = sum(v[1] for v in sweeps.values())
-            per_launch_units = cells_step / (2 if mode == 8 else 1)      # cell-updates one sweep launch processes
+            counting = sum(v[1] for k, v in sweeps.items() if not k.endswith("_colmax")) or launches
+            per_launch_units = cells_step * args.steps / counting       # cell-updates one sweep launch processes
+            reads_per_launch = batch * args.steps * (2 if mode == 8 else 1) / counting if mode in (4, 8) else batch
             avg_s = ms / launches / 1e3
             achieved = per_launch_units * BYTES_PER_CELL_UPDATE[mode] / avg_s / 1e9
             traffic = None
@@ -117,11 +120,12 @@ def main():
                     tr = json.load(open(tj))
                     # measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on the same kernel;
                     # scaled from the profiled batch to this run's batch (traffic is per read)
-                    traffic = round(tr["hbm_bytes_per_read_per_launch"] * batch)
+                    traffic = round(tr["hbm_bytes_per_read_per_launch"] * reads_per_launch)
                 except Exception:
                     traffic = None
             roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "kernel": "k_sweep",
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                    "kernel": {0: "k_m0_simd", 2: "k_poa_banded<true>", 4: "k_sweep", 8: "k_sweep"}[mode],
                     "avg_launch_ms": round(ms / launches, 3), "launches": launches}
         out = {
             "metric": "aligned reads/sec (-m 8 recombination, 1 kbp reads, 10k-row/32-path graph)" if args.config == "C5"
@@ -147,9 +151,10 @@ def main():
             nr = min(nr, len(reads))
             secs, cells, _ = og.bench(omode, reads[:nr], nthreads=cores)
             cpu = {"value": round(nr / secs, 3), "unit": "reads/s", "cores": cores, "kind": "port",
-                   "sample": "%d reads of the same batch, oracle absolute-form restatement with the exact pruned "
-                             "search (the faithful O(L^2 n) search is ~1e11 iterations/read), %d threads, %.1f s"
-                             % (nr, cores, secs)}
+                   "sample": "%d reads of the same batch, %s, %d threads, %.1f s"
+                             % (nr, {0: "oracle m0 (AVX2 semantics, scalar code)", 2: "oracle m2", 4: "oracle absolute-form m4",
+                                     8: "oracle absolute-form m8 with the exact pruned search (the faithful O(L^2 n) "
+                                        "search is ~1e11 iterations/read)"}[mode], cores, secs)}
         out["cpu_baseline"] = cpu
         print(json.dumps(out))
     if dist_on:
