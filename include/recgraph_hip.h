@@ -41,6 +41,8 @@ typedef enum rg_status {
 #define RG_MODE_GAP_POA 2           /* gap_global_abpoa::exec           src/gap_global_abpoa.rs:11  */
 #define RG_MODE_PATHWISE 4          /* pathwise_alignment::exec         src/pathwise_alignment.rs:5 */
 #define RG_MODE_RECOMBINATION 8     /* pathwise_alignment_recombination::exec (aln_mode 8) src/pathwise_alignment_recombination.rs:23 */
+#define RG_MODE_PATHWISE_SEMI 5     /* pathwise_alignment_semiglobal::exec  src/pathwise_alignment_semiglobal.rs:6 */
+#define RG_MODE_RECOMBINATION_SEMI 9/* pathwise_alignment_recombination::exec (aln_mode 9) */
 
 /*
  * Scoring and banding parameters.  Replaces the HashMap<(char,char),i32|f32> score matrix arguments

@@ -29,7 +29,8 @@ static Scores scores_from(const int* t36) {
 extern "C" {
 
 // mode ids
-enum { ORC_M0_SIMD = 0, ORC_M0_SCALAR = 10, ORC_M2 = 2, ORC_M4 = 4, ORC_M4_ABS = 14, ORC_M8 = 8, ORC_M8_PRUNED = 18, ORC_M8_ABS = 28 };
+enum { ORC_M0_SIMD = 0, ORC_M0_SCALAR = 10, ORC_M2 = 2, ORC_M4 = 4, ORC_M4_ABS = 14, ORC_M8 = 8, ORC_M8_PRUNED = 18, ORC_M8_ABS = 28,
+       ORC_M5 = 5, ORC_M5_ABS = 15, ORC_M9 = 9, ORC_M9_PRUNED = 19, ORC_M9_ABS = 29 };
 
 void orc_scores_match_mis(int m, int x, int f32_variant, int* out36) {
     Scores s = f32_variant ? make_scores_match_mis_f32(m, x) : make_scores_match_mis(m, x);
@@ -138,6 +139,11 @@ static Result run_one(OrcGraph* g, int mode, const std::string& read_dollar, con
         case ORC_M8: return m8_literal(read_dollar, name, g->pg, g->rpg, g->dfs, g->dfe, sc, brc, mrc, rbw, false);
         case ORC_M8_PRUNED: return m8_literal(read_dollar, name, g->pg, g->rpg, g->dfs, g->dfe, sc, brc, mrc, rbw, true);
         case ORC_M8_ABS: return m8_abs(read_dollar, name, g->pg, g->rpg, g->dfs, g->dfe, sc, brc, mrc, rbw);
+        case ORC_M5: return m5_literal(read_dollar, name, g->pg, sc);
+        case ORC_M5_ABS: return m5_abs(read_dollar, name, g->pg, sc);
+        case ORC_M9: return m9_literal(read_dollar, name, g->pg, g->rpg, g->dfs, g->dfe, sc, brc, mrc, rbw, false);
+        case ORC_M9_PRUNED: return m9_literal(read_dollar, name, g->pg, g->rpg, g->dfs, g->dfe, sc, brc, mrc, rbw, true);
+        case ORC_M9_ABS: return m9_abs(read_dollar, name, g->pg, g->rpg, g->dfs, g->dfe, sc, brc, mrc, rbw);
         default: { Result r; r.would_panic = true; return r; }
     }
 }

@@ -158,6 +158,15 @@ Result m8_literal(const std::string& read, const std::string& name, const PathGr
                   const std::vector<int64_t>& dfe, const Scores& sc, int brc, float mrc,
                   float rbw, bool pruned);
 
+// semiglobal modes: -m 5 src/pathwise_alignment_semiglobal.rs, -m 9 the aln_mode 9 branches
+Result m5_literal(const std::string& read, const std::string& name, const PathGraph& g, const Scores& sc);
+Result m9_literal(const std::string& read, const std::string& name, const PathGraph& g, const PathGraph& rev,
+                  const std::vector<int64_t>& dfs, const std::vector<int64_t>& dfe, const Scores& sc, int brc, float mrc,
+                  float rbw, bool pruned);
+Result m5_abs(const std::string& read, const std::string& name, const PathGraph& g, const Scores& sc);
+Result m9_abs(const std::string& read, const std::string& name, const PathGraph& g, const PathGraph& rev,
+              const std::vector<int64_t>& dfs, const std::vector<int64_t>& dfe, const Scores& sc, int brc, float mrc, float rbw);
+
 // second restatement (absolute-score formulation), orc_pathwise_abs.cpp
 Result m4_abs(const std::string& read, const std::string& name, const PathGraph& g,
               const Scores& sc);

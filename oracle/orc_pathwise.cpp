@@ -23,7 +23,7 @@ struct Dpm {
 // One DP fill, forward (di=dj=-1: pathwise_alignment_recombination.rs:436-745 ==
 // pathwise_alignment.rs:16-304) or reverse (di=dj=+1: :129-435).  `seq` is the read with '$'
 // for forward, get_rev_sequence(read) (:875-883) for reverse.
-void fill(Dpm& D, const std::string& seq, const PathGraph& g, const Scores& sc, bool forward) {
+void fill(Dpm& D, const std::string& seq, const PathGraph& g, const Scores& sc, bool forward, bool semi = false) {
     const std::string& lnz = g.lnz;
     const size_t L = lnz.size(), W = seq.size(), P = g.paths_number;
     const auto& alphas = g.alphas;
@@ -167,7 +167,7 @@ void fill(Dpm& D, const std::string& seq, const PathGraph& g, const Scores& sc, 
         for (size_t i = 0; i + 1 < L; ++i)
             for (size_t j = 0; j < W; ++j) {
                 if (i == 0 && j == 0) { /* zeros */ }
-                else if (j == 0) border_cell(i, j);
+                else if (j == 0) { if (!semi) border_cell(i, j); /* semiglobal: dpm[i][0] = 0 */ }
                 else if (i == 0) {
                     D.at(0, j, alphas[0]) = D.at(0, j - 1, alphas[0]) + sc.get(seq[j], '-');
                     for (size_t k = alphas[0] + 1; k < P; ++k) D.at(0, j, k) = D.at(0, j - 1, k);
@@ -181,7 +181,7 @@ void fill(Dpm& D, const std::string& seq, const PathGraph& g, const Scores& sc, 
                 else if (i == last_node) {
                     D.at(i, j, alphas[i]) = D.at(i, j + 1, alphas[i]) + sc.get(seq[j], '-');
                     for (size_t k = alphas[i] + 1; k < P; ++k) D.at(i, j, k) = D.at(i, j + 1, k);
-                } else if (j == jborder) border_cell(i, j);
+                } else if (j == jborder) { if (!semi) border_cell(i, j); /* aln_mode 9: zeros (:157-159) */ }
                 else inner_cell(i, j);
             }
     }
@@ -596,6 +596,213 @@ Result m8_literal(const std::string& seq, const std::string& name, const PathGra
                           "], score: " + f32_display(curr) + ", displacement: " + std::to_string(rec_penalty) +
                           "\t" + pss + "\t" + std::to_string(rec_edge);
         gaf.comments = build_cigar(tcigar) + ", " + rec;
+        res.score = (int)curr;
+    }
+    res.out = gaf.to_string() + "\n";
+    res.would_panic = sc.panicked;
+    return res;
+}
+
+// =================================================================================
+// -m 5  (src/pathwise_alignment_semiglobal.rs:6-277 + pathwise_alignment_output.rs:7-184, global_align=false)
+// =================================================================================
+Result m5_literal(const std::string& seq, const std::string& name, const PathGraph& g, const Scores& sc) {
+    Result res;
+    sc.panicked = false;
+    const std::string& lnz = g.lnz;
+    const size_t L = lnz.size(), W = seq.size(), P = g.paths_number;
+    const auto& alphas = g.alphas;
+    Dpm D(L, W, P);
+    fill(D, seq, g, sc, true, true);
+    auto ABSv = [&](size_t i, size_t j, size_t k) { return alphas[i] == k ? D.at(i, j, k) : D.at(i, j, k) + D.at(i, j, alphas[i]); };
+    // best_ending_node :244-277
+    bool have = false; int mx = 0; size_t ending_node = 0, best_path = 0;
+    for (size_t i = 1; i + 1 < L; ++i) {
+        bool hb = false; int bs = 0; size_t bp = 0;
+        for (size_t k = 0; k < P; ++k)
+            if (g.paths_nodes[i][k]) {
+                int v = ABSv(i, W - 1, k);
+                if (!hb || bs < v) { bs = v; bp = k; hb = true; }
+            }
+        if (!hb) { res.would_panic = true; return res; }   // best_path.unwrap() on None
+        if (!have || bs > mx) { mx = bs; ending_node = i; best_path = bp; have = true; }
+    }
+    // build_alignment(global_align = false)
+    auto ABS = [&](size_t i, size_t j) { return ABSv(i, j, best_path); };
+    std::vector<char> cigar, pseq; std::vector<uint64_t> hia;
+    size_t path_length = 0, i = ending_node, j = W - 1;
+    int score = ABS(i, j);
+    res.score = score;
+    while (i > 0 && j > 0) {
+        bool has_pred = false; size_t predecessor = 0; int d = 0, u = 0, l = 0;
+        if (!g.nwp[i]) {
+            d = ABS(i - 1, j - 1) + sc.get(lnz[i], seq[j]); u = ABS(i - 1, j) + sc.get(lnz[i], '-'); l = ABS(i, j - 1) + sc.get('-', seq[j]);
+        } else {
+            for (auto& pk : g.pred_hash.at(i))
+                if (pk.second[best_path]) {
+                    predecessor = pk.first; has_pred = true;
+                    d = ABS(pk.first, j - 1) + sc.get(lnz[i], seq[j]); u = ABS(pk.first, j) + sc.get(lnz[i], '-'); l = ABS(i, j - 1) + sc.get('-', seq[j]);
+                }
+        }
+        int m = std::max(std::max(d, u), l);
+        if (m == d) { cigar.push_back(lnz[i] != seq[j] ? 'd' : 'D'); hia.push_back(g.nodes_id_pos[i]); pseq.push_back(lnz[i]); i = has_pred ? predecessor : i - 1; j -= 1; path_length += 1; }
+        else if (m == u) { cigar.push_back('U'); hia.push_back(g.nodes_id_pos[i]); pseq.push_back(lnz[i]); i = has_pred ? predecessor : i - 1; path_length += 1; }
+        else { cigar.push_back('L'); j -= 1; }
+    }
+    while (j > 0) { cigar.push_back('L'); j -= 1; }
+    std::reverse(cigar.begin(), cigar.end());
+    std::reverse(pseq.begin(), pseq.end());
+    GAF gaf;
+    gaf.query_name = name; gaf.query_length = W - 1; gaf.query_start = 0; gaf.query_end = W - 2; gaf.strand = '+';
+    auto dd = dedup(hia); std::reverse(dd.begin(), dd.end()); gaf.path = dd;
+    get_path_len_start_end(g.nodes_id_pos, i == 0 ? i : i + 1, ending_node, path_length, gaf.path_length, gaf.path_start, gaf.path_end);
+    gaf.alignment_block_length = "*"; gaf.mapping_quality = "*";
+    gaf.comments = build_cigar(cigar) + ", best path: " + std::to_string(best_path) + ", score: " + std::to_string(score) + "\t" + std::string(pseq.begin(), pseq.end());
+    res.out = gaf.to_string() + "\n";
+    res.would_panic = sc.panicked;
+    return res;
+}
+
+// =================================================================================
+// -m 9  (pathwise_alignment_recombination.rs aln_mode 9 + recombination_output.rs:12-361)
+// =================================================================================
+Result m9_literal(const std::string& seq, const std::string& name, const PathGraph& g, const PathGraph& rg,
+                  const std::vector<int64_t>& dfs, const std::vector<int64_t>& dfe, const Scores& sc, int brc, float mrc,
+                  float rbw, bool pruned) {
+    Result res;
+    sc.panicked = false;
+    const std::string& lnz = g.lnz;
+    const size_t L = lnz.size(), W = seq.size(), P = g.paths_number;
+    const auto& ids = g.nodes_id_pos;
+    const auto& np = g.paths_nodes;
+    Dpm m(L, W, P), w(L, W, P);
+    fill(m, seq, g, sc, true, true);
+    absolute_scores(m, g);
+    std::string r_seq = seq.substr(1) + "F";
+    fill(w, r_seq, rg, sc, false, true);
+    absolute_scores(w, rg);
+    auto dms = [&](size_t a, size_t b) -> int { return a == b ? 0 : (int)(std::llabs(dfs[a] - dfs[b]) + std::llabs(dfe[a] - dfe[b])); };
+    // seed :789-800: every row 0..L-2, member paths ascending, strict '<'
+    bool have = false; int mx = 0; size_t bp = 0;
+    for (size_t i = 0; i + 1 < L; ++i)
+        for (size_t k = 0; k < P; ++k)
+            if (np[i][k]) { int v = m.at(i, W - 1, k); if (!have || mx < v) { mx = v; bp = k; have = true; } }
+    float curr = (float)mx;
+    size_t fbp = bp, rbp = bp, fen = 0, rsn = 0, rec_col = 0;
+    bool onedge = false; int rec_penalty = 0;
+    int oob = std::max((int)((float)W * (1.0f - rbw) / 2.0f), 1);
+    std::vector<size_t> fp(L), rp(L);
+    for (size_t j = (size_t)oob; j + (size_t)oob < W; ++j) {
+        for (size_t i = 0; i < L; ++i) {
+            size_t bf = 0, br = 0;
+            for (size_t k = 0; k < P; ++k) {
+                if (std::make_pair(m.at(i, j, k), k) >= std::make_pair(m.at(i, j, bf), bf)) bf = k;
+                if (std::make_pair(w.at(i, j, k), k) >= std::make_pair(w.at(i, j, br), br)) br = k;
+            }
+            fp[i] = bf; rp[i] = br;
+        }
+        std::vector<size_t> fi, ri;
+        if (pruned) {
+            if (brc < 0 || mrc < 0) { res.would_panic = true; return res; }
+            long mfmax = INT32_MIN, wrmax = INT32_MIN;
+            for (size_t i = 1; i + 1 < L; ++i) {
+                if (np[i][fp[i]]) mfmax = std::max<long>(mfmax, m.at(i, j, fp[i]));
+                if (np[i][rp[i]]) wrmax = std::max<long>(wrmax, w.at(i, j, rp[i]));
+            }
+            for (size_t i = 1; i + 1 < L; ++i) {
+                if (np[i][fp[i]] && (long)m.at(i, j, fp[i]) + wrmax - brc >= (long)mx) fi.push_back(i);
+                if (np[i][rp[i]] && (long)w.at(i, j, rp[i]) + mfmax - brc >= (long)mx) ri.push_back(i);
+            }
+        } else for (size_t i = 1; i + 1 < L; ++i) { fi.push_back(i); ri.push_back(i); }
+        for (size_t i : fi) {
+            size_t forw_path = fp[i];
+            if (!np[i][forw_path]) continue;
+            for (size_t rev_i : ri) {
+                if (ids[i] == ids[rev_i]) continue;
+                size_t rev_path = rp[rev_i];
+                if (forw_path == rev_path || !np[rev_i][rev_path]) continue;
+                float penalty = (float)brc + (mrc * (float)dms(i, rev_i));
+                float ns = (float)(m.at(i, j, forw_path) + w.at(rev_i, j, rev_path)) - penalty;
+                bool cond = (i + 1 == L || ids[i] != ids[i + 1]) && ids[rev_i] != ids[rev_i - 1];
+                if (ns > curr || (ns == curr && !onedge && cond)) {
+                    onedge = cond; curr = ns; fen = i; rsn = rev_i; fbp = forw_path; rbp = rev_path; rec_col = j; rec_penalty = dms(i, rev_i);
+                }
+            }
+        }
+    }
+    GAF gaf;
+    gaf.query_name = name; gaf.query_length = W - 1; gaf.query_start = 0; gaf.query_end = W - 2; gaf.strand = '+';
+    gaf.alignment_block_length = "*"; gaf.mapping_quality = "*";
+    auto fwd_walk = [&](size_t& i, size_t& j, size_t path, std::vector<char>& cg, std::vector<uint64_t>& hi, std::vector<char>& ps, size_t& plen) {
+        while (i > 0 && j > 0) {
+            bool has_pred = false; size_t predecessor = 0; int d = 0, u = 0, l = 0;
+            if (!g.nwp[i]) {
+                d = m.at(i - 1, j - 1, path) + sc.get(lnz[i], seq[j]); u = m.at(i - 1, j, path) + sc.get(lnz[i], '-'); l = m.at(i, j - 1, path) + sc.get('-', seq[j]);
+            } else {
+                for (auto& pk : g.pred_hash.at(i))
+                    if (pk.second[path]) {
+                        predecessor = pk.first; has_pred = true;
+                        d = m.at(pk.first, j - 1, path) + sc.get(lnz[i], seq[j]); u = m.at(pk.first, j, path) + sc.get(lnz[i], '-'); l = m.at(i, j - 1, path) + sc.get('-', seq[j]);
+                    }
+            }
+            int mv = std::max(std::max(d, u), l);
+            if (mv == d) { cg.push_back(lnz[i] != seq[j] ? 'd' : 'D'); hi.push_back(ids[i]); ps.push_back(lnz[i]); i = has_pred ? predecessor : i - 1; j -= 1; plen += 1; }
+            else if (mv == u) { cg.push_back('U'); hi.push_back(ids[i]); ps.push_back(lnz[i]); i = has_pred ? predecessor : i - 1; plen += 1; }
+            else { cg.push_back('L'); j -= 1; }
+        }
+        while (j > 0) { cg.push_back('L'); j -= 1; }
+    };
+    if (fbp == rbp) {
+        // ending_node :885-897, then gaf_output_semiglobal_no_rec (recombination_output.rs:239-361)
+        bool hb = false; int bs = 0; size_t en = 0;
+        for (size_t i = 1; i + 1 < L; ++i)
+            if (np[i][fbp]) { int v = m.at(i, W - 1, fbp); if (!hb || v > bs) { bs = v; en = i; hb = true; } }
+        size_t i = en, j = W - 1, plen = 0;
+        int score = m.at(i, j, fbp);
+        res.score = score;
+        std::vector<char> cigar, pseq; std::vector<uint64_t> hia;
+        fwd_walk(i, j, fbp, cigar, hia, pseq, plen);
+        std::reverse(cigar.begin(), cigar.end());
+        std::reverse(pseq.begin(), pseq.end());
+        auto dd = dedup(hia); std::reverse(dd.begin(), dd.end()); gaf.path = dd;
+        get_path_len_start_end(ids, i == 0 ? i : i + 1, en, plen, gaf.path_length, gaf.path_start, gaf.path_end);
+        gaf.comments = build_cigar(cigar) + ", best path: " + std::to_string(fbp) + ", score: " + std::to_string(score) + "\t" + std::string(pseq.begin(), pseq.end());
+    } else {
+        // gaf_output_semiglobal_rec (recombination_output.rs:12-237)
+        std::vector<char> cigar, pseq; std::vector<uint64_t> hia;
+        size_t rlen = 0, i = rsn, j = rec_col, rev_ending = i;
+        while (i > 0 && i < L - 1 && j < W - 1) {
+            bool has_pred = false; size_t predecessor = 0; int d = 0, u = 0, l = 0;
+            if (!rg.nwp[i]) {
+                d = w.at(i + 1, j + 1, rbp) + sc.get(lnz[i], r_seq[j]); u = w.at(i + 1, j, rbp) + sc.get(lnz[i], '-'); l = w.at(i, j + 1, rbp) + sc.get('-', r_seq[j]);
+            } else {
+                for (auto& pk : rg.pred_hash.at(i))
+                    if (pk.second[rbp]) {
+                        predecessor = pk.first; has_pred = true;
+                        d = w.at(pk.first, j + 1, rbp) + sc.get(lnz[i], r_seq[j]); u = w.at(pk.first, j, rbp) + sc.get(lnz[i], '-'); l = w.at(i, j + 1, rbp) + sc.get('-', r_seq[j]);
+                    }
+            }
+            int mv = std::max(std::max(d, u), l);
+            rev_ending = i;
+            if (mv == d) { cigar.push_back(lnz[i] != r_seq[j] ? 'd' : 'D'); hia.push_back(ids[i]); pseq.push_back(lnz[i]); i = has_pred ? predecessor : i + 1; j += 1; rlen += 1; }
+            else if (mv == u) { cigar.push_back('U'); hia.push_back(ids[i]); pseq.push_back(lnz[i]); i = has_pred ? predecessor : i + 1; rlen += 1; }
+            else { cigar.push_back('L'); j += 1; }
+        }
+        while (j < W - 1) { cigar.push_back('L'); j += 1; }
+        std::vector<char> tc, tp; std::vector<uint64_t> th;
+        size_t plen = 0; i = fen; j = rec_col;
+        fwd_walk(i, j, fbp, tc, th, tp, plen);
+        if (tp.empty()) { res.would_panic = true; return res; }   // usize underflow of rec_edge
+        size_t rec_edge = tp.size() - 1;
+        std::reverse(tc.begin(), tc.end()); tc.insert(tc.end(), cigar.begin(), cigar.end());
+        std::reverse(th.begin(), th.end()); th.insert(th.end(), hia.begin(), hia.end());
+        std::reverse(tp.begin(), tp.end()); tp.insert(tp.end(), pseq.begin(), pseq.end());
+        gaf.path = dedup(th);
+        get_rec_path_len_start_end(ids, fen, rsn, i == 0 ? i : i + 1, rev_ending, plen, rlen, gaf.path_length, gaf.path_start, gaf.path_end);
+        gaf.comments = build_cigar(tc) + ", recombination path " + std::to_string(fbp) + " " + std::to_string(rbp) + ", nodes " +
+                       std::to_string(ids[fen]) + "[" + std::to_string(get_node_offset(ids, fen)) + "] " + std::to_string(ids[rsn]) + "[" +
+                       std::to_string(get_node_offset(ids, rsn)) + "], score: " + f32_display(curr) + ", displacement: " +
+                       std::to_string(rec_penalty) + "\t" + std::string(tp.begin(), tp.end()) + "\t" + std::to_string(rec_edge);
         res.score = (int)curr;
     }
     res.out = gaf.to_string() + "\n";

@@ -28,6 +28,8 @@ MODE_GLOBAL_POA_SCALAR = 10
 MODE_GAP_POA = 2
 MODE_PATHWISE = 4
 MODE_RECOMBINATION = 8
+MODE_PATHWISE_SEMI = 5
+MODE_RECOMBINATION_SEMI = 9
 
 READ_BAND_WARNING, READ_BAND_NOT_ENOUGH, READ_WOULD_PANIC, READ_BAD_BASE = 1, 2, 4, 8
 
@@ -341,12 +343,19 @@ def pathwise_alignment_exec(sequence, graph, score_matrix=None):
     return GAFStruct.from_line(text.rstrip("\n"))
 
 
+def pathwise_alignment_semiglobal_exec(sequence, graph, score_matrix=None):
+    """pathwise_alignment_semiglobal::exec (pathwise_alignment_semiglobal.rs:6)."""
+    _, text = _single(graph, "".join(sequence[1:]), "Temp", MODE_PATHWISE_SEMI, 1, score_matrix=score_matrix)
+    return GAFStruct.from_line(text.rstrip("\n"))
+
+
 def pathwise_alignment_recombination_exec(aln_mode, sequence, graph, score_matrix=None, base_rec_cost=4,
                                           multi_rec_cost=0.1, rbw=1.0):
     """pathwise_alignment_recombination::exec (pathwise_alignment_recombination.rs:23); the reverse graph
     and the displacement matrix arguments of the reference are derived inside the graph handle."""
-    if aln_mode != 8:
-        raise _lib.RecGraphError(-1, "only aln_mode 8 is on the accelerated path")
-    _, text = _single(graph, "".join(sequence[1:]), "Temp", MODE_RECOMBINATION, 1, score_matrix=score_matrix,
+    if aln_mode not in (8, 9):
+        raise _lib.RecGraphError(-1, "aln_mode must be 8 (global) or 9 (semiglobal)")
+    _, text = _single(graph, "".join(sequence[1:]), "Temp", MODE_RECOMBINATION if aln_mode == 8 else MODE_RECOMBINATION_SEMI, 1,
+                      score_matrix=score_matrix,
                       R=base_rec_cost, r=multi_rec_cost, B=rbw)
     return GAFStruct.from_line(text.rstrip("\n"))

@@ -1,5 +1,5 @@
 """Command line front-end mirroring the mode dispatch of the reference's ``src/main.rs`` for the modes on
-the accelerated path (``-m 0, 2, 4, 8``): same positional arguments, flag names and defaults
+the accelerated path (``-m 0, 2, 4, 5, 8, 9``): same positional arguments, flag names and defaults
 (``src/args_parser.rs:3-147``), GAF on stdout (or appended to ``-o``), ``Done in N.`` on stderr.
 
     python -m recgraph_amd.cli reads.fa graph.gfa -m 8 -R 4 -r 0.1 -B 1
@@ -55,8 +55,8 @@ def main(argv=None):
     t0 = time.time()
     a = build_parser().parse_args(argv)
     from . import api
-    if a.alignment_mode not in (0, 2, 4, 8):
-        raise SystemExit("Alignment mode must be one of 0, 2, 4, 8 on the accelerated path")   # main.rs:315-317
+    if a.alignment_mode not in (0, 2, 4, 5, 8, 9):
+        raise SystemExit("Alignment mode must be one of 0, 2, 4, 5, 8, 9 on the accelerated path")   # main.rs:315-317
     if a.amb_strand == "true":
         raise SystemExit("-s true (reverse strand retry) is outside the accelerated path")
     if a.matrix in ("none",):
@@ -66,7 +66,8 @@ def main(argv=None):
     seqs, names = get_sequences(a.sequence_path)
     g = api.Graph.from_gfa(a.graph_path)
     mode = {0: api.MODE_GLOBAL_POA_SCALAR if a.scalar else api.MODE_GLOBAL_POA, 2: api.MODE_GAP_POA,
-            4: api.MODE_PATHWISE, 8: api.MODE_RECOMBINATION}[a.alignment_mode]
+            4: api.MODE_PATHWISE, 5: api.MODE_PATHWISE_SEMI, 8: api.MODE_RECOMBINATION,
+            9: api.MODE_RECOMBINATION_SEMI}[a.alignment_mode]
     texts, status = api.align_batch(g, seqs, names, mode=mode, score_matrix=scores, o=-a.gap_open, e=-a.gap_extension,
                                     b=float(a.extra_b), f=a.extra_f, R=a.base_rec_cost, r=a.multi_rec_cost,
                                     B=a.rec_band_width)

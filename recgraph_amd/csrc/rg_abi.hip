@@ -332,11 +332,13 @@ int32_t rg_batch_create(const rg_graph* gc, const rg_params* p, const char* read
     if (!gc || !p || !reads || !read_off || !out || nreads < 1) return fail(RG_ERR_ARG, "null/empty argument");
     rg_graph* g = const_cast<rg_graph*>(gc);
     const int mode = p->mode;
-    if (!(is_poa(mode) || mode == RG_MODE_PATHWISE || mode == RG_MODE_RECOMBINATION)) return fail(RG_ERR_ARG, "unsupported mode");
+    if (!(is_poa(mode) || mode == RG_MODE_PATHWISE || mode == RG_MODE_RECOMBINATION || mode == RG_MODE_PATHWISE_SEMI ||
+          mode == RG_MODE_RECOMBINATION_SEMI))
+        return fail(RG_ERR_ARG, "unsupported mode");
     if (mode == RG_MODE_GAP_POA && (p->gap_open > 0 || p->gap_ext > 0)) return fail(RG_ERR_ARG, "gap penalties must be <= 0");
     if (is_poa(mode) && !g->h.has_lnz) return fail(RG_ERR_ARG, "graph has no LnzGraph view");
     if (!is_poa(mode) && !g->h.has_path) return fail(RG_ERR_ARG, "graph has no paths (P lines)");
-    if (mode == RG_MODE_RECOMBINATION && (p->base_rec_cost < 0 || p->multi_rec_cost < 0))
+    if ((mode == RG_MODE_RECOMBINATION || mode == RG_MODE_RECOMBINATION_SEMI) && (p->base_rec_cost < 0 || p->multi_rec_cost < 0))
         return fail(RG_ERR_ARG, "recombination costs must be non-negative");
     if (mode == RG_MODE_GLOBAL_POA && g->h.L >= (1 << 20))
         return fail(RG_ERR_GRAPH, "m0: rows >= 2^20 break the reference's f32 path-cell decoding (gaf_output.rs:783-786)");

@@ -211,7 +211,9 @@ std::string format_pathwise(const HostGraph& g, const std::string& read, const s
     const int n = (int)read.size();
     Fields f;
     f.name = name; f.qlen = (size_t)n; f.qstart = 0; f.qend = (size_t)(n - 1);
-    const bool rec = mode == RG_MODE_RECOMBINATION && r.best_path != r.rev_path;
+    const bool rec = (mode == RG_MODE_RECOMBINATION || mode == RG_MODE_RECOMBINATION_SEMI) && r.best_path != r.rev_path;
+    // semiglobal walkers stop where the read is consumed: the path may start inside the graph, and the coordinate
+    // helpers receive `start = i + 1` for the row i the walk stopped on (recombination_output.rs:186,331)
     if (!rec) {
         const int bp = r.best_path;
         int i = r.end_row, j = n;
@@ -234,9 +236,10 @@ std::string format_pathwise(const HostGraph& g, const std::string& read, const s
         dedup(ids);
         std::reverse(ids.begin(), ids.end());
         f.path = ids;
-        // utils.rs:221-254 with start = 0
-        f.pstart = 0;
-        f.pend = plen > 0 ? plen - 1 : 0;
+        // utils.rs:221-254; start = 0 for the global modes (the walk pads down to row 0)
+        const int start = i == 0 ? 0 : i + 1;
+        f.pstart = head_in_segment(g, start);
+        f.pend = plen > 0 ? f.pstart + plen - 1 : 0;
         f.plen = f.pend + tail_in_segment(g, r.end_row) + 1;
         f.comments = rle_cigar(ops) + ", best path: " + std::to_string(bp) + ", score: " + std::to_string(r.score) +
                      "\t" + pseq;
@@ -247,6 +250,7 @@ std::string format_pathwise(const HostGraph& g, const std::string& read, const s
     std::string fops, fseq, rops, rseq;
     std::vector<uint64_t> fids, rids;
     size_t flen = 0, rlen = 0;
+    int fwd_stop = 0;
     {   // forward half, walked backwards from (fen, rec_col)
         int i = r.fen, j = r.rec_col;
         for (int k = 0; k < r.n_fwd_ops; ++k) {
@@ -260,6 +264,7 @@ std::string format_pathwise(const HostGraph& g, const std::string& read, const s
                 i = step_on_path(g, i, fp, true); ++flen;
             } else { fops.push_back('L'); j -= 1; }
         }
+        fwd_stop = i;
     }
     int rev_ending = r.rsn;
     {   // reverse half, walked forwards from (rsn, rec_col); r_seq[j] = read[j+1] (get_rev_sequence)
@@ -287,13 +292,15 @@ std::string format_pathwise(const HostGraph& g, const std::string& read, const s
     fids.insert(fids.end(), rids.begin(), rids.end());
     dedup(fids);
     f.path = fids;
-    // utils.rs:256-323 with start = 0
+    // utils.rs:256-323
     {
-        size_t forw_path_end = flen > 0 ? flen - 1 : 0;
+        const int start = fwd_stop == 0 ? 0 : fwd_stop + 1;
+        const size_t path_start = head_in_segment(g, start);
+        size_t forw_path_end = flen > 0 ? path_start + flen - 1 : 0;
         size_t forw_path_len = forw_path_end + tail_in_segment(g, r.fen) + 1;
         size_t rev_path_start = head_in_segment(g, r.rsn);
         size_t rev_path_end = rlen > 0 ? rev_path_start + rlen - 1 : 0;
-        f.pstart = 0;
+        f.pstart = path_start;
         f.pend = forw_path_len + rev_path_end;
         f.plen = forw_path_len + (rev_path_end + tail_in_segment(g, rev_ending) + 1);
     }

@@ -114,7 +114,10 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
                     std::vector<std::pair<std::string, std::pair<double, long long>>>& stats) {
     if (!pw.impl) pw.impl = new PathWorkImpl();
     PathWorkImpl& w = *pw.impl;
-    const int mode = p.mode;
+    const int pmode = p.mode;
+    const bool semi = pmode == RG_MODE_PATHWISE_SEMI || pmode == RG_MODE_RECOMBINATION_SEMI;
+    // pipeline selector: the semiglobal modes run the same kernels with the `semi` switches
+    const int mode = pmode == RG_MODE_PATHWISE_SEMI ? RG_MODE_PATHWISE : pmode == RG_MODE_RECOMBINATION_SEMI ? RG_MODE_RECOMBINATION : pmode;
     const int P = h.P, L = h.L;
     int C = 4;
     while (C * WAVE < max_n + 1) C *= 2;
@@ -245,8 +248,10 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
         for (int i = 0; i < 36; ++i) sa.sc.t[i] = p.scores[i];
         sa.reads = d_reads; sa.read_off = off; sa.bad = bad; sa.state = w.state.p; sa.roll = w.roll.p;
         sa.fsteps = w.fsteps.p; sa.rsteps = w.rsteps.p; sa.nfsteps = w.nfsteps; sa.nrsteps = w.nrsteps;
+        sa.semi = semi ? 1 : 0;
         sa.rbw = p.rec_band_width; sa.cand_cap = 0; sa.dir_words = dir_words; sa.cells = d_cells;
-        SeedArgs se{gd, w.state.p, chunk, mode};
+        SeedArgs se;
+        se.g = gd; se.state = w.state.p; se.nreads = chunk; se.mode = pmode; se.sc = sa.sc; se.reads = d_reads; se.read_off = off;
         if (mode == RG_MODE_PATHWISE) {
             SweepArgs f = sa;
             f.rev = 0; f.track_best = 0; f.dirs = w.fdirs.p; f.dirs_stride = fdirs_stride; f.count_cells = 1;
@@ -254,7 +259,7 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
             TIMED(T, "k_seed", launch_seed(se, stream));
         } else {
             if (two_sweep) {
-                Opt0Args oa{gd, sa.sc, d_reads, off, bad, w.fpoff.p, w.fprow.p, w.lb.p};
+                Opt0Args oa{gd, sa.sc, d_reads, off, bad, w.fpoff.p, w.fprow.p, w.lb.p, semi ? 1 : 0};
                 TIMED(T, "k_opt0", launch_opt0(oa, chunk, C, stream));
                 SweepArgs f = sa;
                 f.rev = 0; f.track_best = 1; f.lb = w.lb.p; f.brc = p.base_rec_cost; f.maxmatch = maxmatch;
@@ -313,6 +318,7 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
         }
         LayerArgs la;
         memset(&la, 0, sizeof la);
+        la.semi = semi ? 1 : 0;
         la.g = gd; la.sc = sa.sc; la.reads = d_reads; la.read_off = off; la.state = w.state.p; la.dir_words = dir_words;
         la.layer_stride = layer_stride; la.fpoff = w.fpoff.p; la.fprow = w.fprow.p; la.fpslot = w.fpslot.p;
         la.rpoff = w.rpoff.p; la.rprow = w.rprow.p; la.rpslot = w.rpslot.p;
@@ -327,7 +333,7 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
         ta.g = gd; ta.sc = sa.sc; ta.reads = d_reads; ta.read_off = off; ta.state = w.state.p; ta.rec = d_rec + done;
         ta.ops = d_ops + (long long)done * ops_stride; ta.ops_stride = ops_stride; ta.flayer = w.flayer.p;
         ta.rlayer = w.rlayer.p; ta.layer_stride = layer_stride; ta.fpoff = w.fpoff.p; ta.fprow = w.fprow.p;
-        ta.rpoff = w.rpoff.p; ta.rprow = w.rprow.p; ta.nreads = chunk; ta.mode = mode;
+        ta.rpoff = w.rpoff.p; ta.rprow = w.rprow.p; ta.nreads = chunk; ta.mode = pmode; ta.semi = semi ? 1 : 0;
         TIMED(T, "k_trace", launch_trace(ta, C, stream));
         if ((rc = T.collect(stats))) return rc;
         HIPCHK(hipMemcpy(&cells_done, d_cells, sizeof cells_done, hipMemcpyDeviceToHost));

@@ -10,10 +10,12 @@ struct ReadState {
     int s0;            // best no-recombination score (seed of the search) / m4 best score
     int seed_path;
     int end_row;       // sink row of the chosen path
+    int end_row_best;  // semiglobal: row of the overall best last-column value
     int fwd_path, rev_path, fen, rsn, rec_col, displacement;
     float fscore;
     int bound;         // integer lower bound of the final search maximum (>= s0), tightens the pruning
-    int sink_val[64];  // A[sink row][n][k]
+    int sink_val[64];  // A[sink row][n][k]; semiglobal: best last-column value of path k over its rows >= 1
+    int path_end_row[64];   // semiglobal: first row attaining sink_val[k] (ending_node, pathwise_alignment_recombination.rs:885-897)
 };
 
 // one entry of the recombination candidate lists: best member of (row, col) that can still matter
@@ -38,6 +40,7 @@ struct SweepArgs {
     const int* lb;             // per read lower bound of S0: when set (forward sweep only) the threshold of column
                                // j is lb + brc - (n - j) * maxmatch (no reverse information needed)
     int brc, maxmatch;
+    int semi;                  // semiglobal modes (-m 5 / -m 9): border column stays 0, free end row
     float rbw;                 // -B: columns outside the recombination band never emit
     int* colmax_out;           // [reads][wpad] per-column maximum of the best members, or null
     int* colarg_out;           // [reads][wpad] (row << 8 | path) of a cell attaining that maximum
@@ -57,6 +60,9 @@ struct SeedArgs {
     ReadState* state;
     int nreads;
     int mode;
+    DevScores sc;
+    const uint8_t* reads;
+    const long long* read_off;
 };
 
 struct ThrArgs {
@@ -88,6 +94,7 @@ struct Opt0Args {
     const uint8_t* bad;
     const int* fpoff; const int* fprow;
     int* lb;                   // out: exact global alignment score of the read against path 0
+    int semi;
 };
 
 struct SearchArgs {
@@ -116,6 +123,7 @@ struct LayerArgs {
     const uint32_t* dirs;
     long long dirs_stride;
     int dir_words;
+    int semi;
     int* layer;                // [reads][layer_stride]
     long long layer_stride;
     const int* fpoff; const int* fprow; const int* fpslot;   // rows of every path, forward order
@@ -138,6 +146,7 @@ struct TraceArgs {
     const int* rpoff; const int* rprow;
     int nreads;
     int mode;
+    int semi;
 };
 
 void launch_sweep(const SweepArgs& a, int nreads, int C, bool lds, hipStream_t s);

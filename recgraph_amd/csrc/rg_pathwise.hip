@@ -61,7 +61,7 @@ struct RowOps {
     // group alpha: max(d, u, l) as a lane-local serial scan + one wave prefix-max; returns the direction masks and
     // the fill-forward source lane (nearest lane to the left that owns a non-L column)
     static __device__ __forceinline__ void alpha(int (&row)[C], const int (&s)[C], const int (&GP)[kUni ? 1 : C], int gcost,
-                                                 int g_i, int lane, int ncols, unsigned& dmask, unsigned& lmask, int& src) {
+                                                 int g_i, int g0, int lane, int ncols, unsigned& dmask, unsigned& lmask, int& src) {
         int prev_old = dpp_shr1(row[C - 1], NEG);
         int runmax = NEG;
         unsigned dm = 0, lm = 0;
@@ -69,7 +69,8 @@ struct RowOps {
         for (int q = 0; q < C; ++q) {
             const int c = lane * C + q;
             const int old = row[q];
-            const int d = prev_old + s[q], u = old + g_i;
+            // g0: what the border column adds (the row's gap cost; 0 in the semiglobal modes)
+            const int d = prev_old + s[q], u = old + (q == 0 ? (c == 0 ? g0 : g_i) : g_i);
             const bool isd = (q == 0 ? c != 0 : true) && d >= u;   // border column 0: U only; priority D > U
             int du = isd ? d : u;
             du = c < ncols ? du : NEG;
@@ -95,13 +96,13 @@ struct RowOps {
     }
     // member: follow the alpha's directions with the path's own values
     static __device__ __forceinline__ void member(int (&row)[C], const int (&s)[C], const int (&GP)[kUni ? 1 : C], int gcost,
-                                                  int g_i, int lane, int ncols, unsigned dmask, unsigned lmask, int src) {
+                                                  int g_i, int g0, int lane, int ncols, unsigned dmask, unsigned lmask, int src) {
         int prev_old = dpp_shr1(row[C - 1], NEG);
         int last = NEG;
 #pragma unroll
         for (int q = 0; q < C; ++q) {
             const int old = row[q];
-            const int base = ((dmask >> q) & 1) ? prev_old + s[q] : old + g_i;
+            const int base = ((dmask >> q) & 1) ? prev_old + s[q] : old + (q == 0 ? (lane == 0 ? g0 : g_i) : g_i);
             prev_old = old;
             const int y = base - gp(GP, gcost, lane, q);
             row[q] = y;
@@ -286,6 +287,34 @@ __global__ __launch_bounds__(64, RG_SWEEP_WAVES) void k_sweep(SweepArgs a) {
     };
     constexpr int F_FIRST = 1, F_LAST = 2, F_INNER = 4;
 
+    // semiglobal end-row selection (forward sweep): the lane that owns column n folds every member value
+    //   * per path: first row (>= 1) with the largest last-column value  (ending_node, recombination.rs:885-897)
+    //   * overall: per row the lowest path id among the row maxima, across rows the first strictly larger row
+    //     (best_ending_node, pathwise_alignment_semiglobal.rs:244-277; -m 9 seed :789-800 which also counts row 0)
+    const bool semi_end = a.semi && !rev;
+    const int ln_end = n / C, ql_end = n % C;
+    int* endv = sct + 64;          // [64]
+    int* endr = sct + 128;         // [64]
+    if (semi_end) { endv[lane] = INT32_MIN; endr[lane] = 0; }
+    __syncthreads();
+    int gbest_val = INT32_MIN, gbest_row = 0, gbest_path = 0, rowkey = INT32_MIN;
+    auto end_fold = [&](int k, int i, const int (&row)[C]) {
+        int v = 0;
+#pragma unroll
+        for (int q = 0; q < C; ++q) if (q == ql_end) v = row[q];
+        if (lane == ln_end) {
+            if (v > endv[k]) { endv[k] = v; endr[k] = i; }
+            rowkey = max(rowkey, v * 64 + (63 - k));
+        }
+    };
+    auto end_row_done = [&](int i) {
+        if (lane == ln_end && rowkey != INT32_MIN) {
+            const int rv = rowkey >> 6, rk = 63 - (rowkey & 63);
+            if (rv > gbest_val) { gbest_val = rv; gbest_row = i; gbest_path = rk; }
+        }
+        rowkey = INT32_MIN;
+    };
+
     int s[C];
     int bkey[C];
     while (t < nsteps) {
@@ -315,18 +344,24 @@ __global__ __launch_bounds__(64, RG_SWEEP_WAVES) void k_sweep(SweepArgs a) {
                 }
             while (true) {
                 const int g_i = __builtin_amdgcn_readfirstlane(sct[li * 6 + GAP]);
+                const int g0 = a.semi ? 0 : g_i;
 #pragma unroll
                 for (int q = 0; q < C; ++q) s[q] = sct[li * 6 + (int)((erp >> (4 * q)) & 7)];
                 unsigned dmask = 0, lmask = 0;
                 int src = 0;
 #pragma unroll
                 for (int kk = 0; kk < KMAX; ++kk)
-                    if (kk < nm && mk[kk] == ga) RowOps<C, kUni>::alpha(r[kk], s, GP, gcost, g_i, lane, ncols, dmask, lmask, src);
+                    if (kk < nm && mk[kk] == ga) RowOps<C, kUni>::alpha(r[kk], s, GP, gcost, g_i, g0, lane, ncols, dmask, lmask, src);
                 if (dirs) store_dirs(slot, dmask, lmask);
 #pragma unroll
                 for (int kk = 0; kk < KMAX; ++kk)
-                    if (kk < nm && mk[kk] != ga) RowOps<C, kUni>::member(r[kk], s, GP, gcost, g_i, lane, ncols, dmask, lmask, src);
+                    if (kk < nm && mk[kk] != ga) RowOps<C, kUni>::member(r[kk], s, GP, gcost, g_i, g0, lane, ncols, dmask, lmask, src);
                 cells += (unsigned long long)nm;
+                if (semi_end) {
+#pragma unroll
+                    for (int kk = 0; kk < KMAX; ++kk) if (kk < nm) end_fold(mk[kk], i, r[kk]);
+                    end_row_done(i);
+                }
                 if (track) {
 #pragma unroll
                     for (int q = 0; q < C; ++q) bkey[q] = INT32_MIN;
@@ -355,6 +390,7 @@ __global__ __launch_bounds__(64, RG_SWEEP_WAVES) void k_sweep(SweepArgs a) {
         }
         // ---- general (row, group) step ----
         const int g_i = __builtin_amdgcn_readfirstlane(sct[li * 6 + GAP]);
+        const int g0 = a.semi ? 0 : g_i;
         if (flags & F_FIRST) {
 #pragma unroll
             for (int q = 0; q < C; ++q) { s[q] = sct[li * 6 + (int)((erp >> (4 * q)) & 7)]; bkey[q] = INT32_MIN; }
@@ -375,12 +411,13 @@ __global__ __launch_bounds__(64, RG_SWEEP_WAVES) void k_sweep(SweepArgs a) {
             }
             unsigned dmask, lmask;
             int src;
-            RowOps<C, kUni>::alpha(rowa, s, GP, gcost, g_i, lane, ncols, dmask, lmask, src);
+            RowOps<C, kUni>::alpha(rowa, s, GP, gcost, g_i, g0, lane, ncols, dmask, lmask, src);
 #pragma unroll
             for (int q = 0; q < C; ++q) {
                 rows.st(ga, q * WAVE + lane, wpad, rowa[q]);
                 if (track && (lane * C + q) < ncols) bkey[q] = max(bkey[q], rowa[q] * 64 + ga);
             }
+            if (semi_end) end_fold(ga, i, rowa);
             if (dirs) store_dirs(slot, dmask, lmask);
             // other members follow the alpha's directions; the next member's row is always in flight
             while (knext >= 0) {
@@ -394,15 +431,17 @@ __global__ __launch_bounds__(64, RG_SWEEP_WAVES) void k_sweep(SweepArgs a) {
 #pragma unroll
                     for (int q = 0; q < C; ++q) nxt[q] = rows.ld(knext, q * WAVE + lane, wpad);
                 } else knext = -1;
-                RowOps<C, kUni>::member(cur, s, GP, gcost, g_i, lane, ncols, dmask, lmask, src);
+                RowOps<C, kUni>::member(cur, s, GP, gcost, g_i, g0, lane, ncols, dmask, lmask, src);
 #pragma unroll
                 for (int q = 0; q < C; ++q) {
                     rows.st(k, q * WAVE + lane, wpad, cur[q]);
                     if (track && (lane * C + q) < ncols) bkey[q] = max(bkey[q], cur[q] * 64 + k);
                 }
+                if (semi_end) end_fold(k, i, cur);
             }
             // no barrier: every lane only ever re-reads the row words it wrote itself
         }
+        if (semi_end && (flags & F_LAST)) end_row_done(i);
         if (track && (flags & F_LAST)) row_end(i, ((w1 >> 24) & 127) - 1, bkey);
         ++t;
     }
@@ -420,10 +459,14 @@ __global__ __launch_bounds__(64, RG_SWEEP_WAVES) void k_sweep(SweepArgs a) {
     }
     if (a.ncand_out && lane == 0) a.ncand_out[rd] = ncand;
     __syncthreads();
-    if (!rev) {
+    if (!rev && !a.semi) {
         // value of every path at its sink row, column n (lane/slot that owns column n)
         const int cn = n, ql = cn % C, ln = cn / C;
         for (int k = lane; k < P; k += WAVE) rs->sink_val[k] = rows.ld(k, ql * WAVE + ln, wpad);
+    }
+    if (semi_end) {
+        if (lane < P) { rs->sink_val[lane] = endv[lane]; rs->path_end_row[lane] = endr[lane]; }
+        if (lane == ln_end) { rs->s0 = gbest_val; rs->end_row_best = gbest_row; rs->seed_path = gbest_path; }
     }
     if (lane == 0 && a.count_cells) atomicAdd(a.cells, cells * (unsigned long long)(n + 1));
 }
@@ -462,6 +505,7 @@ __global__ __launch_bounds__(64) void k_opt0(Opt0Args a) {
         for (int q = 0; q < C; ++q) { GP[q] += pre; row[q] = lane * C + q < ncols ? GP[q] : NEG; }
     }
     const int beg = a.fpoff[0], cnt = a.fpoff[1] - beg;
+    int semibest = NEG;
     for (int t = 0; t < cnt; ++t) {
         const int i = a.fprow[beg + t];
         const int li = g.lnz[i];
@@ -472,7 +516,7 @@ __global__ __launch_bounds__(64) void k_opt0(Opt0Args a) {
         for (int q = 0; q < C; ++q) {
             const int c = lane * C + q;
             const int old = row[q];
-            const int d = prev_old + sct[li * 6 + er[q]], u = old + g_i;
+            const int d = prev_old + sct[li * 6 + er[q]], u = old + ((a.semi && c == 0) ? 0 : g_i);
             int du = (c != 0 && d >= u) ? d : u;
             du = c < ncols ? du : NEG;
             prev_old = old;
@@ -488,12 +532,18 @@ __global__ __launch_bounds__(64) void k_opt0(Opt0Args a) {
             row[q] = c < ncols ? y + GP[q] : NEG;
             run = y;
         }
+        if (a.semi) {   // free end row: best last-column value over the rows of path 0
+            int v = NEG;
+#pragma unroll
+            for (int q = 0; q < C; ++q) if (q == n % C) v = row[q];
+            semibest = max(semibest, v);
+        }
     }
     const int ln = n / C, ql = n % C;
     int v = NEG;
 #pragma unroll
     for (int q = 0; q < C; ++q) if (q == ql) v = row[q];
-    if (lane == ln) a.lb[rd] = v;
+    if (lane == ln) a.lb[rd] = a.semi ? semibest : v;
 }
 
 // After the forward sweep: seed / best path (pathwise_alignment.rs:305-325,
@@ -505,6 +555,24 @@ __global__ void k_seed(SeedArgs a) {
     if (rs->status & (ST_BAD_BASE | ST_WOULD_PANIC)) return;
     const PathGraphDev& g = a.g;
     const int L = g.L, P = g.P;
+    if (a.mode == RG_MODE_PATHWISE_SEMI) {
+        // best_ending_node (pathwise_alignment_semiglobal.rs:244-277), folded by the sweep
+        rs->bound = rs->s0; rs->end_row = rs->end_row_best; rs->fwd_path = rs->seed_path; rs->rev_path = rs->seed_path;
+        return;
+    }
+    if (a.mode == RG_MODE_RECOMBINATION_SEMI) {
+        // seed over rows 0..L-2 (pathwise_alignment_recombination.rs:789-800): row 0 is the all-gap row of every path,
+        // it wins ties (lowest row) with path 0 (lowest id)
+        const long long ro = a.read_off[rd];
+        const int n = (int)(a.read_off[rd + 1] - ro);
+        int gapsum = 0;
+        for (int j = 0; j < n; ++j) gapsum += a.sc.t[a.reads[ro + j] * 6 + 5];
+        if (rs->s0 <= gapsum) { rs->s0 = gapsum; rs->seed_path = 0; }
+        const int bp = rs->seed_path;
+        rs->bound = rs->s0; rs->fwd_path = bp; rs->rev_path = bp;
+        rs->end_row = rs->path_end_row[bp];       // ending_node(.., best_path, ..) :885-897 (rows >= 1 only)
+        return;
+    }
     if (a.mode == RG_MODE_PATHWISE) {
         // results[k] = A[sink(k)][n][k] for paths registered at F, 0 otherwise; max of (score, path id)
         int best = 0, bp = 0, bend = 0;
@@ -781,7 +849,7 @@ __global__ __launch_bounds__(64) void k_layer(LayerArgs a) {
 #pragma unroll
         for (int q = 0; q < C; ++q) {
             const int om1 = q == 0 ? pk : cur[q - 1];
-            const int base = ((dmask >> q) & 1) ? om1 + sct[li * 6 + er[q]] : cur[q] + g_i;
+            const int base = ((dmask >> q) & 1) ? om1 + sct[li * 6 + er[q]] : cur[q] + ((a.semi && q == 0 && lane == 0) ? 0 : g_i);
             y[q] = base - GP[q];
             if (!((lmask >> q) & 1) && act[q]) last = y[q];
         }
@@ -818,7 +886,7 @@ __global__ __launch_bounds__(64) void k_trace(TraceArgs a) {
     const int L = g.L;
     uint8_t* ops = a.ops + (long long)rd * a.ops_stride;
     int nops = 0;
-    const bool recomb = a.mode == RG_MODE_RECOMBINATION && rs->fwd_path != rs->rev_path;
+    const bool recomb = (a.mode == RG_MODE_RECOMBINATION || a.mode == RG_MODE_RECOMBINATION_SEMI) && rs->fwd_path != rs->rev_path;
     auto at = [&](const int* layer, int idx, int c) { return layer[(long long)idx * wpad + (c % C) * WAVE + c / C]; };
     const int* fl = a.flayer + (long long)rd * a.layer_stride;
     // ---- forward walk from (row, j) back to the source on path fp ----
@@ -844,7 +912,7 @@ __global__ __launch_bounds__(64) void k_trace(TraceArgs a) {
         else { ops[nops++] = OP_L; j -= 1; }
     }
     while (j > 0) { ops[nops++] = OP_L; j -= 1; }
-    while (t > 0) { ops[nops++] = OP_U; t -= 1; }
+    while (!a.semi && t > 0) { ops[nops++] = OP_U; t -= 1; }   // semiglobal: the alignment may start inside the graph
     const int nfwd = nops;
     if (recomb) {
         // ---- reverse walk from (rsn, rec_col) forward to the sink on path rp ----
@@ -876,7 +944,7 @@ __global__ __launch_bounds__(64) void k_trace(TraceArgs a) {
             else { ops[nops++] = OP_L; jj += 1; }
         }
         while (jj < n) { ops[nops++] = OP_L | OP_CONT; jj += 1; }
-        while (tt > 0) { ops[nops++] = OP_U | OP_CONT; tt -= 1; }
+        while (!a.semi && tt > 0) { ops[nops++] = OP_U | OP_CONT; tt -= 1; }
         (void)L;
     }
     rec->status = rs->status;
@@ -895,7 +963,7 @@ __global__ __launch_bounds__(64) void k_trace(TraceArgs a) {
 // launchers
 template <int C, bool kUni>
 static void launch_sweep_cu(const SweepArgs& a, int nreads, bool lds, hipStream_t s) {
-    const size_t sct_bytes = 64 * sizeof(int);
+    const size_t sct_bytes = 192 * sizeof(int);
     if (lds) {
         const size_t bytes = (size_t)a.g.P * C * WAVE * sizeof(int) + sct_bytes;
         (void)hipFuncSetAttribute((const void*)k_sweep<C, true, kUni>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);

@@ -67,3 +67,26 @@ def test_synthetic_haplotype_graph(oracle):
     _check(oracle, g.gfa(), reads, api.MODE_PATHWISE, oracle.M4_ABS)
     _check(oracle, g.gfa(), reads, api.MODE_RECOMBINATION, oracle.M8_ABS)
     _check(oracle, g.gfa(), reads[:6], api.MODE_RECOMBINATION, oracle.M8_PRUNED)
+
+
+def test_semiglobal_modes(oracle, example_gfa, example_reads):
+    """-m 5 (pathwise_alignment_semiglobal.rs) and -m 9 (aln_mode 9 branches)."""
+    from recgraph_amd import api, synth
+    rng = np.random.default_rng(4)
+    for gfa in (DIAMOND, TWO_BUBBLES):
+        reads = ["".join("ACGT"[int(x)] for x in rng.integers(0, 4, size=int(rng.integers(1, 9)))) for _ in range(40)]
+        reads += ["A", "T", "ATG", "TG", "GCT", "ATGCT", "TTTTTTTT", "N"]
+        _check(oracle, gfa, reads, api.MODE_PATHWISE_SEMI, oracle.M5)
+        _check(oracle, gfa, reads, api.MODE_RECOMBINATION_SEMI, oracle.M9)
+        _check(oracle, gfa, reads, api.MODE_RECOMBINATION_SEMI, oracle.M9, R=0, r=0.0)
+        _check(oracle, gfa, reads, api.MODE_RECOMBINATION_SEMI, oracle.M9, R=1, r=0.5, B=0.6)
+    names, reads = example_reads
+    _check(oracle, example_gfa, reads, api.MODE_PATHWISE_SEMI, oracle.M5_ABS, names=names)
+    _check(oracle, example_gfa, reads, api.MODE_RECOMBINATION_SEMI, oracle.M9_ABS, names=names)
+    _check(oracle, example_gfa, reads[:3], api.MODE_RECOMBINATION_SEMI, oracle.M9_PRUNED, names=names[:3])
+    g = synth.haplotype_graph(1500, 8, path_len=300, seed=11)
+    rd = synth.haplotype_reads(g, 32, length=120, seed=13, mosaic_frac=0.5)
+    rd += [g.path_sequence(2)[50:170], g.path_sequence(3)[100:160] + g.path_sequence(5)[160:230], "ACGT" * 10]
+    _check(oracle, g.gfa(), rd, api.MODE_PATHWISE_SEMI, oracle.M5_ABS)
+    _check(oracle, g.gfa(), rd, api.MODE_RECOMBINATION_SEMI, oracle.M9_ABS)
+    _check(oracle, g.gfa(), rd, api.MODE_RECOMBINATION_SEMI, oracle.M9_ABS, R=0, r=0.0)

@@ -138,6 +138,25 @@ def test_literal_and_absolute_restatements_agree(oracle):
                 assert b == g.align(oracle.M8_ABS, rd, **kw)[0]
 
 
+def test_semiglobal_restatements_agree(oracle):
+    """-m 5 / -m 9: literal vs absolute-form restatement, unpruned vs pruned search."""
+    from recgraph_amd import synth
+    rng = np.random.default_rng(6)
+    for seed in range(5):
+        sg = synth.haplotype_graph(int(rng.integers(60, 140)), int(rng.integers(2, 7)), path_len=int(rng.integers(14, 30)),
+                                   seed=300 + seed)
+        g = oracle.Graph.from_gfa_text(sg.gfa())
+        n = len(sg.path_sequence(0))
+        reads = synth.haplotype_reads(sg, 4, length=max(4, n - 2), seed=seed, mosaic_frac=0.5)
+        reads += ["ACGT", sg.path_sequence(1)[n // 3:2 * n // 3], sg.path_sequence(0)[:n // 2]]
+        for rd in reads:
+            assert g.align(oracle.M5, rd)[0] == g.align(oracle.M5_ABS, rd)[0]
+            for kw in ({}, {"R": 0, "r": 0.0}, {"R": 2, "r": 0.7, "B": 0.5}):
+                b = g.align(oracle.M9, rd, **kw)[0]
+                assert b == g.align(oracle.M9_PRUNED, rd, **kw)[0]
+                assert b == g.align(oracle.M9_ABS, rd, **kw)[0]
+
+
 def test_example_data_restatements_agree(oracle, example_gfa, example_reads):
     names, reads = example_reads
     g = oracle.Graph.from_gfa_text(example_gfa)
