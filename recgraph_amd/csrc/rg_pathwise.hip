@@ -144,7 +144,7 @@ __global__ __launch_bounds__(64, RG_SWEEP_WAVES) void k_sweep(SweepArgs a) {
 
     Rows<kLds> rows{kLds ? nullptr : a.roll + (long long)rd * P * wpad};
     // per-column constants of this lane
-    unsigned long long erp = 0;   // 4 bits per column: read base facing column c (forward read[c]; reverse read[n-c+1])
+    unsigned long long erp[(C + 15) / 16] = {};   // 4 bits per column: read base facing column c (forward read[c]; reverse read[n-c+1])
     int GP[kUni ? 1 : C];         // prefix sums of the read-gap cost up to column c (general matrices only)
     const int gcost = sct[GAP];
     int thr[C];                   // emission threshold per column (INT32_MAX = never)
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(64, RG_SWEEP_WAVES) void k_sweep(SweepArgs a) {
             const int c = lane * C + q;
             int code = 4;
             if (c >= 1 && c < ncols) code = rev ? read[n - c + 1] : read[c];
-            erp |= (unsigned long long)code << (4 * q);
+            erp[q / 16] |= (unsigned long long)code << (4 * (q % 16));
             run += (c >= 1 && c < ncols) ? sct[code * 6 + GAP] : 0;
             gpl[q] = run;
         }
@@ -346,7 +346,7 @@ __global__ __launch_bounds__(64, RG_SWEEP_WAVES) void k_sweep(SweepArgs a) {
                 const int g_i = __builtin_amdgcn_readfirstlane(sct[li * 6 + GAP]);
                 const int g0 = a.semi ? 0 : g_i;
 #pragma unroll
-                for (int q = 0; q < C; ++q) s[q] = sct[li * 6 + (int)((erp >> (4 * q)) & 7)];
+                for (int q = 0; q < C; ++q) s[q] = sct[li * 6 + (int)((erp[q / 16] >> (4 * (q % 16))) & 7)];
                 unsigned dmask = 0, lmask = 0;
                 int src = 0;
 #pragma unroll
@@ -393,7 +393,7 @@ __global__ __launch_bounds__(64, RG_SWEEP_WAVES) void k_sweep(SweepArgs a) {
         const int g0 = a.semi ? 0 : g_i;
         if (flags & F_FIRST) {
 #pragma unroll
-            for (int q = 0; q < C; ++q) { s[q] = sct[li * 6 + (int)((erp >> (4 * q)) & 7)]; bkey[q] = INT32_MIN; }
+            for (int q = 0; q < C; ++q) { s[q] = sct[li * 6 + (int)((erp[q / 16] >> (4 * (q % 16))) & 7)]; bkey[q] = INT32_MIN; }
         }
         {
             unsigned long long rest = gmask & ~(1ull << ga);

@@ -90,3 +90,34 @@ def test_semiglobal_modes(oracle, example_gfa, example_reads):
     _check(oracle, g.gfa(), rd, api.MODE_PATHWISE_SEMI, oracle.M5_ABS)
     _check(oracle, g.gfa(), rd, api.MODE_RECOMBINATION_SEMI, oracle.M9_ABS)
     _check(oracle, g.gfa(), rd, api.MODE_RECOMBINATION_SEMI, oracle.M9_ABS, R=0, r=0.0)
+
+
+def test_wide_and_long_shapes(oracle):
+    """Kernel template coverage: C = 32 (reads up to 2047 bases), more than 32 paths (64-bit masks),
+    general (non-uniform) gap scores, and the read-length limit as a status code."""
+    from recgraph_amd import _lib, api, synth
+    # long reads: C = 32 columns per lane
+    g = synth.haplotype_graph(4000, 6, path_len=1400, seed=21)
+    rd = synth.haplotype_reads(g, 6, length=1400, seed=22, mosaic_frac=0.5) + [g.path_sequence(1)[:1100]]
+    _check(oracle, g.gfa(), rd, api.MODE_PATHWISE, oracle.M4_ABS)
+    _check(oracle, g.gfa(), rd, api.MODE_RECOMBINATION, oracle.M8_ABS)
+    _check(oracle, g.gfa(), rd[:3], api.MODE_RECOMBINATION_SEMI, oracle.M9_ABS)
+    # 40 paths
+    g = synth.haplotype_graph(1200, 40, path_len=150, seed=23)
+    rd = synth.haplotype_reads(g, 24, length=150, seed=24, mosaic_frac=0.5)
+    _check(oracle, g.gfa(), rd, api.MODE_PATHWISE, oracle.M4_ABS)
+    _check(oracle, g.gfa(), rd, api.MODE_RECOMBINATION, oracle.M8_ABS)
+    _check(oracle, g.gfa(), rd[:6], api.MODE_RECOMBINATION, oracle.M8_PRUNED)
+    # non-uniform gap costs (a custom matrix as api.rs callers may pass): the general-GP kernel variant
+    sm = api.create_score_matrix_i32(3, -5)
+    sm[("A", "-")] = -7; sm[("-", "A")] = -7; sm[("G", "-")] = -12; sm[("-", "G")] = -12
+    og = oracle.Graph.from_gfa_text(g.gfa())
+    gg = api.Graph.from_gfa_text(g.gfa())
+    table = api._table_from_dict(sm)
+    for mode, om in ((api.MODE_PATHWISE, oracle.M4_ABS), (api.MODE_RECOMBINATION, oracle.M8_ABS)):
+        texts, _ = api.align_batch(gg, rd[:10], None, mode=mode, score_matrix=sm)
+        for i, r in enumerate(rd[:10]):
+            assert texts[i] == og.align(om, r, name="read%d" % i, scores=table)[0]
+    # reads longer than the supported 2047 bases: status code, no abort
+    with pytest.raises(_lib.RecGraphError):
+        api.align_batch(gg, ["ACGT" * 600], None, mode=api.MODE_PATHWISE)
