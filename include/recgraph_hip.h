@@ -43,6 +43,9 @@ typedef enum rg_status {
 #define RG_MODE_RECOMBINATION 8     /* pathwise_alignment_recombination::exec (aln_mode 8) src/pathwise_alignment_recombination.rs:23 */
 #define RG_MODE_PATHWISE_SEMI 5     /* pathwise_alignment_semiglobal::exec  src/pathwise_alignment_semiglobal.rs:6 */
 #define RG_MODE_RECOMBINATION_SEMI 9/* pathwise_alignment_recombination::exec (aln_mode 9) */
+#define RG_MODE_LOCAL_POA 1         /* local_poa::exec_simd             src/local_poa.rs:9          */
+#define RG_MODE_LOCAL_POA_SCALAR 11 /* local_poa::exec (no-AVX2 path)   src/local_poa.rs:176        */
+#define RG_MODE_GAP_LOCAL_POA 3     /* gap_local_poa::exec              src/gap_local_poa.rs:6      */
 
 /*
  * Scoring and banding parameters.  Replaces the HashMap<(char,char),i32|f32> score matrix arguments

@@ -14,6 +14,7 @@ _LIB = os.path.join(_HERE, "liboracle.so")
 
 M0_SIMD, M0_SCALAR, M2, M4, M4_ABS, M8, M8_PRUNED, M8_ABS = 0, 10, 2, 4, 14, 8, 18, 28
 M5, M5_ABS, M9, M9_PRUNED, M9_ABS = 5, 15, 9, 19, 29
+M1_SIMD, M1_SCALAR, M3 = 1, 11, 3
 
 
 def build(force=False):

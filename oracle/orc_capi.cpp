@@ -30,7 +30,8 @@ extern "C" {
 
 // mode ids
 enum { ORC_M0_SIMD = 0, ORC_M0_SCALAR = 10, ORC_M2 = 2, ORC_M4 = 4, ORC_M4_ABS = 14, ORC_M8 = 8, ORC_M8_PRUNED = 18, ORC_M8_ABS = 28,
-       ORC_M5 = 5, ORC_M5_ABS = 15, ORC_M9 = 9, ORC_M9_PRUNED = 19, ORC_M9_ABS = 29 };
+       ORC_M5 = 5, ORC_M5_ABS = 15, ORC_M9 = 9, ORC_M9_PRUNED = 19, ORC_M9_ABS = 29, ORC_M1_SIMD = 1, ORC_M1_SCALAR = 11,
+       ORC_M3 = 3 };
 
 void orc_scores_match_mis(int m, int x, int f32_variant, int* out36) {
     Scores s = f32_variant ? make_scores_match_mis_f32(m, x) : make_scores_match_mis(m, x);
@@ -134,6 +135,9 @@ static Result run_one(OrcGraph* g, int mode, const std::string& read_dollar, con
         case ORC_M0_SIMD: return m0_simd(read_dollar, name, idx, g->lnz, sc, bta, g->r_values, cells);
         case ORC_M0_SCALAR: return m0_scalar(read_dollar, name, idx, g->lnz, sc, bta, cells);
         case ORC_M2: return m2_gap(read_dollar, name, idx, g->lnz, sc, o, e, bta, cells);
+        case ORC_M1_SIMD: return m1_simd(read_dollar, name, idx, g->lnz, sc, cells);
+        case ORC_M1_SCALAR: return m1_scalar(read_dollar, name, idx, g->lnz, sc, cells);
+        case ORC_M3: return m3_gap_local(read_dollar, name, idx, g->lnz, sc, o, e, cells);
         case ORC_M4: return m4_literal(read_dollar, name, g->pg, sc);
         case ORC_M4_ABS: return m4_abs(read_dollar, name, g->pg, sc);
         case ORC_M8: return m8_literal(read_dollar, name, g->pg, g->rpg, g->dfs, g->dfe, sc, brc, mrc, rbw, false);

@@ -146,6 +146,15 @@ Result m0_scalar(const std::string& read, const std::string& name, size_t idx,
 Result m2_gap(const std::string& read, const std::string& name, size_t idx, const LnzGraph& g,
               const Scores& sc, int o, int e, size_t bta, uint64_t* cells = nullptr);
 
+// local POA, orc_local.cpp: -m 1 AVX2 path src/local_poa.rs:9-174, -m 1 scalar path :176-262,
+// -m 3 src/gap_local_poa.rs:6-183; GAF walkers gaf_output.rs:383-752
+Result m1_simd(const std::string& read, const std::string& name, size_t idx, const LnzGraph& g, const Scores& sc,
+               uint64_t* cells = nullptr);
+Result m1_scalar(const std::string& read, const std::string& name, size_t idx, const LnzGraph& g, const Scores& sc,
+                 uint64_t* cells = nullptr);
+Result m3_gap_local(const std::string& read, const std::string& name, size_t idx, const LnzGraph& g, const Scores& sc,
+                    int o, int e, uint64_t* cells = nullptr);
+
 // m4: src/pathwise_alignment.rs:5-340 + pathwise_alignment_output.rs:7-184 (literal,
 // delta-encoded dpm)
 Result m4_literal(const std::string& read, const std::string& name, const PathGraph& g,

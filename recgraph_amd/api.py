@@ -30,6 +30,9 @@ MODE_PATHWISE = 4
 MODE_RECOMBINATION = 8
 MODE_PATHWISE_SEMI = 5
 MODE_RECOMBINATION_SEMI = 9
+MODE_LOCAL_POA = 1
+MODE_LOCAL_POA_SCALAR = 11
+MODE_GAP_LOCAL_POA = 3
 
 READ_BAND_WARNING, READ_BAND_NOT_ENOUGH, READ_WOULD_PANIC, READ_BAD_BASE = 1, 2, 4, 8
 
@@ -317,6 +320,43 @@ def align_global_gap(read, graph, sequence_name=None, score_matrix=None, bases_t
     _, text = _single(graph, read, name, MODE_GAP_POA, idx, score_matrix=sm, bta=bta, o=-10 if o is None else o,
                       e=-6 if e is None else e)
     return GAFStruct.from_line(text.rstrip("\n").split("\n")[-1])
+
+
+def align_local_no_gap(read, graph, sequence_name=None, score_matrix=None):
+    """api.rs:76-99.  Defaults: f32 matrix (2, -4, gaps -4), name ("no_name", 1)."""
+    sm = score_matrix if score_matrix is not None else create_score_matrix_f32(2, -4)
+    name, idx = sequence_name if sequence_name is not None else ("no_name", 1)
+    if idx == 0:
+        raise _lib.RecGraphError(-1, "alignment.1.unwrap() on None (api.rs:97)")
+    _, text = _single(graph, read, name, MODE_LOCAL_POA, idx, score_matrix=sm)
+    return GAFStruct.from_line(text.rstrip("\n").split("\n")[-1])
+
+
+def align_local_gap(read, graph, sequence_name=None, score_matrix=None, o=None, e=None):
+    """api.rs:102-128.  Defaults: i32 matrix (2, -4), o = -10, e = -6."""
+    sm = score_matrix if score_matrix is not None else create_score_matrix_i32(2, -4)
+    name, idx = sequence_name if sequence_name is not None else ("no_name", 1)
+    if idx == 0:
+        raise _lib.RecGraphError(-1, "alignment.1.unwrap() on None (api.rs:127)")
+    _, text = _single(graph, read, name, MODE_GAP_LOCAL_POA, idx, score_matrix=sm, o=-10 if o is None else o,
+                      e=-6 if e is None else e)
+    return GAFStruct.from_line(text.rstrip("\n").split("\n")[-1])
+
+
+def local_poa_exec(sequence, seq_name, graph, score_matrix, scalar=True):
+    """local_poa::exec (local_poa.rs:176) / exec_simd (:9): returns (score, GAFStruct | None)."""
+    mode = MODE_LOCAL_POA_SCALAR if scalar else MODE_LOCAL_POA
+    b, text = _single(graph, "".join(sequence[1:]), seq_name[0], mode, seq_name[1], score_matrix=score_matrix)
+    gaf = GAFStruct.from_line(text.rstrip("\n").split("\n")[-1]) if seq_name[1] != 0 and text else None
+    return b.score(0), gaf
+
+
+def gap_local_poa_exec(sequence, seq_name, graph, score_matrix, o, e):
+    """gap_local_poa::exec (gap_local_poa.rs:6): returns (score, GAFStruct | None)."""
+    b, text = _single(graph, "".join(sequence[1:]), seq_name[0], MODE_GAP_LOCAL_POA, seq_name[1],
+                      score_matrix=score_matrix, o=o, e=e)
+    gaf = GAFStruct.from_line(text.rstrip("\n").split("\n")[-1]) if seq_name[1] != 0 and text else None
+    return b.score(0), gaf
 
 
 def global_abpoa_exec(sequence, seq_name, graph, score_matrix, bta, scalar=True):

@@ -1,5 +1,5 @@
 """Command line front-end mirroring the mode dispatch of the reference's ``src/main.rs`` for the modes on
-the accelerated path (``-m 0, 2, 4, 5, 8, 9``): same positional arguments, flag names and defaults
+the accelerated path (``-m 0, 1, 2, 3, 4, 5, 8, 9``): same positional arguments, flag names and defaults
 (``src/args_parser.rs:3-147``), GAF on stdout (or appended to ``-o``), ``Done in N.`` on stderr.
 
     python -m recgraph_amd.cli reads.fa graph.gfa -m 8 -R 4 -r 0.1 -B 1
@@ -47,7 +47,7 @@ def build_parser():
     p.add_argument("-s", "--amb-strand", default="false", choices=["true", "false"])
     p.add_argument("-b", "--extra-b", type=int, default=1)
     p.add_argument("-f", "--extra-f", type=float, default=0.01)
-    p.add_argument("--scalar", action="store_true", help="-m 0 with the non-AVX2 path of the reference")
+    p.add_argument("--scalar", action="store_true", help="-m 0 / -m 1 with the non-AVX2 path of the reference")
     return p
 
 
@@ -55,8 +55,8 @@ def main(argv=None):
     t0 = time.time()
     a = build_parser().parse_args(argv)
     from . import api
-    if a.alignment_mode not in (0, 2, 4, 5, 8, 9):
-        raise SystemExit("Alignment mode must be one of 0, 2, 4, 5, 8, 9 on the accelerated path")   # main.rs:315-317
+    if a.alignment_mode not in (0, 1, 2, 3, 4, 5, 8, 9):
+        raise SystemExit("Alignment mode must be in [0..5] or [8, 9]")   # main.rs:315-317
     if a.amb_strand == "true":
         raise SystemExit("-s true (reverse strand retry) is outside the accelerated path")
     if a.matrix in ("none",):
@@ -66,6 +66,7 @@ def main(argv=None):
     seqs, names = get_sequences(a.sequence_path)
     g = api.Graph.from_gfa(a.graph_path)
     mode = {0: api.MODE_GLOBAL_POA_SCALAR if a.scalar else api.MODE_GLOBAL_POA, 2: api.MODE_GAP_POA,
+            1: api.MODE_LOCAL_POA_SCALAR if a.scalar else api.MODE_LOCAL_POA, 3: api.MODE_GAP_LOCAL_POA,
             4: api.MODE_PATHWISE, 5: api.MODE_PATHWISE_SEMI, 8: api.MODE_RECOMBINATION,
             9: api.MODE_RECOMBINATION_SEMI}[a.alignment_mode]
     texts, status = api.align_batch(g, seqs, names, mode=mode, score_matrix=scores, o=-a.gap_open, e=-a.gap_extension,

@@ -29,6 +29,7 @@ struct DevBuf {
     T* p = nullptr;
     size_t n = 0;
     ~DevBuf() { if (p) (void)hipFree(p); }
+    size_t bytes() const { return p ? n * sizeof(T) : 0; }
     int alloc(size_t count) {
         if (count <= n && p) return RG_OK;
         if (p) { (void)hipFree(p); p = nullptr; n = 0; }
@@ -195,13 +196,60 @@ struct Timed {
     }
 };
 
-bool is_poa(int mode) { return mode == RG_MODE_GLOBAL_POA || mode == RG_MODE_GLOBAL_POA_SCALAR || mode == RG_MODE_GAP_POA; }
+bool is_local(int mode) { return mode == RG_MODE_LOCAL_POA || mode == RG_MODE_LOCAL_POA_SCALAR || mode == RG_MODE_GAP_LOCAL_POA; }
+bool is_poa(int mode) {
+    return mode == RG_MODE_GLOBAL_POA || mode == RG_MODE_GLOBAL_POA_SCALAR || mode == RG_MODE_GAP_POA || is_local(mode);
+}
+
+// Local modes fill full (L-1) x W matrices: reads are processed in launches of as many reads as fit the free HBM.
+int run_local(rg_batch* b) {
+    rg_graph* g = b->g;
+    const HostGraph& h = g->h;
+    const int mode = b->p.mode;
+    const int planes = mode == RG_MODE_GAP_LOCAL_POA ? 2 : 1;
+    const int variant = mode == RG_MODE_LOCAL_POA ? 0 : mode == RG_MODE_LOCAL_POA_SCALAR ? 1 : 2;
+    const char* kname = variant == 0 ? "k_m1_local_simd" : variant == 1 ? "k_m1_local_scalar" : "k_m3_gap_local";
+    Timed T(b);
+    for (auto& s : b->stats) { s.ms = 0; s.launches = 0; }
+    b->cap_cells = (long long)(h.L - 1) * (b->max_n + 1);
+    const size_t per_read = (size_t)b->cap_cells * planes * (sizeof(int) + sizeof(uint32_t));
+    size_t free_b = 0, total_b = 0;
+    HIPCHK(hipMemGetInfo(&free_b, &total_b));
+    free_b += b->d_arena_m.bytes() + b->d_arena_pw.bytes();   // arenas of a previous run are reused
+    const size_t budget = free_b / 4 * 3;
+    if (per_read > budget) return fail(RG_ERR_CAPACITY, "local POA: one read's L x W matrices exceed the free HBM");
+    const long long chunk = (long long)std::min<size_t>((size_t)b->nreads, budget / per_read);
+    int rc;
+    if ((rc = b->d_arena_m.alloc((size_t)chunk * b->cap_cells * planes)) ||
+        (rc = b->d_arena_pw.alloc((size_t)chunk * b->cap_cells * planes)))
+        return rc;
+    HIPCHK(hipMemsetAsync(b->d_cells.p, 0, sizeof(unsigned long long), b->stream));
+    PoaArgs a;
+    a.g = DevLnz{h.L, g->d_lnz.p, g->d_pred_off.p, g->d_pred_rows.p, g->d_r_values.p, g->d_min_pred.p};
+    for (int i = 0; i < 36; ++i) a.sc.t[i] = b->p.scores[i];
+    a.reads = b->d_reads.p; a.read_off = b->d_off.p; a.bad = b->d_bad.p; a.bta = b->d_bta.p; a.col0 = b->d_col0.p;
+    a.gap_open = b->p.gap_open; a.gap_ext = b->p.gap_ext;
+    a.cap_cells = b->cap_cells; a.arena_m = b->d_arena_m.p; a.arena_pw = b->d_arena_pw.p; a.rinfo = b->d_rinfo.p;
+    a.rec = b->d_rec.p; a.ops = b->d_ops.p; a.oprows = b->d_oprows.p; a.ops_stride = b->ops_stride;
+    a.cells = b->d_cells.p;
+    for (long long base = 0; base < b->nreads; base += chunk) {
+        a.read_base = (int)base;
+        a.nreads = (int)std::min<long long>(chunk, b->nreads - base);
+        if ((rc = T.run(kname, [&] { launch_local(a, variant, b->stream); }))) return rc;
+    }
+    if ((rc = T.collect())) return rc;
+    unsigned long long c = 0;
+    HIPCHK(hipMemcpy(&c, b->d_cells.p, sizeof c, hipMemcpyDeviceToHost));
+    b->cells = c;
+    return RG_OK;
+}
 
 int run_poa(rg_batch* b) {
     rg_graph* g = b->g;
     const HostGraph& h = g->h;
     if (!h.has_lnz) return fail(RG_ERR_ARG, "graph has no LnzGraph view");
     const int mode = b->p.mode;
+    if (is_local(mode)) return run_local(b);
     const int planes = mode == RG_MODE_GAP_POA ? 3 : 1;   // m2: m | y | (spare) score planes, w0 | w1 path planes
     Timed T(b);
     for (auto& s : b->stats) { s.ms = 0; s.launches = 0; }
@@ -215,7 +263,7 @@ int run_poa(rg_batch* b) {
         a.g = DevLnz{h.L, g->d_lnz.p, g->d_pred_off.p, g->d_pred_rows.p, g->d_r_values.p, g->d_min_pred.p};
         for (int i = 0; i < 36; ++i) a.sc.t[i] = b->p.scores[i];
         a.reads = b->d_reads.p; a.read_off = b->d_off.p; a.bad = b->d_bad.p; a.bta = b->d_bta.p; a.col0 = b->d_col0.p;
-        a.nreads = (int)b->nreads; a.gap_open = b->p.gap_open; a.gap_ext = b->p.gap_ext;
+        a.nreads = (int)b->nreads; a.read_base = 0; a.gap_open = b->p.gap_open; a.gap_ext = b->p.gap_ext;
         a.cap_cells = b->cap_cells; a.arena_m = b->d_arena_m.p; a.arena_pw = b->d_arena_pw.p; a.rinfo = b->d_rinfo.p;
         a.rec = b->d_rec.p; a.ops = b->d_ops.p; a.oprows = b->d_oprows.p; a.ops_stride = b->ops_stride;
         a.cells = b->d_cells.p;
@@ -335,14 +383,16 @@ int32_t rg_batch_create(const rg_graph* gc, const rg_params* p, const char* read
     if (!(is_poa(mode) || mode == RG_MODE_PATHWISE || mode == RG_MODE_RECOMBINATION || mode == RG_MODE_PATHWISE_SEMI ||
           mode == RG_MODE_RECOMBINATION_SEMI))
         return fail(RG_ERR_ARG, "unsupported mode");
-    if (mode == RG_MODE_GAP_POA && (p->gap_open > 0 || p->gap_ext > 0)) return fail(RG_ERR_ARG, "gap penalties must be <= 0");
+    if ((mode == RG_MODE_GAP_POA || mode == RG_MODE_GAP_LOCAL_POA) && (p->gap_open > 0 || p->gap_ext > 0))
+        return fail(RG_ERR_ARG, "gap penalties must be <= 0");
     if (is_poa(mode) && !g->h.has_lnz) return fail(RG_ERR_ARG, "graph has no LnzGraph view");
     if (!is_poa(mode) && !g->h.has_path) return fail(RG_ERR_ARG, "graph has no paths (P lines)");
     if ((mode == RG_MODE_RECOMBINATION || mode == RG_MODE_RECOMBINATION_SEMI) && (p->base_rec_cost < 0 || p->multi_rec_cost < 0))
         return fail(RG_ERR_ARG, "recombination costs must be non-negative");
-    if (mode == RG_MODE_GLOBAL_POA && g->h.L >= (1 << 20))
-        return fail(RG_ERR_GRAPH, "m0: rows >= 2^20 break the reference's f32 path-cell decoding (gaf_output.rs:783-786)");
-    if ((mode == RG_MODE_GAP_POA || mode == RG_MODE_GLOBAL_POA_SCALAR) && g->h.L > 65536)
+    if ((mode == RG_MODE_GLOBAL_POA || mode == RG_MODE_LOCAL_POA) && g->h.L >= (1 << 20))
+        return fail(RG_ERR_GRAPH, "rows >= 2^20 break the reference's f32 path-cell decoding (gaf_output.rs:664-668, 783-786)");
+    if ((mode == RG_MODE_GAP_POA || mode == RG_MODE_GLOBAL_POA_SCALAR || mode == RG_MODE_LOCAL_POA_SCALAR ||
+         mode == RG_MODE_GAP_LOCAL_POA) && g->h.L > 65536)
         return fail(RG_ERR_GRAPH, "rows >= 65536 are truncated by the reference's u16 path cells (bitfield_path.rs:41)");
     int rc = upload_graph(g);
     if (rc) return rc;
@@ -451,7 +501,10 @@ int64_t rg_result_gaf(const rg_batch* b, int64_t i, const char* name, int64_t se
         switch (b->p.mode) {
             case RG_MODE_GLOBAL_POA: out = format_m0_simd(b->g->h, read, nm, r); break;
             case RG_MODE_GLOBAL_POA_SCALAR:
-            case RG_MODE_GAP_POA: out = format_poa_banded(b->g->h, read, nm, r); break;
+            case RG_MODE_GAP_POA:
+            case RG_MODE_LOCAL_POA:
+            case RG_MODE_LOCAL_POA_SCALAR:
+            case RG_MODE_GAP_LOCAL_POA: out = format_poa_banded(b->g->h, read, nm, r); break;
             default: out = format_pathwise(b->g->h, read, nm, r, b->p.mode); break;
         }
     } else if ((d.status & (ST_BAD_BASE | ST_WOULD_PANIC)) == 0 && (d.status & ST_BAND_WARNING)) {

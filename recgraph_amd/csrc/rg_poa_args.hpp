@@ -13,6 +13,7 @@ struct PoaArgs {
     const int* bta;            // per read bases_to_add (main.rs:57)
     const int* col0;           // m0: m[i][0] per row (global_abpoa.rs:36-46), depends on scores only
     int nreads;
+    int read_base;             // local modes: first read of this launch (arena slots are launch-relative)
     int gap_open, gap_ext;     // m2
     long long cap_cells;       // arena capacity per read (cells)
     int* arena_m;              // [nreads][cap_cells] (m2: 3 planes)
@@ -28,5 +29,6 @@ struct PoaArgs {
 void launch_m0_simd(const PoaArgs& a, hipStream_t s);
 void launch_m2(const PoaArgs& a, hipStream_t s);
 void launch_m0_scalar(const PoaArgs& a, hipStream_t s);
+void launch_local(const PoaArgs& a, int variant, hipStream_t s);   // 0: -m 1 AVX2 semantics, 1: -m 1 scalar, 2: -m 3
 
 }  // namespace rg

@@ -34,6 +34,71 @@ def test_m2_reference_scores(oracle, v):
     assert not panic and score == v["score"]
 
 
+@pytest.mark.parametrize("v", VEC["local_poa"], ids=lambda v: v["ref"])
+def test_m1_reference_scores(oracle, v):
+    """local_poa.rs:300-378 (the tests call the scalar exec; the AVX2 restatement must agree on them)."""
+    g = oracle.Graph.lnz_literal(v["lnz"], _preds(v["preds"]))
+    for mode in (oracle.M1_SCALAR, oracle.M1_SIMD):
+        out, score, panic, _ = g.align(mode, v["read"], idx=0, scores=_scores(oracle, v["scores"]))
+        assert not panic and score == v["score"]
+
+
+@pytest.mark.parametrize("v", VEC["gap_local_poa"], ids=lambda v: v["ref"])
+def test_m3_reference_scores(oracle, v):
+    """gap_local_poa.rs:186-270."""
+    g = oracle.Graph.lnz_literal(v["lnz"], _preds(v["preds"]))
+    out, score, panic, _ = g.align(oracle.M3, v["read"], idx=0, scores=_scores(oracle, v["scores"]), o=v["o"], e=v["e"])
+    assert not panic and score == v["score"]
+
+
+def _smith_waterman(ref, read, m, x, gap):
+    H = [[0] * (len(read) + 1) for _ in range(len(ref) + 1)]
+    best = 0
+    for i in range(1, len(ref) + 1):
+        for j in range(1, len(read) + 1):
+            s = m if ref[i - 1] == read[j - 1] else x
+            H[i][j] = max(0, H[i - 1][j - 1] + s, H[i - 1][j] + gap, H[i][j - 1] + gap)
+            best = max(best, H[i][j])
+    return best
+
+
+def _gotoh_local(ref, read, m, x, o, e):
+    NEG = -10 ** 9
+    n, w = len(ref), len(read)
+    H = [[0] * (w + 1) for _ in range(n + 1)]
+    X = [[0] * (w + 1) for _ in range(n + 1)]   # the reference keeps 0 on the borders of x / y
+    Y = [[0] * (w + 1) for _ in range(n + 1)]
+    best = 0
+    for i in range(1, n + 1):
+        for j in range(1, w + 1):
+            X[i][j] = max(X[i][j - 1] + e, H[i][j - 1] + o + e)
+            Y[i][j] = max(Y[i - 1][j] + e, H[i - 1][j] + o + e)
+            s = m if ref[i - 1] == read[j - 1] else x
+            H[i][j] = max(0, H[i - 1][j - 1] + s, X[i][j], Y[i][j])
+            best = max(best, H[i][j])
+    return best
+
+
+def test_local_modes_equal_smith_waterman_on_a_chain(oracle):
+    """Independent check: on a single-segment graph local POA is Smith-Waterman (m1) / Gotoh with zero borders (m3)."""
+    rng = np.random.default_rng(5)
+    for t in range(40):
+        ref = "".join("ACGT"[int(k)] for k in rng.integers(0, 4, size=int(rng.integers(2, 40))))
+        read = "".join("ACGT"[int(k)] for k in rng.integers(0, 4, size=int(rng.integers(1, 30))))
+        if t % 2:
+            a = int(rng.integers(0, len(ref) - 1))
+            read = read[:5] + ref[a:a + 12] + read[5:]
+        g = oracle.Graph.from_gfa_text("S\t1\t%s\n" % ref, want_path=False)
+        sc = oracle.scores_match_mis(2, -4)            # i32 variant: gaps cost -8
+        scf = oracle.scores_match_mis(2, -4, True)     # f32 variant: gaps cost -4
+        assert g.align(oracle.M1_SCALAR, read, idx=0, scores=sc)[1] == _smith_waterman(ref, read, 2, -4, -8)
+        # the AVX2 flavour never clamps the scalar tail of a multi-predecessor row (local_poa.rs:128-156; row 1 always is
+        # one), so it is Smith-Waterman only when the read leaves no tail: (n + 1) % 8 == 1
+        r8 = (read * 8)[:max(8, len(read) // 8 * 8)]
+        assert g.align(oracle.M1_SIMD, r8, idx=0, scores=scf)[1] == _smith_waterman(ref, r8, 2, -4, -4)
+        assert g.align(oracle.M3, read, idx=0, scores=sc, o=-4, e=-2)[1] == _gotoh_local(ref, read, 2, -4, -4, -2)
+
+
 def test_m2_with_o0_equals_m0_scalar(oracle):
     """The reference's own cross-check idea (gap_global_abpoa.rs:642): o = 0 and e = gap score."""
     rng = np.random.default_rng(1)
