@@ -65,6 +65,8 @@ typedef struct rg_params {
     int32_t base_rec_cost; /* -R, pathwise_alignment_recombination.rs:29                       */
     float multi_rec_cost;  /* -r                                                              */
     float rec_band_width;  /* -B                                                              */
+    int32_t amb_mode;      /* POA modes, `-s true` retry (main.rs:82-106): bit 0 = node ids of the reversed handle
+                              order (utils.rs:144-165 with amb_mode), bit 1 = strand '-' (gaf_output.rs:225)       */
 } rg_params;
 
 /* Fill *p with the CLI defaults (args_parser.rs:3-147: M=2 X=4 O=4 E=2 R=4 r=0.1 B=1 b=1 f=0.01). */

@@ -45,6 +45,10 @@ def lib():
         l.orc_align.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_char_p, C.c_longlong, C.POINTER(C.c_int),
                                 C.c_int, C.c_int, C.c_longlong, C.c_int, C.c_float, C.c_float, C.c_char_p,
                                 C.c_longlong, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_ulonglong)]
+        l.orc_align_amb.restype = C.c_longlong
+        l.orc_align_amb.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_char_p, C.c_char_p, C.c_longlong, C.POINTER(C.c_int),
+                                    C.c_int, C.c_int, C.c_longlong, C.c_char_p, C.c_longlong, C.POINTER(C.c_int),
+                                    C.POINTER(C.c_int)]
         l.orc_bench.restype = C.c_double
         l.orc_bench.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.POINTER(C.c_longlong), C.c_longlong,
                                 C.POINTER(C.c_int), C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_float,
@@ -148,6 +152,54 @@ class Graph:
                 break
             cap = n + 16
         return buf.value.decode(), score.value, bool(flags.value), cells.value
+
+    def align_amb(self, mode, amb, read, name="read", idx=1, scores=None, o=-4, e=-2, bta=0):
+        """POA modes with the handle table / strand of `-s true` (amb bit 0: reversed handles, bit 1: strand '-')."""
+        if scores is None:
+            scores = scores_match_mis(2, -4)
+        sc = (C.c_int * 36)(*scores)
+        score = C.c_int(0)
+        flags = C.c_int(0)
+        cap = 1 << 16
+        while True:
+            buf = C.create_string_buffer(cap)
+            n = lib().orc_align_amb(self.h, mode, amb, read.encode(), name.encode(), idx, sc, o, e, bta, buf, cap,
+                                    C.byref(score), C.byref(flags))
+            if n + 1 <= cap:
+                break
+            cap = n + 16
+        return buf.value.decode(), score.value, bool(flags.value)
+
+    def main_rs_amb_strand(self, m, read, name, idx, scores=None, o=-4, e=-2, b=1.0, f=0.01, avx2=True):
+        """What main.rs prints for one read under `-s true`, modes 0-3 (main.rs:47-253).  Returns stdout text."""
+        import numpy as np
+        bta = int(np.float32(b) + np.float32(f) * np.float32(len(read) + 1))
+        comp = {"A": "T", "C": "G", "G": "C", "T": "A", "N": "N"}
+        rc = "".join(comp[c] for c in reversed(read.upper().replace("-", "N")))   # sequences.rs:65-82
+        def pick(fwd, rev, take_rev):
+            # warnings are printed inside exec (both runs, in order); write_gaf then prints the chosen record
+            fl, rl = fwd[0].splitlines(True), rev[0].splitlines(True)
+            return "".join(fl[:-1]) + "".join(rl[:-1]) + (rl[-1] if take_rev else fl[-1])
+
+        if m in (0, 2):
+            fmode = (M0_SIMD if avx2 else M0_SCALAR) if m == 0 else M2
+            rmode = M0_SCALAR if m == 0 else M2          # main.rs:88: the retry always uses the scalar exec
+            fwd = self.align_amb(fmode, 0, read, name, idx, scores, o, e, bta)
+            if fwd[1] < 0:
+                rev = self.align_amb(rmode, 3, rc, name, idx, scores, o, e, bta)
+                assert not rev[2]
+                return pick(fwd, rev, rev[1] > fwd[1])
+            return fwd[0]
+        if m == 1:
+            mode = M1_SIMD if avx2 else M1_SCALAR
+            fwd = self.align_amb(mode, 0, read, name, idx, scores, o, e, bta)
+            rev = self.align_amb(mode, 3, rc, name, idx, scores, o, e, bta)
+            return pick(fwd, rev, not (fwd[1] < rev[1]))    # main.rs:160-164 (sic)
+        if m == 3:
+            fwd = self.align_amb(M3, 0, read, name, idx, scores, o, e, bta)
+            rev = self.align_amb(M3, 1, rc, name, idx, scores, o, e, bta)   # amb_mode = false, reversed handles (:240)
+            return pick(fwd, rev, rev[1] > fwd[1])
+        raise ValueError(m)
 
     def bench(self, mode, reads, scores=None, o=-4, e=-2, b=1.0, f=0.01, R=4, r=0.1, B=1.0, nthreads=1):
         """Time `reads` (list of str) on `nthreads` host threads.  Returns (seconds, cells, checksum)."""

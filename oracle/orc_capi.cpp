@@ -152,6 +152,27 @@ static Result run_one(OrcGraph* g, int mode, const std::string& read_dollar, con
     }
 }
 
+// `-s true` support (main.rs:82-106, 132-165, 188-212, 229-253): the reference aligns the reverse complement of the
+// read against the SAME LnzGraph, with the handle table of the reversed handle order and (modes 0-2) strand '-'.
+// amb bit 0: use hofp_rev; bit 1: strand '-'.  sequences.rs:65-82 rev_and_compl is applied by the caller.
+long long orc_align_amb(void* h, int mode, int amb, const char* read, const char* name, long long idx, const int* scores36,
+                        int o, int e, long long bta, char* out, long long cap, int* score, int* flags) {
+    auto* g = (OrcGraph*)h;
+    std::string rd = "$";
+    for (const char* p = read; *p; ++p) rd += (*p == '-') ? 'N' : (char)std::toupper(*p);
+    Scores sc = scores_from(scores36);
+    OrcGraph view;
+    view.lnz = g->lnz;
+    view.r_values = g->r_values;
+    if ((amb & 1) && !g->lnz.hofp_rev.empty()) view.lnz.hofp = g->lnz.hofp_rev;
+    view.lnz.strand = (amb & 2) ? '-' : '+';
+    uint64_t c = 0;
+    Result r = run_one(&view, mode, rd, name, (size_t)idx, sc, o, e, (size_t)bta, 0, 0.f, 0.f, &c);
+    if (score) *score = r.score;
+    if (flags) *flags = r.would_panic ? 1 : 0;
+    return put(r.out, out, cap);
+}
+
 // One read (bases without the '$'; sequences.rs:48-61 build_align_string is applied here).
 // idx is seq_name.1 of the reference (0 = score only).  Returns the length of the stdout text.
 long long orc_align(void* h, int mode, const char* read, const char* name, long long idx, const int* scores36,

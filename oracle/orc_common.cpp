@@ -158,6 +158,15 @@ LnzGraph create_graph_struct(const Gfa& g) {
         out.hofp[i] = std::to_string(sorted[(size_t)(curr - 1)]);
     }
     out.hofp[0] = "-1";
+    // create_handle_pos_in_lnz(.., amb_mode = true): same nwp walk over the handles reversed (and flipped: same id)
+    std::vector<uint64_t> rsorted(sorted.rbegin(), sorted.rend());
+    out.hofp_rev.assign(lin.size() - 1, "");
+    curr = 0;
+    for (size_t i = 1; i + 1 < lin.size(); ++i) {
+        if (out.nwp[i]) curr += 1;
+        out.hofp_rev[i] = std::to_string(rsorted[(size_t)(curr - 1)]);
+    }
+    out.hofp_rev[0] = "-1";
     return out;
 }
 

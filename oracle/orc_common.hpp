@@ -82,6 +82,8 @@ struct LnzGraph {
     std::vector<uint8_t> nwp;                        // size L
     std::map<size_t, std::vector<size_t>> pred_hash;  // row -> preds (stored order)
     std::vector<std::string> hofp;                   // utils.rs:144-165, rows 0..L-2
+    std::vector<std::string> hofp_rev;               // same with amb_mode = true (graph.rs:128-142: handles reversed)
+    char strand = '+';                               // `if amb_mode { '-' } else { '+' }` of the GAF walkers
 };
 LnzGraph create_graph_struct(const Gfa& g);  // src/graph.rs:31-123 (amb_mode=false)
 

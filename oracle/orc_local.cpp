@@ -50,7 +50,7 @@ bool finish_gaf(Result& res, const LnzGraph& g, const std::string& name, size_t 
     gaf.query_length = W - 1;
     gaf.query_start = col;
     gaf.query_end = last_col;
-    gaf.strand = '+';
+    gaf.strand = g.strand;
     gaf.path.clear();
     for (auto* s : dd) {
         if ((*s)[0] == '-') return false;  // "-1".parse::<usize>() fails

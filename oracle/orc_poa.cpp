@@ -219,7 +219,7 @@ Result m0_simd(const std::string& read, const std::string& name, size_t idx, con
     gaf.query_length = W - 1;
     gaf.query_start = col;
     gaf.query_end = last_col;
-    gaf.strand = '+';
+    gaf.strand = g.strand;
     gaf.path.clear();
     for (auto* s : dd) gaf.path.push_back(std::stoull(*s));
     gaf.path_length = path_length;
@@ -428,7 +428,7 @@ Result m0_scalar(const std::string& seq, const std::string& name, size_t idx, co
     gaf.query_length = W - 1;
     gaf.query_start = col;
     gaf.query_end = last_col + ampl[last_row].first;
-    gaf.strand = '+';
+    gaf.strand = g.strand;
     gaf.path.clear();
     for (auto* s : dd) {
         if ((*s)[0] == '-') { res.would_panic = true; return res; }
@@ -672,7 +672,7 @@ Result m2_gap(const std::string& seq, const std::string& name, size_t idx, const
     gaf.query_length = W - 1;
     gaf.query_start = col;
     gaf.query_end = last_col + ampl[last_row].first;
-    gaf.strand = '+';
+    gaf.strand = g.strand;
     gaf.path.clear();
     for (auto* s : dd) {
         if ((*s)[0] == '-') { res.would_panic = true; return res; }

@@ -16,7 +16,8 @@ class RecGraphError(RuntimeError):
 class Params(C.Structure):
     _fields_ = [("mode", C.c_int32), ("scores", C.c_int32 * 36), ("gap_open", C.c_int32), ("gap_ext", C.c_int32),
                 ("band_b", C.c_float), ("band_f", C.c_float), ("bta_override", C.c_int64),
-                ("base_rec_cost", C.c_int32), ("multi_rec_cost", C.c_float), ("rec_band_width", C.c_float)]
+                ("base_rec_cost", C.c_int32), ("multi_rec_cost", C.c_float), ("rec_band_width", C.c_float),
+                ("amb_mode", C.c_int32)]
 
 
 def library_path():

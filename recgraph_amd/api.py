@@ -183,7 +183,7 @@ class Graph:
         return buf.value.decode()
 
 
-def make_params(mode, score_matrix=None, o=None, e=None, b=None, f=None, bta=None, R=None, r=None, B=None):
+def make_params(mode, score_matrix=None, o=None, e=None, b=None, f=None, bta=None, R=None, r=None, B=None, amb=None):
     p = Params()
     _lib.load().rg_params_default(C.byref(p), mode)
     if score_matrix is not None:
@@ -206,6 +206,8 @@ def make_params(mode, score_matrix=None, o=None, e=None, b=None, f=None, bta=Non
         p.multi_rec_cost = r
     if B is not None:
         p.rec_band_width = B
+    if amb is not None:
+        p.amb_mode = amb
     return p
 
 
@@ -271,16 +273,59 @@ class Batch:
                 for k in range(lib.rg_batch_kernel_count(self._h))}
 
 
-def align_batch(graph, reads, names=None, mode=MODE_GLOBAL_POA, seq_index_base=1, **kw):
+_COMPLEMENT = {"A": "T", "C": "G", "G": "C", "T": "A", "N": "N"}
+
+
+def rev_and_compl(read):
+    """sequences::rev_and_compl (sequences.rs:65-82) on a read without its '$'."""
+    try:
+        return "".join(_COMPLEMENT[c] for c in reversed(read))
+    except KeyError as ex:
+        raise _lib.RecGraphError(-1, "wrong char: %s, unable to rev&compl" % ex.args[0])
+
+
+def align_batch(graph, reads, names=None, mode=MODE_GLOBAL_POA, seq_index_base=1, amb_strand=False, **kw):
     """The reference's per-read loop as one device batch.  Returns, per read, exactly the text the
-    reference prints on stdout (warning lines + GAF line), and the per-read status bits."""
+    reference prints on stdout (warning lines + GAF line), and the per-read status bits.
+
+    ``amb_strand`` is ``-s true`` (main.rs:82-106, 132-165, 188-212, 229-253; POA modes only): a second batch aligns
+    the reverse complement of the reads that qualify against the same graph, labelled with the reversed handle order,
+    and the reference's per-mode comparison picks which record is written."""
     p = make_params(mode, **kw)
     b = Batch(graph, reads, p)
     b.run()
     b.fetch()
-    names = names or ["read%d" % i for i in range(len(reads))]
-    return [b.gaf_text(i, names[i], seq_index_base + i) for i in range(len(reads))], [b.status(i) for i in
-                                                                                      range(len(reads))]
+    n = len(reads)
+    names = names or ["read%d" % i for i in range(n)]
+    texts = [b.gaf_text(i, names[i], seq_index_base + i) for i in range(n)]
+    status = [b.status(i) for i in range(n)]
+    poa_global = (MODE_GLOBAL_POA, MODE_GLOBAL_POA_SCALAR, MODE_GAP_POA)
+    poa_local = (MODE_LOCAL_POA, MODE_LOCAL_POA_SCALAR, MODE_GAP_LOCAL_POA)
+    if not amb_strand or mode not in poa_global + poa_local:
+        return texts, status
+    ok = [i for i in range(n) if not status[i] & (READ_WOULD_PANIC | READ_BAD_BASE)]
+    sel = [i for i in ok if mode in poa_local or b.score(i) < 0]          # main.rs:82,188 `alignment.0 < 0`
+    if not sel:
+        return texts, status
+    rmode = MODE_GLOBAL_POA_SCALAR if mode == MODE_GLOBAL_POA else mode    # main.rs:88: the retry uses the scalar exec
+    amb = 1 if mode == MODE_GAP_LOCAL_POA else 3                           # main.rs:240 passes amb_mode = false
+    canon = ["".join("N" if c == "-" else c.upper() for c in reads[i]) for i in sel]   # sequences.rs:13-22
+    rb = Batch(graph, [rev_and_compl(r) for r in canon], make_params(rmode, amb=amb, **kw))
+    rb.run()
+    rb.fetch()
+    for k, i in enumerate(sel):
+        if rb.status(k) & (READ_WOULD_PANIC | READ_BAD_BASE):
+            status[i] |= rb.status(k) & (READ_WOULD_PANIC | READ_BAD_BASE)
+            continue
+        fl = texts[i].splitlines(True)
+        rl = rb.gaf_text(k, names[i], seq_index_base + i).splitlines(True)
+        if mode in (MODE_LOCAL_POA, MODE_LOCAL_POA_SCALAR):
+            take_rev = not (b.score(i) < rb.score(k))                      # main.rs:160-164 (sic)
+        else:
+            take_rev = rb.score(k) > b.score(i)
+        # warning lines are printed while the two exec calls run; write_gaf then prints the chosen record
+        texts[i] = "".join(fl[:-1]) + "".join(rl[:-1]) + (rl[-1] if take_rev else fl[-1])
+    return texts, status
 
 
 def _single(graph, read, name, mode, seq_index=1, **kw):

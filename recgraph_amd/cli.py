@@ -57,8 +57,7 @@ def main(argv=None):
     from . import api
     if a.alignment_mode not in (0, 1, 2, 3, 4, 5, 8, 9):
         raise SystemExit("Alignment mode must be in [0..5] or [8, 9]")   # main.rs:315-317
-    if a.amb_strand == "true":
-        raise SystemExit("-s true (reverse strand retry) is outside the accelerated path")
+    amb = a.amb_strand == "true" and a.alignment_mode in (0, 1, 2, 3)     # modes 4+ ignore -s (main.rs:254-313)
     if a.matrix in ("none",):
         scores = api.create_score_matrix_i32(a.match_score, -a.mismatch_score)   # args_parser.rs:155
     else:
@@ -71,7 +70,7 @@ def main(argv=None):
             9: api.MODE_RECOMBINATION_SEMI}[a.alignment_mode]
     texts, status = api.align_batch(g, seqs, names, mode=mode, score_matrix=scores, o=-a.gap_open, e=-a.gap_extension,
                                     b=float(a.extra_b), f=a.extra_f, R=a.base_rec_cost, r=a.multi_rec_cost,
-                                    B=a.rec_band_width)
+                                    B=a.rec_band_width, amb_strand=amb)
     for i, st in enumerate(status):
         if st & (api.READ_WOULD_PANIC | api.READ_BAD_BASE):
             raise SystemExit("read %d (%s): the reference panics on this input" % (i, names[i]))

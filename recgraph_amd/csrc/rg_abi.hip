@@ -394,6 +394,9 @@ int32_t rg_batch_create(const rg_graph* gc, const rg_params* p, const char* read
     if ((mode == RG_MODE_GAP_POA || mode == RG_MODE_GLOBAL_POA_SCALAR || mode == RG_MODE_LOCAL_POA_SCALAR ||
          mode == RG_MODE_GAP_LOCAL_POA) && g->h.L > 65536)
         return fail(RG_ERR_GRAPH, "rows >= 65536 are truncated by the reference's u16 path cells (bitfield_path.rs:41)");
+    if (p->amb_mode & ~3) return fail(RG_ERR_ARG, "amb_mode: only bits 0 and 1 are defined");
+    if (p->amb_mode && !is_poa(mode)) return fail(RG_ERR_ARG, "amb_mode applies to the POA modes only (main.rs:82,132,188,229)");
+    if (p->amb_mode & 1) build_rev_ids(g->h);
     int rc = upload_graph(g);
     if (rc) return rc;
     auto b = std::make_unique<rg_batch>();
@@ -499,12 +502,12 @@ int64_t rg_result_gaf(const rg_batch* b, int64_t i, const char* name, int64_t se
         std::string read = b->reads.substr((size_t)b->off[i], (size_t)(b->off[i + 1] - b->off[i]));
         std::string nm = name ? name : "";
         switch (b->p.mode) {
-            case RG_MODE_GLOBAL_POA: out = format_m0_simd(b->g->h, read, nm, r); break;
+            case RG_MODE_GLOBAL_POA: out = format_m0_simd(b->g->h, read, nm, r, b->p.amb_mode); break;
             case RG_MODE_GLOBAL_POA_SCALAR:
             case RG_MODE_GAP_POA:
             case RG_MODE_LOCAL_POA:
             case RG_MODE_LOCAL_POA_SCALAR:
-            case RG_MODE_GAP_LOCAL_POA: out = format_poa_banded(b->g->h, read, nm, r); break;
+            case RG_MODE_GAP_LOCAL_POA: out = format_poa_banded(b->g->h, read, nm, r, b->p.amb_mode); break;
             default: out = format_pathwise(b->g->h, read, nm, r, b->p.mode); break;
         }
     } else if ((d.status & (ST_BAD_BASE | ST_WOULD_PANIC)) == 0 && (d.status & ST_BAND_WARNING)) {

@@ -104,8 +104,24 @@ int step_on_path(const HostGraph& g, int row, int path, bool fwd) {
 }  // namespace
 
 // ---------------------------------------------------------------------------------
+// node ids per row under `-s true`: the k-th node in row order is labelled with the id of the k-th node from the end
+// (create_handle_pos_in_lnz over the reversed handle list, utils.rs:144-165 + graph.rs:128-142)
+void build_rev_ids(HostGraph& g) {
+    if (!g.node_id_rev.empty()) return;
+    std::vector<uint64_t> runs;
+    for (int i = 1; i + 1 < g.L; ++i)
+        if (i == 1 || g.seg_off[i] == 1) runs.push_back(g.node_id[i]);
+    g.node_id_rev.assign(g.L, 0);
+    size_t k = 0;
+    for (int i = 1; i + 1 < g.L; ++i) {
+        if (i > 1 && g.seg_off[i] == 1) ++k;
+        g.node_id_rev[i] = runs[runs.size() - 1 - k];
+    }
+}
+
 std::string format_m0_simd(const HostGraph& g, const std::string& read, const std::string& name,
-                           const ReadRecord& r) {
+                           const ReadRecord& r, int amb) {
+    const std::vector<uint64_t>& nid = (amb & 1) ? g.node_id_rev : g.node_id;
     if (r.status & RG_READ_BAND_NOT_ENOUGH) return std::string("band not enough for correct output\n") + kEmptyGaf + "\n";
     int row = r.end_row, col = r.end_col;
     std::string ops, pseq;
@@ -114,12 +130,12 @@ std::string format_m0_simd(const HostGraph& g, const std::string& read, const st
     for (int k = 0; k < r.n_ops; ++k) {
         uint8_t op = r.ops[k] & 0x7f;
         if (op == OP_D) {
-            ids.push_back(g.node_id[row]); pseq.push_back(g.lnz[row]);
+            ids.push_back(nid[row]); pseq.push_back(g.lnz[row]);
             row = r.rows[k]; col -= 1;
             ops.push_back(g.lnz[row] == read_at(read, col) ? 'D' : 'd');   // tested on the destination cell
             ++plen; ++residues;
         } else if (op == OP_U) {
-            ids.push_back(g.node_id[row]); pseq.push_back(g.lnz[row]);
+            ids.push_back(nid[row]); pseq.push_back(g.lnz[row]);
             row = r.rows[k];
             ops.push_back('U'); ++plen;
         } else { col -= 1; ops.push_back('L'); }
@@ -130,6 +146,7 @@ std::string format_m0_simd(const HostGraph& g, const std::string& read, const st
     std::reverse(ids.begin(), ids.end());
     Fields f;
     f.name = name; f.qlen = read.size(); f.qstart = (size_t)col; f.qend = (size_t)r.end_col;
+    f.strand = (amb & 2) ? '-' : '+';
     f.path = ids; f.plen = plen;
     f.pstart = (size_t)g.seg_off[row];          // node_start (gaf_output.rs:867-874)
     f.pend = (size_t)g.seg_off[r.end_row];
@@ -142,7 +159,8 @@ std::string format_m0_simd(const HostGraph& g, const std::string& read, const st
 // m0 scalar and m2: per-segment cigar strings (gaf_output.rs:96-381).  Ops flagged OP_CONT were
 // produced inside an X/Y run of the m2 walker, which does not re-check segment/direction changes.
 std::string format_poa_banded(const HostGraph& g, const std::string& read, const std::string& name,
-                              const ReadRecord& r) {
+                              const ReadRecord& r, int amb) {
+    const std::vector<uint64_t>& nid = (amb & 1) ? g.node_id_rev : g.node_id;
     std::string out;
     if (r.status & RG_READ_BAND_WARNING) out += "Band length probably too short, maybe try with larger b and f\n";
     int row = r.end_row;
@@ -168,7 +186,7 @@ std::string format_poa_banded(const HostGraph& g, const std::string& read, const
         const bool mismatch = raw & 0x40;
         if (!cont) {
             bool is_root = row == 0;
-            uint64_t h = g.node_id[row];
+            uint64_t h = nid[row];
             if (!have_handle || is_root != curr_is_root || h != curr_handle) {
                 flush();
                 cigars.push_back(cigar);
@@ -180,10 +198,10 @@ std::string format_poa_banded(const HostGraph& g, const std::string& read, const
             last_dir = d;
         }
         if (op == OP_D) {
-            ids.push_back(g.node_id[row]); row = r.rows[k]; cm += 1; ++plen;
+            ids.push_back(nid[row]); row = r.rows[k]; cm += 1; ++plen;
             if (!mismatch) ++residues;
         } else if (op == OP_U) {
-            ids.push_back(g.node_id[row]); row = r.rows[k]; ci += 1; ++plen;
+            ids.push_back(nid[row]); row = r.rows[k]; ci += 1; ++plen;
         } else cd += 1;
     }
     flush();
@@ -192,6 +210,7 @@ std::string format_poa_banded(const HostGraph& g, const std::string& read, const
     std::reverse(ids.begin(), ids.end());
     Fields f;
     f.name = name; f.qlen = read.size(); f.qstart = (size_t)r.stop_col; f.qend = (size_t)r.end_col;
+    f.strand = (amb & 2) ? '-' : '+';
     f.path = ids; f.plen = plen;
     f.pstart = (size_t)g.seg_off[row];
     f.pend = (size_t)g.seg_off[r.end_row];

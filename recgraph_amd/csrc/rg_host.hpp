@@ -31,6 +31,7 @@ struct HostGraph {
     std::string lnz;
     std::vector<uint64_t> node_id;    // segment id per row, 0 for rows 0 and L-1
     std::vector<int32_t> seg_off;     // 1-based offset of the row inside its segment (0 for row 0 / F)
+    std::vector<uint64_t> node_id_rev; // `-s true`: id per row when the handle order is reversed (utils.rs:144-165, amb_mode)
 
     // ---- LnzGraph view (m0/m2) ----
     bool has_lnz = false;
@@ -83,9 +84,12 @@ struct ReadRecord {
 };
 
 // GAF text exactly as the reference prints it
-std::string format_m0_simd(const HostGraph& g, const std::string& read, const std::string& name, const ReadRecord& r);
+// amb: rg_params.amb_mode (bit 0 reversed handle ids, bit 1 strand '-')
+std::string format_m0_simd(const HostGraph& g, const std::string& read, const std::string& name, const ReadRecord& r,
+                           int amb = 0);
 std::string format_poa_banded(const HostGraph& g, const std::string& read, const std::string& name,
-                              const ReadRecord& r);
+                              const ReadRecord& r, int amb = 0);
+void build_rev_ids(HostGraph& g);
 std::string format_pathwise(const HostGraph& g, const std::string& read, const std::string& name,
                             const ReadRecord& r, int mode);
 std::string f32_display(float v);
