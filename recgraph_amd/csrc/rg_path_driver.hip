@@ -133,8 +133,13 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
     // so it is not the default.
     const bool use_reg = C <= 16 && getenv("RG_SWEEP_REG") != nullptr;
     if (use_reg) lds = true;   // no HBM rolling-row buffer needed
+    // packed 16-bit rows (rg_sweep16.hip) whenever the scores of this batch provably fit; RG_SWEEP_I32=1 forces k_sweep
+    DevScores dsc;
+    for (int i = 0; i < 36; ++i) dsc.t[i] = p.scores[i];
+    const bool use16 = !lds && !use_reg && !getenv("RG_SWEEP_I32") && sweep16_admissible(dsc, h.max_path_rows, max_n, C);
     auto sweep = [&](const SweepArgs& sa_, int nr) {
         if (use_reg) launch_sweep_reg(sa_, nr, C, stream);
+        else if (use16) launch_sweep16(sa_, nr, C, stream);
         else launch_sweep(sa_, nr, C, lds, stream);
     };
     int rc;

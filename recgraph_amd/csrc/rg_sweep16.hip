@@ -1,0 +1,444 @@
+// Packed 16-bit DP sweep for gfx950 (-m 4 / -m 5 / -m 8 / -m 9): k_sweep of rg_pathwise.hip with two DP columns per
+// 32-bit register (v_pk_add_i16 / v_pk_max_i16 / v_bfi_b32), selected by the driver when every absolute score of
+// the batch provably fits 16 bits and the read-gap cost is uniform (every matrix the reference's CLI can build).
+//
+// Why: the i32 sweep is bound by the rolling rows (one row store + one row load per member-path update; at config 5
+// the resident set of one launch, 2048 reads x 32 paths x 1024 columns x 4 B = 268 MB, does not fit the 256 MB
+// Infinity Cache and streams through HBM) and by VALU work.  Packing halves the bytes (134 MB: cache resident) and
+// roughly halves the VALU instructions per cell.
+//
+// Layout: lane t owns columns t*C .. t*C+C-1 as in k_sweep; register r of a row (r < H = C/2) holds column
+// t*C + r in its low half and column t*C + H + r in its high half, so the lane-local serial recurrences run as TWO
+// independent chains per instruction (low halves: columns 0..H-1 of the lane, high halves: H..C-1); the chains are
+// stitched with 32-bit per-lane arithmetic (a dozen instructions per row update) and one wave-level DPP prefix max
+// exactly like the i32 kernel.  Rows in HBM are [path][r][lane] packed words.
+//
+// Outputs (direction words, column maxima + arguments, candidates, sink values, semiglobal end rows) are
+// bit-identical to k_sweep's: everything downstream is shared.
+#include <algorithm>
+
+#include "rg_path_kernels.hpp"
+
+namespace rg {
+
+namespace {
+
+constexpr int NEG32 = INT32_MIN / 4;
+constexpr int NEG16 = -30000;                               // "minus infinity" of a 16-bit lane; real values stay > -24000
+constexpr int NEGPAIR = (int)(((unsigned)(NEG16 & 0xffff) << 16) | (unsigned)(NEG16 & 0xffff));
+constexpr int ONE2 = 0x00010001;
+
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ int pk_add(int a, int b) {
+    return __builtin_bit_cast(int, (s16x2)(__builtin_bit_cast(s16x2, a) + __builtin_bit_cast(s16x2, b)));
+}
+__device__ __forceinline__ int pk_sub(int a, int b) {
+    return __builtin_bit_cast(int, (s16x2)(__builtin_bit_cast(s16x2, a) - __builtin_bit_cast(s16x2, b)));
+}
+__device__ __forceinline__ int pk_max(int a, int b) {
+    return __builtin_bit_cast(int, __builtin_elementwise_max(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b)));
+}
+__device__ __forceinline__ int pk_minu(int a, int b) {
+    return __builtin_bit_cast(int, __builtin_elementwise_min(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
+}
+__device__ __forceinline__ int pack16(int lo, int hi) { return (int)(((unsigned)hi << 16) | ((unsigned)lo & 0xffffu)); }
+__device__ __forceinline__ int lo16(int v) { return (int)(short)(v & 0xffff); }
+__device__ __forceinline__ int hi16(int v) { return v >> 16; }
+// per half: mask ? a : b   (mask halves are 0 or 0xffff)
+__device__ __forceinline__ int bfi(int mask, int a, int b) { return (mask & a) | (~mask & b); }
+
+// Row operators on packed rows.  MU / ML: per register, 0xffff in the halves whose column took U (not D) / L.
+template <int C>
+struct RowOps16 {
+    static constexpr int H = C / 2;
+    // bit r = column r of the lane (low half), bit 16 + r = column H + r (high half)
+    static constexpr unsigned FULL = H >= 16 ? 0xffffffffu : ((((1u << H) - 1u) << 16) | ((1u << H) - 1u));
+
+    static __device__ __forceinline__ void alpha(int (&row)[H], const int (&s)[H], int g, int g_i, int g0, int lane,
+                                                 int (&MU)[H], int (&ML)[H], unsigned& umask, unsigned& lmask, int& src) {
+        const int G2 = pack16(g, g);
+        const int GI = pack16(g_i, g_i);
+        const int GI0 = lane == 0 ? pack16(g0, g_i) : GI;          // border column 0 adds g0
+        int prev = __builtin_amdgcn_alignbit(row[H - 1], dpp_shr1(row[H - 1], NEGPAIR), 16);
+        int run = NEGPAIR;
+        unsigned um = 0;
+#pragma unroll
+        for (int r = 0; r < H; ++r) {
+            const int old = row[r];
+            const int d = pk_add(prev, s[r]), u = pk_add(old, r == 0 ? GI0 : GI);
+            const int du = pk_max(d, u);                            // D on ties (d >= u); lane 0 column 0: d = -inf -> U
+            const int nd = pk_minu(du ^ d, ONE2);                   // 1 where U
+            um |= (unsigned)nd << r;
+            MU[r] = pk_sub(0, nd);
+            run = pk_max(du, pk_add(run, G2));                      // chain without carry-in, for the totals
+            row[r] = du;
+            prev = old;
+        }
+        // stitch: value at the lane's last column reachable from sources inside the lane, in z-space (v - c*g)
+        const int TL = lo16(run), TH = hi16(run);
+        const int E = max(TH, TL + H * g);
+        const int z = E - (lane * C + C - 1) * g;
+        const int ze = dpp_shr1(dpp_incl_max(z, NEG32), NEG32);     // best source of the lanes to the left
+        const int bl = max(ze + (lane * C - 1) * g, NEG16);         // value "at column lane*C - 1"
+        const int bh = max(max(TL, bl + H * g), NEG16);             // value at column lane*C + H - 1
+        int vprev = pack16(bl, bh);
+        unsigned lm = 0;
+#pragma unroll
+        for (int r = 0; r < H; ++r) {
+            const int du = row[r];
+            const int v = pk_max(du, pk_add(vprev, G2));
+            const int nl = pk_minu(v ^ du, ONE2);                   // 1 where L (left strictly better)
+            lm |= (unsigned)nl << r;
+            ML[r] = pk_sub(0, nl);
+            row[r] = v;
+            vprev = v;
+        }
+        src = dpp_shr1(dpp_incl_max((lm & FULL) != FULL ? lane : -1, -1), 0);
+        umask = um; lmask = lm;
+    }
+
+    static __device__ __forceinline__ void member(int (&row)[H], const int (&s)[H], int g, int g_i, int g0, int lane,
+                                                  const int (&MU)[H], const int (&ML)[H], unsigned lmask, int src) {
+        const int G2 = pack16(g, g);
+        const int GI = pack16(g_i, g_i);
+        const int GI0 = lane == 0 ? pack16(g0, g_i) : GI;
+        int prev = __builtin_amdgcn_alignbit(row[H - 1], dpp_shr1(row[H - 1], NEGPAIR), 16);
+        int lastv = NEGPAIR;                                        // base of the last non-L column of each half
+#pragma unroll
+        for (int r = 0; r < H; ++r) {
+            const int old = row[r];
+            const int base = bfi(MU[r], pk_add(old, r == 0 ? GI0 : GI), pk_add(prev, s[r]));
+            row[r] = base;
+            lastv = bfi(ML[r], lastv, base);
+            prev = old;
+        }
+        // z-value of the lane's last non-L column, fetched by the lanes to the right that start with L columns
+        const unsigned nl = ~lmask & FULL;
+        const unsigned nl_lo = nl & 0xffffu, nl_hi = nl >> 16;
+        const int p_lo = 31 - __clz((int)(nl_lo | 1u)), p_hi = 31 - __clz((int)(nl_hi | 1u));
+        const int v_lo = lo16(lastv), v_hi = hi16(lastv);
+        int zl = NEG32;
+        if (nl_lo) zl = v_lo - (lane * C + p_lo) * g;
+        if (nl_hi) zl = v_hi - (lane * C + H + p_hi) * g;
+        const int cur = __shfl(zl, src, WAVE);
+        const int bl = max(cur + (lane * C - 1) * g, NEG16);
+        const int bh = max(nl_lo ? v_lo + (H - 1 - p_lo) * g : bl + H * g, NEG16);
+        int vprev = pack16(bl, bh);
+#pragma unroll
+        for (int r = 0; r < H; ++r) {
+            const int v = bfi(ML[r], pk_add(vprev, G2), row[r]);
+            row[r] = v;
+            vprev = v;
+        }
+    }
+};
+
+// spread the low 16 bits of x to the even bit positions
+__device__ __forceinline__ uint32_t spread16(uint32_t x) {
+    x &= 0xffffu;
+    x = (x | (x << 8)) & 0x00ff00ffu;
+    x = (x | (x << 4)) & 0x0f0f0f0fu;
+    x = (x | (x << 2)) & 0x33333333u;
+    x = (x | (x << 1)) & 0x55555555u;
+    return x;
+}
+
+}  // namespace
+
+template <int C>
+__global__ __launch_bounds__(64, 2) void k_sweep16(SweepArgs a) {
+    constexpr int H = C / 2;
+    const int rd = blockIdx.x;
+    const int lane = threadIdx.x;
+    const PathGraphDev& g = a.g;
+    const int P = g.P;
+    const int wpad = C * WAVE;          // columns per read (i32 side buffers)
+    const int wrow = H * WAVE;          // packed words per rolling row
+    ReadState* rs = a.state + rd;
+    const long long ro = a.read_off[rd];
+    const int n = __builtin_amdgcn_readfirstlane((int)(a.read_off[rd + 1] - ro));
+    if (a.bad[rd] || n + 1 > wpad) {
+        if (lane == 0 && !a.rev) { rs->status = a.bad[rd] ? ST_BAD_BASE : ST_WOULD_PANIC; }
+        return;
+    }
+    const uint8_t* read = a.reads + ro - 1;  // read[1..n]
+    const bool rev = a.rev;
+    const int ncols = rev ? n : n + 1;
+    const int GAP = 5;
+    extern __shared__ __attribute__((aligned(16))) int lds16[];
+    int* sct = lds16;                    // [36] score table
+    int* endv = lds16 + 64;              // [64]
+    int* endr = lds16 + 128;             // [64]
+    int* s2 = lds16 + 192;               // [5][64] packed score pairs: s2[li*64 + (code_lo | code_hi << 3)]
+    if (lane < 36) sct[lane] = a.sc.t[lane];
+    __syncthreads();
+    for (int e = lane; e < 5 * 64; e += WAVE) {
+        const int li = e >> 6, cl = e & 7, ch = (e >> 3) & 7;
+        s2[e] = (cl < 6 && ch < 6) ? pack16(sct[li * 6 + cl], sct[li * 6 + ch]) : 0;
+    }
+    int* rows = a.roll + (long long)rd * P * wrow;
+    const int gcost = sct[GAP];          // uniform read-gap cost (checked by the launcher)
+    // per-column constants of this lane
+    unsigned long long pcode[(H + 7) / 8] = {};   // 8 bits per register: code_lo | code_hi << 3
+    int thr[C];
+    unsigned cvalid = 0;                 // RowOps16 bit layout: columns of this lane that exist
+    const int oob = max((int)((float)(n + 1) * (1.0f - a.rbw) / 2.0f), 1);
+    {
+#pragma unroll
+        for (int q = 0; q < C; ++q) {
+            const int c = lane * C + q;
+            int code = 4;
+            if (c >= 1 && c < ncols) code = rev ? read[n - c + 1] : read[c];
+            const int r = q % H, hi = q / H;
+            pcode[r / 8] |= (unsigned long long)code << (8 * (r % 8) + 3 * hi);
+            if (c < ncols) cvalid |= 1u << (r + 16 * hi);
+            const int j = rev ? n - c : c;
+            thr[q] = INT32_MAX;
+            if (c < ncols && j >= oob && j < n + 1 - oob) {
+                if (a.thr) thr[q] = a.thr[(long long)rd * wpad + j];
+                else if (a.lb) thr[q] = a.lb[rd] + a.brc - (n - j) * a.maxmatch;
+            }
+        }
+        // start rows: the gap-only row, identical for every path (uniform gap cost: c * gcost)
+        for (int k = 0; k < P; ++k) {
+#pragma unroll
+            for (int r = 0; r < H; ++r) {
+                const int c0 = lane * C + r, c1 = c0 + H;
+                rows[(long long)k * wrow + r * WAVE + lane] = pack16(c0 < ncols ? c0 * gcost : NEG16, c1 < ncols ? c1 * gcost : NEG16);
+            }
+        }
+    }
+    __syncthreads();
+
+    int colmax[C], colarg[C];
+#pragma unroll
+    for (int q = 0; q < C; ++q) { colmax[q] = NEG32; colarg[q] = 0; }
+    unsigned ncand = 0;
+    unsigned long long cells = 0;
+    Cand* cand = a.cand ? a.cand + (long long)rd * a.cand_cap : nullptr;
+    uint32_t* dirs = a.dirs ? a.dirs + (long long)rd * a.dirs_stride : nullptr;
+    const bool track = a.track_best;
+
+    auto row_end = [&](int i, int knm, const int (&bkey)[C]) {
+        unsigned emask = 0;
+#pragma unroll
+        for (int q = 0; q < C; ++q) {
+            const int bv = bkey[q] >> 6, bk = bkey[q] & 63;
+            const bool exists = (cvalid >> ((q % H) + 16 * (q / H))) & 1;
+            const bool valid = exists && bkey[q] != INT32_MIN && (knm < 0 || bv > 0 || (bv == 0 && bk > knm));
+            if (valid) {
+                if (bv > colmax[q]) { colmax[q] = bv; colarg[q] = (i << 8) | bk; }
+                if (bv >= thr[q]) emask |= 1u << q;
+            }
+        }
+        if (cand && __any(emask != 0)) {
+            const int cnt = __popc(emask);
+            const int incl = dpp_incl_sum(cnt);
+            const int total = __shfl(incl, WAVE - 1, WAVE);
+            unsigned pos = ncand + (unsigned)(incl - cnt);
+#pragma unroll
+            for (int q = 0; q < C; ++q) {
+                if ((emask >> q) & 1) {
+                    if (pos < a.cand_cap) {
+                        const int c = lane * C + q;
+                        Cand cd;
+                        cd.row = i; cd.col = rev ? n - c : c; cd.val = bkey[q] >> 6; cd.path = bkey[q] & 63;
+                        cand[pos] = cd;
+                    }
+                    ++pos;
+                }
+            }
+            ncand += (unsigned)total;
+        }
+    };
+    // direction words: 2 bits per column in column order (q), 1 = D, 2 = U, 3 = L
+    auto store_dirs = [&](int slot, unsigned umask, unsigned lmask) {
+        // code bit 0 = L | D = L | ~U, bit 1 = L | U
+        const unsigned b0 = lmask | ~umask, b1 = lmask | umask;
+        if (C <= 16) {
+            const unsigned q0 = (b0 & ((1u << H) - 1u)) | (((b0 >> 16) & ((1u << H) - 1u)) << H);
+            const unsigned q1 = (b1 & ((1u << H) - 1u)) | (((b1 >> 16) & ((1u << H) - 1u)) << H);
+            uint32_t wv = spread16(q0) | (spread16(q1) << 1);
+            if (C < 16) wv &= (1u << (2 * C)) - 1u;
+            dirs[(long long)slot * a.dir_words + lane] = wv;
+        } else {
+            // columns 0..15 are the low halves, 16..31 the high halves
+            dirs[(long long)slot * a.dir_words + lane] = spread16(b0) | (spread16(b1) << 1);
+            dirs[(long long)slot * a.dir_words + WAVE + lane] = spread16(b0 >> 16) | (spread16(b1 >> 16) << 1);
+        }
+    };
+
+    const int4* steps = rev ? a.rsteps : a.fsteps;
+    const int nsteps = rev ? a.nrsteps : a.nfsteps;
+    int4 recs = make_int4(0, 0, 0, 0), recs_next = make_int4(0, 0, 0, 0);
+    if (lane < nsteps) recs = steps[lane];
+    if (WAVE + lane < nsteps) recs_next = steps[WAVE + lane];
+    int t = 0;
+    auto fetch = [&](int tt, int& w0, int& w1, unsigned long long& gmask) {
+        const int idx = tt & (WAVE - 1);
+        if (idx == 0 && tt > 0) {
+            recs = recs_next;
+            const int nb = tt + WAVE + lane;
+            recs_next = nb < nsteps ? steps[nb] : make_int4(0, 0, 0, 0);
+        }
+        w0 = __builtin_amdgcn_readlane(recs.x, idx);
+        w1 = __builtin_amdgcn_readlane(recs.y, idx);
+        gmask = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(recs.w, idx) << 32) |
+                (unsigned)__builtin_amdgcn_readlane(recs.z, idx);
+    };
+    constexpr int F_FIRST = 1, F_LAST = 2;
+
+    // semiglobal end-row selection (see k_sweep)
+    const bool semi_end = a.semi && !rev;
+    const int ln_end = n / C, ql_end = n % C;
+    if (semi_end) { endv[lane] = INT32_MIN; endr[lane] = 0; }
+    __syncthreads();
+    int gbest_val = INT32_MIN, gbest_row = 0, gbest_path = 0, rowkey = INT32_MIN;
+    auto end_fold = [&](int k, int i, const int (&row)[H]) {
+        int pv = 0;
+#pragma unroll
+        for (int r = 0; r < H; ++r) if (r == ql_end % H) pv = row[r];
+        const int v = ql_end >= H ? hi16(pv) : lo16(pv);
+        if (lane == ln_end) {
+            if (v > endv[k]) { endv[k] = v; endr[k] = i; }
+            rowkey = max(rowkey, v * 64 + (63 - k));
+        }
+    };
+    auto end_row_done = [&](int i) {
+        if (lane == ln_end && rowkey != INT32_MIN) {
+            const int rv = rowkey >> 6, rk = 63 - (rowkey & 63);
+            if (rv > gbest_val) { gbest_val = rv; gbest_row = i; gbest_path = rk; }
+        }
+        rowkey = INT32_MIN;
+    };
+    auto fold_keys = [&](int (&bkey)[C], const int (&row)[H], int k) {
+#pragma unroll
+        for (int r = 0; r < H; ++r) {
+            bkey[r] = max(bkey[r], lo16(row[r]) * 64 + k);
+            bkey[r + H] = max(bkey[r + H], hi16(row[r]) * 64 + k);
+        }
+    };
+
+    int s[H];
+    int bkey[C];
+    int MU[H], ML[H];
+    while (t < nsteps) {
+        int w0, w1;
+        unsigned long long gmask;
+        fetch(t, w0, w1, gmask);
+        const int i = w0 & 0xfffff;
+        const int li = (w0 >> 20) & 7;
+        const int flags = (w0 >> 23) & 7;
+        const int ga = (w0 >> 26) & 63;
+        const int slot = w1 & 0xffffff;
+        const int nm = __popcll(gmask);
+        const int g_i = __builtin_amdgcn_readfirstlane(sct[li * 6 + GAP]);
+        const int g0 = a.semi ? 0 : g_i;
+        if (flags & F_FIRST) {
+#pragma unroll
+            for (int r = 0; r < H; ++r) s[r] = s2[li * 64 + (int)((pcode[r / 8] >> (8 * (r % 8))) & 63)];
+#pragma unroll
+            for (int q = 0; q < C; ++q) bkey[q] = INT32_MIN;
+        }
+        {
+            unsigned long long rest = gmask & ~(1ull << ga);
+            cells += (unsigned long long)nm;
+            int rowa[H], nxt[H];
+#pragma unroll
+            for (int r = 0; r < H; ++r) rowa[r] = rows[(long long)ga * wrow + r * WAVE + lane];
+            int knext = -1;
+            if (rest) {
+                knext = __builtin_ctzll(rest);
+                rest &= rest - 1;
+#pragma unroll
+                for (int r = 0; r < H; ++r) nxt[r] = rows[(long long)knext * wrow + r * WAVE + lane];
+            }
+            unsigned umask, lmask;
+            int src;
+            RowOps16<C>::alpha(rowa, s, gcost, g_i, g0, lane, MU, ML, umask, lmask, src);
+#pragma unroll
+            for (int r = 0; r < H; ++r) rows[(long long)ga * wrow + r * WAVE + lane] = rowa[r];
+            if (track) fold_keys(bkey, rowa, ga);
+            if (semi_end) end_fold(ga, i, rowa);
+            if (dirs) store_dirs(slot, umask, lmask);
+            while (knext >= 0) {
+                const int k = knext;
+                int cur[H];
+#pragma unroll
+                for (int r = 0; r < H; ++r) cur[r] = nxt[r];
+                if (rest) {
+                    knext = __builtin_ctzll(rest);
+                    rest &= rest - 1;
+#pragma unroll
+                    for (int r = 0; r < H; ++r) nxt[r] = rows[(long long)knext * wrow + r * WAVE + lane];
+                } else knext = -1;
+                RowOps16<C>::member(cur, s, gcost, g_i, g0, lane, MU, ML, lmask, src);
+#pragma unroll
+                for (int r = 0; r < H; ++r) rows[(long long)k * wrow + r * WAVE + lane] = cur[r];
+                if (track) fold_keys(bkey, cur, k);
+                if (semi_end) end_fold(k, i, cur);
+            }
+        }
+        if (semi_end && (flags & F_LAST)) end_row_done(i);
+        if (track && (flags & F_LAST)) row_end(i, ((w1 >> 24) & 127) - 1, bkey);
+        ++t;
+    }
+
+    // ---- outputs ----
+    if (a.colmax_out) {
+#pragma unroll
+        for (int q = 0; q < C; ++q) {
+            const int c = lane * C + q;
+            if (c < ncols) {
+                a.colmax_out[(long long)rd * wpad + (rev ? n - c : c)] = colmax[q];
+                if (a.colarg_out) a.colarg_out[(long long)rd * wpad + (rev ? n - c : c)] = colarg[q];
+            }
+        }
+    }
+    if (a.ncand_out && lane == 0) a.ncand_out[rd] = ncand;
+    __syncthreads();
+    if (!rev && !a.semi) {
+        const int ql = n % C, ln = n / C;
+        for (int k = lane; k < P; k += WAVE) {
+            const int pv = rows[(long long)k * wrow + (ql % H) * WAVE + ln];
+            rs->sink_val[k] = ql >= H ? hi16(pv) : lo16(pv);
+        }
+    }
+    if (semi_end) {
+        if (lane < P) { rs->sink_val[lane] = endv[lane]; rs->path_end_row[lane] = endr[lane]; }
+        if (lane == ln_end) { rs->s0 = gbest_val; rs->end_row_best = gbest_row; rs->seed_path = gbest_path; }
+    }
+    if (lane == 0 && a.count_cells) atomicAdd(a.cells, cells * (unsigned long long)(n + 1));
+}
+
+// Host-side admission test: uniform read-gap cost and every absolute score provably inside the 16-bit budget.
+// A cell of path k at (row i, column j) is the score of an alignment of j read bases against at most `max_path_rows`
+// graph rows: |value| <= (max_path_rows + n) * max|entry|.  NEG16 plus a few steps of drift must not wrap either.
+bool sweep16_admissible(const DevScores& sc, int max_path_rows, int max_n, int C) {
+    for (int b = 1; b < 5; ++b) if (sc.t[b * 6 + 5] != sc.t[5]) return false;
+    long long maxabs = 0;
+    for (int x = 0; x < 6; ++x)
+        for (int y = 0; y < 6; ++y) {
+            if (x == 5 && y == 5) continue;
+            const long long v = sc.t[x * 6 + y];
+            maxabs = std::max(maxabs, v < 0 ? -v : v);
+        }
+    if (maxabs > 1000) return false;
+    if ((long long)(max_path_rows + max_n + 2) * maxabs > 24000) return false;
+    if ((long long)(C / 2 + 2) * maxabs > 2000) return false;
+    return true;
+}
+
+void launch_sweep16(const SweepArgs& a, int nreads, int C, hipStream_t s) {
+    const size_t bytes = (size_t)(192 + 5 * 64) * sizeof(int);
+    switch (C) {
+        case 4: hipLaunchKernelGGL((k_sweep16<4>), dim3(nreads), dim3(64), bytes, s, a); break;
+        case 8: hipLaunchKernelGGL((k_sweep16<8>), dim3(nreads), dim3(64), bytes, s, a); break;
+        case 16: hipLaunchKernelGGL((k_sweep16<16>), dim3(nreads), dim3(64), bytes, s, a); break;
+        default: hipLaunchKernelGGL((k_sweep16<32>), dim3(nreads), dim3(64), bytes, s, a); break;
+    }
+}
+
+}  // namespace rg
