@@ -313,7 +313,7 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
             }
             if (needf > w.fcap || needr > w.rcap) {
                 const unsigned long long full = (unsigned long long)L * wpad;
-                if ((needf > w.fcap && w.fcap >= full) || (needr > w.rcap && w.rcap >= full))
+                if ((needf > w.fcap && w.fcap >= full) || (needr > w.rcap && w.rcap >= full) || needf > full || needr > full)
                     return fail(RG_ERR_CAPACITY, "candidate list overflow at full size");
                 while (w.fcap < needf) w.fcap = (unsigned)std::min<unsigned long long>(2ull * w.fcap, full);
                 while (w.rcap < needr) w.rcap = (unsigned)std::min<unsigned long long>(2ull * w.rcap, full);

@@ -13,8 +13,9 @@
 // stitched with 32-bit per-lane arithmetic (a dozen instructions per row update) and one wave-level DPP prefix max
 // exactly like the i32 kernel.  Rows in HBM are [path][r][lane] packed words.
 //
-// Outputs (direction words, column maxima + arguments, candidates, sink values, semiglobal end rows) are
-// bit-identical to k_sweep's: everything downstream is shared.
+// Outputs (direction words, column maxima, candidates, sink values, semiglobal end rows) are identical to k_sweep's;
+// the argument recorded for a column maximum may be a different cell with the same value (k_bound only needs a real
+// cell: any candidate pair gives a valid lower bound).  Everything downstream is shared.
 #include <algorithm>
 
 #include "rg_path_kernels.hpp"
@@ -47,7 +48,13 @@ __device__ __forceinline__ int pack16(int lo, int hi) { return (int)(((unsigned)
 __device__ __forceinline__ int lo16(int v) { return (int)(short)(v & 0xffff); }
 __device__ __forceinline__ int hi16(int v) { return v >> 16; }
 // per half: mask ? a : b   (mask halves are 0 or 0xffff)
-__device__ __forceinline__ int bfi(int mask, int a, int b) { return (mask & a) | (~mask & b); }
+__device__ __forceinline__ int bfi(int mask, int a, int b) {
+#ifdef RG16_OLD_BFI
+    return (mask & a) | (~mask & b);
+#else
+    return __builtin_amdgcn_bitop3_b32(mask, a, b, 0xCA);   // (mask & a) | (~mask & b) in ONE v_bitop3_b32
+#endif
+}
 
 // Row operators on packed rows.  MU / ML: per register, 0xffff in the halves whose column took U (not D) / L.
 template <int C>
@@ -182,8 +189,7 @@ __global__ __launch_bounds__(64, 2) void k_sweep16(SweepArgs a) {
     const int gcost = sct[GAP];          // uniform read-gap cost (checked by the launcher)
     // per-column constants of this lane
     unsigned long long pcode[(H + 7) / 8] = {};   // 8 bits per register: code_lo | code_hi << 3
-    int thr[C];
-    unsigned cvalid = 0;                 // RowOps16 bit layout: columns of this lane that exist
+    int thrk[C];                         // emission threshold << 16 per column (INT32_MAX = never; columns that do not exist)
     const int oob = max((int)((float)(n + 1) * (1.0f - a.rbw) / 2.0f), 1);
     {
 #pragma unroll
@@ -193,13 +199,14 @@ __global__ __launch_bounds__(64, 2) void k_sweep16(SweepArgs a) {
             if (c >= 1 && c < ncols) code = rev ? read[n - c + 1] : read[c];
             const int r = q % H, hi = q / H;
             pcode[r / 8] |= (unsigned long long)code << (8 * (r % 8) + 3 * hi);
-            if (c < ncols) cvalid |= 1u << (r + 16 * hi);
             const int j = rev ? n - c : c;
-            thr[q] = INT32_MAX;
+            int th = INT32_MAX;
             if (c < ncols && j >= oob && j < n + 1 - oob) {
-                if (a.thr) thr[q] = a.thr[(long long)rd * wpad + j];
-                else if (a.lb) thr[q] = a.lb[rd] + a.brc - (n - j) * a.maxmatch;
+                if (a.thr) th = a.thr[(long long)rd * wpad + j];
+                else if (a.lb) th = a.lb[rd] + a.brc - (n - j) * a.maxmatch;
             }
+            // keys are value << 16 | path with |value| < 2^15: thresholds outside that range mean always / never
+            thrk[q] = th > 32767 ? INT32_MAX : (th < -32768 ? INT32_MIN : th * 65536);
         }
         // start rows: the gap-only row, identical for every path (uniform gap cost: c * gcost)
         for (int k = 0; k < P; ++k) {
@@ -212,26 +219,28 @@ __global__ __launch_bounds__(64, 2) void k_sweep16(SweepArgs a) {
     }
     __syncthreads();
 
-    int colmax[C], colarg[C];
+    int ckey[C], crow[C];               // best usable (value << 16 | path) per column and its row
 #pragma unroll
-    for (int q = 0; q < C; ++q) { colmax[q] = NEG32; colarg[q] = 0; }
+    for (int q = 0; q < C; ++q) { ckey[q] = INT32_MIN; crow[q] = 0; }
     unsigned ncand = 0;
     unsigned long long cells = 0;
     Cand* cand = a.cand ? a.cand + (long long)rd * a.cand_cap : nullptr;
     uint32_t* dirs = a.dirs ? a.dirs + (long long)rd * a.dirs_stride : nullptr;
     const bool track = a.track_best;
 
+    // Per-row epilogue on the packed keys bkey = value << 16 | path (non-members of the reference's matrices hold 0,
+    // so a cell is usable iff its winner is a member: value > 0, or value == 0 and path > knm, or no non-member
+    // exists -> bkey > kthr with kthr = knm (>= 0) or INT32_MIN).  ckey keeps the best usable key per column and the
+    // row it came from; emission compares against thr << 16.
     auto row_end = [&](int i, int knm, const int (&bkey)[C]) {
+        const int kthr = knm >= 0 ? knm : INT32_MIN;
         unsigned emask = 0;
 #pragma unroll
         for (int q = 0; q < C; ++q) {
-            const int bv = bkey[q] >> 6, bk = bkey[q] & 63;
-            const bool exists = (cvalid >> ((q % H) + 16 * (q / H))) & 1;
-            const bool valid = exists && bkey[q] != INT32_MIN && (knm < 0 || bv > 0 || (bv == 0 && bk > knm));
-            if (valid) {
-                if (bv > colmax[q]) { colmax[q] = bv; colarg[q] = (i << 8) | bk; }
-                if (bv >= thr[q]) emask |= 1u << q;
-            }
+            const bool better = bkey[q] > max(ckey[q], kthr);
+            ckey[q] = better ? bkey[q] : ckey[q];
+            crow[q] = better ? i : crow[q];
+            emask |= (bkey[q] >= thrk[q] && bkey[q] > kthr) ? (1u << q) : 0u;
         }
         if (cand && __any(emask != 0)) {
             const int cnt = __popc(emask);
@@ -244,7 +253,7 @@ __global__ __launch_bounds__(64, 2) void k_sweep16(SweepArgs a) {
                     if (pos < a.cand_cap) {
                         const int c = lane * C + q;
                         Cand cd;
-                        cd.row = i; cd.col = rev ? n - c : c; cd.val = bkey[q] >> 6; cd.path = bkey[q] & 63;
+                        cd.row = i; cd.col = rev ? n - c : c; cd.val = bkey[q] >> 16; cd.path = bkey[q] & 0xffff;
                         cand[pos] = cd;
                     }
                     ++pos;
@@ -316,8 +325,9 @@ __global__ __launch_bounds__(64, 2) void k_sweep16(SweepArgs a) {
     auto fold_keys = [&](int (&bkey)[C], const int (&row)[H], int k) {
 #pragma unroll
         for (int r = 0; r < H; ++r) {
-            bkey[r] = max(bkey[r], lo16(row[r]) * 64 + k);
-            bkey[r + H] = max(bkey[r + H], hi16(row[r]) * 64 + k);
+            // key = value << 16 | path: one v_lshl_or_b32 / v_and_or_b32 per column
+            bkey[r] = max(bkey[r], (int)(((unsigned)row[r] << 16) | (unsigned)k));
+            bkey[r + H] = max(bkey[r + H], (int)(((unsigned)row[r] & 0xffff0000u) | (unsigned)k));
         }
     };
 
@@ -392,8 +402,8 @@ __global__ __launch_bounds__(64, 2) void k_sweep16(SweepArgs a) {
         for (int q = 0; q < C; ++q) {
             const int c = lane * C + q;
             if (c < ncols) {
-                a.colmax_out[(long long)rd * wpad + (rev ? n - c : c)] = colmax[q];
-                if (a.colarg_out) a.colarg_out[(long long)rd * wpad + (rev ? n - c : c)] = colarg[q];
+                a.colmax_out[(long long)rd * wpad + (rev ? n - c : c)] = ckey[q] == INT32_MIN ? NEG32 : ckey[q] >> 16;
+                if (a.colarg_out) a.colarg_out[(long long)rd * wpad + (rev ? n - c : c)] = (crow[q] << 8) | (ckey[q] & 63);
             }
         }
     }
