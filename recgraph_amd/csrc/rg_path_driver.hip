@@ -47,7 +47,9 @@ struct PathWorkImpl {
     Buf<int> roll, mf, wr, mfarg, wrarg, thr, flayer, rlayer;
     Buf<uint32_t> fdirs, rdirs;
     Buf<Cand> fcand, rcand;
-    Buf<unsigned> nf, nr, ridx;
+    Buf<unsigned> nf, nr, ridx, nrec;
+    Buf<int> frec;
+    unsigned frec_cap = 0;
     Buf<int> lb;
     Buf<int4> fsteps, rsteps;
     int nfsteps = 0, nrsteps = 0;
@@ -219,14 +221,19 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
         for (int y = 0; y < 5; ++y) maxmatch = std::max(maxmatch, p.scores[x * 6 + y]);
     }
     const bool two_sweep = mode == RG_MODE_RECOMBINATION && gaps_nonpos && !use_reg && !getenv("RG_THREE_SWEEPS");
-    if (w.fcap == 0) { w.fcap = two_sweep ? 1u << 20 : 1u << 15; w.rcap = 1u << 19; }
+    // forward emissions of the two-sweep pipeline are loose (threshold from the path-0 score): k_sweep16 writes them as
+    // (row, lane) records that k_expand filters with the final bound; k_sweep writes plain Cand entries
+    const bool use_rec = two_sweep && use16 && !getenv("RG_NO_FREC");
+    const int recw = 4 + C;
+    if (w.fcap == 0) { w.fcap = (two_sweep && !use_rec) ? 1u << 20 : 1u << 15; w.rcap = 1u << 19; w.frec_cap = 1u << 16; }
     stats.clear();
     HIPCHK(hipMemsetAsync(d_cells, 0, sizeof(unsigned long long), stream));
     Timer T{&w, stream};
     int done = 0;
     unsigned long long cells_done = 0;
     while (done < nreads) {
-        const size_t per_read_all = per_read + (mode == RG_MODE_RECOMBINATION ? ((size_t)w.fcap * sizeof(Cand) + (size_t)w.rcap * (sizeof(Cand) + 4)) : 0);
+        const size_t per_read_all = per_read + (mode == RG_MODE_RECOMBINATION ? ((size_t)w.fcap * sizeof(Cand) + (size_t)w.rcap * (sizeof(Cand) + 4) +
+                                                                                     (use_rec ? (size_t)w.frec_cap * recw * 4 : 0)) : 0);
         int maxchunk = (int)std::min<size_t>(8192, std::max<size_t>(1, budget / per_read_all));
         const int left = nreads - done;
         const int nchunks = (left + maxchunk - 1) / maxchunk;
@@ -241,8 +248,9 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
                 (rc = w.mfarg.alloc((size_t)chunk * wpad)) || (rc = w.wrarg.alloc((size_t)chunk * wpad)) ||
                 (rc = w.thr.alloc((size_t)chunk * wpad)) || (rc = w.fcand.alloc((size_t)chunk * w.fcap)) ||
                 (rc = w.rcand.alloc((size_t)chunk * w.rcap)) || (rc = w.ridx.alloc((size_t)chunk * w.rcap)) ||
-                (rc = w.nf.alloc(chunk)) || (rc = w.nr.alloc(chunk)) || (rc = w.lb.alloc(chunk)))
+                (rc = w.nf.alloc(chunk)) || (rc = w.nr.alloc(chunk)) || (rc = w.lb.alloc(chunk)) || (rc = w.nrec.alloc(chunk)))
                 return rc;
+            if (use_rec && (rc = w.frec.alloc((size_t)chunk * w.frec_cap * recw))) return rc;
         }
         const uint8_t* bad = d_bad + done;
         const long long* off = d_off + done;
@@ -269,6 +277,7 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
                 SweepArgs f = sa;
                 f.rev = 0; f.track_best = 1; f.lb = w.lb.p; f.brc = p.base_rec_cost; f.maxmatch = maxmatch;
                 f.colmax_out = w.mf.p; f.colarg_out = w.mfarg.p; f.cand = w.fcand.p; f.cand_cap = w.fcap; f.ncand_out = w.nf.p;
+                if (use_rec) { f.cand = nullptr; f.cand_cap = 0; f.frec = w.frec.p; f.frec_cap = w.frec_cap; f.ncand_out = w.nrec.p; }
                 f.dirs = w.fdirs.p; f.dirs_stride = fdirs_stride; f.count_cells = 1;
                 TIMED(T, "k_sweep_fwd", sweep(f, chunk));
                 TIMED(T, "k_seed", launch_seed(se, stream));
@@ -295,6 +304,10 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
                 f2.dirs = w.fdirs.p; f2.dirs_stride = fdirs_stride; f2.count_cells = 1;
                 TIMED(T, "k_sweep_fwd", sweep(f2, chunk));
             }
+            if (use_rec) {
+                ExpandArgs ea{w.state.p, w.frec.p, w.frec_cap, w.nrec.p, w.fcand.p, w.fcap, w.nf.p, w.wr.p, wpad, p.base_rec_cost};
+                TIMED(T, "k_expand", launch_expand(ea, chunk, C, stream));
+            }
             SearchArgs sr{gd, w.state.p, w.fcand.p, w.rcand.p, w.nf.p, w.nr.p, w.ridx.p, w.fcap, w.rcap, w.wr.p, wpad, p.base_rec_cost,
                           p.multi_rec_cost};
             TIMED(T, "k_search", launch_search(sr, chunk, stream));
@@ -303,8 +316,22 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
             std::vector<unsigned> hn(chunk), hr(chunk);
             HIPCHK(hipMemcpy(hn.data(), w.nf.p, sizeof(unsigned) * chunk, hipMemcpyDeviceToHost));
             HIPCHK(hipMemcpy(hr.data(), w.nr.p, sizeof(unsigned) * chunk, hipMemcpyDeviceToHost));
-            unsigned needf = 0, needr = 0;
+            unsigned needf = 0, needr = 0, needrec = 0;
             for (int i = 0; i < chunk; ++i) { needf = std::max(needf, hn[i]); needr = std::max(needr, hr[i]); }
+            if (use_rec) {
+                std::vector<unsigned> hc(chunk);
+                HIPCHK(hipMemcpy(hc.data(), w.nrec.p, sizeof(unsigned) * chunk, hipMemcpyDeviceToHost));
+                unsigned long long sc = 0;
+                for (int i = 0; i < chunk; ++i) { needrec = std::max(needrec, hc[i]); sc += hc[i]; }
+                if (getenv("RG_DEBUG")) fprintf(stderr, "[rg] forward records mean %.1f max %u (cap %u)\n", (double)sc / chunk, needrec, w.frec_cap);
+                if (needrec > w.frec_cap) {
+                    const unsigned long long fullrec = (unsigned long long)L * WAVE;
+                    if (w.frec_cap >= fullrec) return fail(RG_ERR_CAPACITY, "forward record list overflow at full size");
+                    while (w.frec_cap < needrec) w.frec_cap = (unsigned)std::min<unsigned long long>(2ull * w.frec_cap, fullrec);
+                    HIPCHK(hipMemcpy(d_cells, &cells_done, sizeof cells_done, hipMemcpyHostToDevice));
+                    continue;
+                }
+            }
             if (getenv("RG_DEBUG")) {
                 unsigned long long sf = 0, sr = 0;
                 for (int i = 0; i < chunk; ++i) { sf += hn[i]; sr += hr[i]; }

@@ -53,6 +53,25 @@ struct SweepArgs {
     unsigned long long* cells;
     int count_cells;
     int oob;                   // unused (computed per read from rbw)
+    // k_sweep16, forward sweep of the two-sweep pipeline: loose emissions go out as one record per (row, lane) instead
+    // of one Cand per cell: (4 + C) ints = {row << 6 | lane, column mask, 0, 0, key[C]} with key = value << 16 | path
+    int* frec;                 // [reads][frec_cap][4 + C] or null
+    unsigned frec_cap;
+};
+
+// expands the (row, lane) records of the forward sweep into Cand entries, keeping only cells that can still reach
+// the final bound with the best reverse partner of their column
+struct ExpandArgs {
+    ReadState* state;
+    const int* frec;
+    unsigned frec_cap;
+    const unsigned* nrec;
+    Cand* fcand;
+    unsigned fcap;
+    unsigned* nf;
+    const int* wr;
+    int wpad;
+    int brc;
 };
 
 struct SeedArgs {
@@ -153,6 +172,7 @@ void launch_sweep(const SweepArgs& a, int nreads, int C, bool lds, hipStream_t s
 void launch_sweep_reg(const SweepArgs& a, int nreads, int C, hipStream_t s);
 void launch_sweep16(const SweepArgs& a, int nreads, int C, hipStream_t s);   // packed 16-bit rows (rg_sweep16.hip)
 bool sweep16_admissible(const DevScores& sc, int max_path_rows, int max_n, int C);
+void launch_expand(const ExpandArgs& a, int nreads, int C, hipStream_t s);
 void launch_seed(const SeedArgs& a, hipStream_t s);
 void launch_opt0(const Opt0Args& a, int nreads, int C, hipStream_t s);
 void launch_threshold(const ThrArgs& a, int nreads, hipStream_t s);

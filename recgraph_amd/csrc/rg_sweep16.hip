@@ -242,7 +242,22 @@ __global__ __launch_bounds__(64, 2) void k_sweep16(SweepArgs a) {
             crow[q] = better ? i : crow[q];
             emask |= (bkey[q] >= thrk[q] && bkey[q] > kthr) ? (1u << q) : 0u;
         }
-        if (cand && __any(emask != 0)) {
+        if (a.frec) {
+            // one fixed-size record per (row, lane) with any emission: 1 + C/4 16-byte stores instead of a Cand per cell
+            if (__any(emask != 0)) {
+                const int has = emask != 0 ? 1 : 0;
+                const int incl = dpp_incl_sum(has);
+                const int total = __shfl(incl, WAVE - 1, WAVE);
+                const unsigned pos = ncand + (unsigned)(incl - has);
+                if (has && pos < a.frec_cap) {
+                    int4* rp = reinterpret_cast<int4*>(a.frec + ((long long)rd * a.frec_cap + pos) * (4 + C));
+                    rp[0] = make_int4((i << 6) | lane, (int)emask, 0, 0);
+#pragma unroll
+                    for (int q4 = 0; q4 < C / 4; ++q4) rp[1 + q4] = make_int4(bkey[4 * q4], bkey[4 * q4 + 1], bkey[4 * q4 + 2], bkey[4 * q4 + 3]);
+                }
+                ncand += (unsigned)total;
+            }
+        } else if (cand && __any(emask != 0)) {
             const int cnt = __popc(emask);
             const int incl = dpp_incl_sum(cnt);
             const int total = __shfl(incl, WAVE - 1, WAVE);
@@ -439,6 +454,47 @@ bool sweep16_admissible(const DevScores& sc, int max_path_rows, int max_n, int C
     if ((long long)(max_path_rows + max_n + 2) * maxabs > 24000) return false;
     if ((long long)(C / 2 + 2) * maxabs > 2000) return false;
     return true;
+}
+
+// Forward (row, lane) records -> Cand list, filtered with the final bound (the same test k_search applies).
+template <int C>
+__global__ __launch_bounds__(64) void k_expand(ExpandArgs a) {
+    const int rd = blockIdx.x;
+    const int lane = threadIdx.x;
+    ReadState* rs = a.state + rd;
+    if (lane == 0) a.nf[rd] = 0;
+    __syncthreads();
+    if (rs->status & (ST_BAD_BASE | ST_WOULD_PANIC)) return;
+    const unsigned nrec = a.nrec[rd];
+    if (nrec > a.frec_cap) { if (lane == 0) rs->status |= ST_OVERFLOW; return; }
+    const int bound = rs->bound;
+    const int* base = a.frec + (long long)rd * a.frec_cap * (4 + C);
+    Cand* out = a.fcand + (long long)rd * a.fcap;
+    const int* wr = a.wr + (long long)rd * a.wpad;
+    for (unsigned t = lane; t < nrec; t += WAVE) {
+        const int* rp = base + (long long)t * (4 + C);
+        const int rl = rp[0];
+        unsigned em = (unsigned)rp[1];
+        const int row = rl >> 6, ln = rl & 63;
+        while (em) {
+            const int q = __ffs((int)em) - 1;
+            em &= em - 1;
+            const int key = rp[4 + q];
+            const int val = key >> 16, col = ln * C + q;
+            if (val + wr[col] - a.brc < bound) continue;
+            const unsigned pos = atomicAdd(&a.nf[rd], 1u);
+            if (pos < a.fcap) { Cand cd; cd.row = row; cd.col = col; cd.val = val; cd.path = key & 0xffff; out[pos] = cd; }
+        }
+    }
+}
+
+void launch_expand(const ExpandArgs& a, int nreads, int C, hipStream_t s) {
+    switch (C) {
+        case 4: hipLaunchKernelGGL((k_expand<4>), dim3(nreads), dim3(64), 0, s, a); break;
+        case 8: hipLaunchKernelGGL((k_expand<8>), dim3(nreads), dim3(64), 0, s, a); break;
+        case 16: hipLaunchKernelGGL((k_expand<16>), dim3(nreads), dim3(64), 0, s, a); break;
+        default: hipLaunchKernelGGL((k_expand<32>), dim3(nreads), dim3(64), 0, s, a); break;
+    }
 }
 
 void launch_sweep16(const SweepArgs& a, int nreads, int C, hipStream_t s) {
