@@ -351,7 +351,7 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
         LayerArgs la;
         memset(&la, 0, sizeof la);
         la.semi = semi ? 1 : 0;
-        la.g = gd; la.sc = sa.sc; la.reads = d_reads; la.read_off = off; la.state = w.state.p; la.dir_words = dir_words;
+        la.g = gd; la.sc = sa.sc; la.reads = d_reads; la.read_off = off; la.state = w.state.p; la.dir_words = dir_words; la.dir_fmt = use16 ? 1 : 0;
         la.layer_stride = layer_stride; la.fpoff = w.fpoff.p; la.fprow = w.fprow.p; la.fpslot = w.fpslot.p;
         la.rpoff = w.rpoff.p; la.rprow = w.rprow.p; la.rpslot = w.rpslot.p;
         la.rev = 0; la.dirs = w.fdirs.p; la.dirs_stride = fdirs_stride; la.layer = w.flayer.p;

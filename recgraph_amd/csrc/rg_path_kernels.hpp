@@ -142,6 +142,7 @@ struct LayerArgs {
     const uint32_t* dirs;
     long long dirs_stride;
     int dir_words;
+    int dir_fmt;               // 0: 2 bits per column (k_sweep), 1: U mask | L mask (k_sweep16)
     int semi;
     int* layer;                // [reads][layer_stride]
     long long layer_stride;

@@ -818,7 +818,15 @@ __global__ __launch_bounds__(64) void k_layer(LayerArgs a) {
         const int li = g.lnz[i];
         const int g_i = sct[li * 6 + GAP];
         unsigned dmask = 0, lmask = 0;
-        if (C <= 16) {
+        if (a.dir_fmt == 1) {
+            if (C <= 16) {
+                const uint32_t wv = dirs[(long long)slot * a.dir_words + lane];
+                dmask = ~wv & 0xffffu; lmask = wv >> 16;
+            } else {
+                dmask = ~dirs[(long long)slot * a.dir_words + lane];
+                lmask = dirs[(long long)slot * a.dir_words + WAVE + lane];
+            }
+        } else if (C <= 16) {
             const uint32_t wv = dirs[(long long)slot * a.dir_words + lane];
 #pragma unroll
             for (int q = 0; q < C; ++q) {

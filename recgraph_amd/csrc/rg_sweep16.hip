@@ -44,6 +44,10 @@ __device__ __forceinline__ int pk_max(int a, int b) {
 __device__ __forceinline__ int pk_minu(int a, int b) {
     return __builtin_bit_cast(int, __builtin_elementwise_min(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
 }
+// per half: 0xffff where the half of `v` is negative, else 0  (v_pk_ashrrev_i16)
+__device__ __forceinline__ int pk_sign(int v) {
+    return __builtin_bit_cast(int, (s16x2)(__builtin_bit_cast(s16x2, v) >> (s16x2)(15)));
+}
 __device__ __forceinline__ int pack16(int lo, int hi) { return (int)(((unsigned)hi << 16) | ((unsigned)lo & 0xffffu)); }
 __device__ __forceinline__ int lo16(int v) { return (int)(short)(v & 0xffff); }
 __device__ __forceinline__ int hi16(int v) { return v >> 16; }
@@ -76,9 +80,8 @@ struct RowOps16 {
             const int old = row[r];
             const int d = pk_add(prev, s[r]), u = pk_add(old, r == 0 ? GI0 : GI);
             const int du = pk_max(d, u);                            // D on ties (d >= u); lane 0 column 0: d = -inf -> U
-            const int nd = pk_minu(du ^ d, ONE2);                   // 1 where U
-            um |= (unsigned)nd << r;
-            MU[r] = pk_sub(0, nd);
+            MU[r] = pk_sign(pk_sub(d, du));                         // d - max(d, u) < 0 where U (|d - u| is a few scores: no wrap)
+            um |= (unsigned)MU[r] & ((unsigned)ONE2 << r);
             run = pk_max(du, pk_add(run, G2));                      // chain without carry-in, for the totals
             row[r] = du;
             prev = old;
@@ -96,9 +99,8 @@ struct RowOps16 {
         for (int r = 0; r < H; ++r) {
             const int du = row[r];
             const int v = pk_max(du, pk_add(vprev, G2));
-            const int nl = pk_minu(v ^ du, ONE2);                   // 1 where L (left strictly better)
-            lm |= (unsigned)nl << r;
-            ML[r] = pk_sub(0, nl);
+            ML[r] = pk_sign(pk_sub(du, v));                         // du - max(du, left) < 0 where L (left strictly better)
+            lm |= (unsigned)ML[r] & ((unsigned)ONE2 << r);
             row[r] = v;
             vprev = v;
         }
@@ -141,16 +143,6 @@ struct RowOps16 {
         }
     }
 };
-
-// spread the low 16 bits of x to the even bit positions
-__device__ __forceinline__ uint32_t spread16(uint32_t x) {
-    x &= 0xffffu;
-    x = (x | (x << 8)) & 0x00ff00ffu;
-    x = (x | (x << 4)) & 0x0f0f0f0fu;
-    x = (x | (x << 2)) & 0x33333333u;
-    x = (x | (x << 1)) & 0x55555555u;
-    return x;
-}
 
 }  // namespace
 
@@ -277,20 +269,16 @@ __global__ __launch_bounds__(64, 2) void k_sweep16(SweepArgs a) {
             ncand += (unsigned)total;
         }
     };
-    // direction words: 2 bits per column in column order (q), 1 = D, 2 = U, 3 = L
+    // direction words, format 1 (LayerArgs::dir_fmt): C <= 16: one word per lane, U bits of the C columns in the low
+    // half and L bits in the high half; C = 32: word 0 = U bits, word 1 = L bits (the masks already are in column order)
     auto store_dirs = [&](int slot, unsigned umask, unsigned lmask) {
-        // code bit 0 = L | D = L | ~U, bit 1 = L | U
-        const unsigned b0 = lmask | ~umask, b1 = lmask | umask;
         if (C <= 16) {
-            const unsigned q0 = (b0 & ((1u << H) - 1u)) | (((b0 >> 16) & ((1u << H) - 1u)) << H);
-            const unsigned q1 = (b1 & ((1u << H) - 1u)) | (((b1 >> 16) & ((1u << H) - 1u)) << H);
-            uint32_t wv = spread16(q0) | (spread16(q1) << 1);
-            if (C < 16) wv &= (1u << (2 * C)) - 1u;
-            dirs[(long long)slot * a.dir_words + lane] = wv;
+            const unsigned u16 = (umask & ((1u << H) - 1u)) | ((umask >> (16 - H)) & (((1u << H) - 1u) << H));
+            const unsigned l16 = (lmask & ((1u << H) - 1u)) | ((lmask >> (16 - H)) & (((1u << H) - 1u) << H));
+            dirs[(long long)slot * a.dir_words + lane] = u16 | (l16 << 16);
         } else {
-            // columns 0..15 are the low halves, 16..31 the high halves
-            dirs[(long long)slot * a.dir_words + lane] = spread16(b0) | (spread16(b1) << 1);
-            dirs[(long long)slot * a.dir_words + WAVE + lane] = spread16(b0 >> 16) | (spread16(b1 >> 16) << 1);
+            dirs[(long long)slot * a.dir_words + lane] = umask;
+            dirs[(long long)slot * a.dir_words + WAVE + lane] = lmask;
         }
     };
 
