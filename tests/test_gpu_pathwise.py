@@ -121,3 +121,29 @@ def test_wide_and_long_shapes(oracle):
     # reads longer than the supported 2047 bases: status code, no abort
     with pytest.raises(_lib.RecGraphError):
         api.align_batch(gg, ["ACGT" * 600], None, mode=api.MODE_PATHWISE)
+
+
+def test_sweep_kernel_variants_agree(oracle, monkeypatch):
+    """The packed 16-bit sweep (default when the scores fit), the i32 sweep (RG_SWEEP_I32) and the Cand-list forward
+    emission (RG_NO_FREC) are three implementations of the same DP: byte-identical records, all equal to the oracle.
+    A matrix whose scores do not fit 16 bits must take the i32 kernel by itself."""
+    from recgraph_amd import api, synth
+    g = synth.haplotype_graph(2500, 12, path_len=400, seed=31)
+    rd = synth.haplotype_reads(g, 40, length=400, seed=32, mosaic_frac=0.6) + [g.path_sequence(4)[:333], "ACGTTGCA" * 9]
+    gg = api.Graph.from_gfa_text(g.gfa())
+    for mode, om, cut in ((api.MODE_RECOMBINATION, oracle.M8_ABS, 42), (api.MODE_RECOMBINATION_SEMI, oracle.M9_ABS, 12),
+                          (api.MODE_PATHWISE, oracle.M4_ABS, 42), (api.MODE_PATHWISE_SEMI, oracle.M5_ABS, 12)):
+        reads = [r[:180] for r in rd[:cut]] if mode in (api.MODE_RECOMBINATION_SEMI, api.MODE_PATHWISE_SEMI) else rd[:cut]
+        base = _check(oracle, g.gfa(), reads, mode, om)
+        for var in ("RG_SWEEP_I32", "RG_NO_FREC"):
+            monkeypatch.setenv(var, "1")
+            texts, _ = api.align_batch(gg, reads, ["r%d" % i for i in range(len(reads))], mode=mode)
+            monkeypatch.delenv(var)
+            assert texts == base, var
+    # scores outside the 16-bit budget: (rows on a path + read length) * max |score| > 24000
+    sm = api.create_score_matrix_i32(90, -120)
+    table = api._table_from_dict(sm)
+    og = oracle.Graph.from_gfa_text(g.gfa())
+    texts, _ = api.align_batch(gg, rd[:8], None, mode=api.MODE_RECOMBINATION, score_matrix=sm)
+    for i, r in enumerate(rd[:8]):
+        assert texts[i] == og.align(oracle.M8_ABS, r, name="read%d" % i, scores=table)[0]
