@@ -125,14 +125,17 @@ def main():
                     traffic = None
             roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                    "kernel": {0: "k_m0_simd", 2: "k_poa_banded<true>", 4: "k_sweep", 8: "k_sweep"}[mode],
+                    "kernel": {0: "k_m0_simd", 2: "k_poa_banded<true>", 4: "k_sweep", 8: "k_sweep"}[mode] +
+                              ("16" if any(k.startswith("k_sweep16") for k in sweeps) else ""),
                     "avg_launch_ms": round(ms / launches, 3), "launches": launches}
         out = {
             "metric": "aligned reads/sec (-m 8 recombination, 1 kbp reads, 10k-row/32-path graph)" if args.config == "C5"
             else "aligned reads/sec (%s)" % args.config,
             "value": round(total_reads / dt, 2), "unit": "reads/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None,
+            # arithmetic type of the DP cells: packed 16-bit integers when the batch's scores provably fit, else int32
+            "dtype": "int16" if any(k.startswith("k_sweep16") for k in kstats) else "int32", "data": "synthetic",
             "config": {"workload": "BASELINE.json configs[%d] (%s): -m %d, %d bp reads, graph rows=%d paths=%d, batch=%d reads/GPU/step"
                        % (num - 1, args.config, mode, cfg["n"], graph.rows, graph.paths_number, batch),
                        "parallelism": "read-shard x%d" % world},

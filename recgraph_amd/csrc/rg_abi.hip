@@ -433,7 +433,10 @@ int32_t rg_batch_create(const rg_graph* gc, const rg_params* p, const char* read
         return rc;
     if ((rc = b->d_rec.alloc(nreads)) || (rc = b->d_cells.alloc(1))) return rc;
     const HostGraph& h = g->h;
-    b->ops_stride = (long long)h.L + b->max_n + 8;
+    // traceback ops per read: POA walks at most L rows + n columns; a pathwise walk stays on the rows of one path per
+    // half (forward to the source, reverse to the sink): <= 2 * (rows of the longest path + n)
+    b->ops_stride = is_poa(mode) ? (long long)h.L + b->max_n + 8
+                                 : std::min<long long>((long long)h.L + b->max_n + 8, 2ll * (h.max_path_rows + b->max_n) + 16);
     if ((rc = b->d_ops.alloc((size_t)nreads * b->ops_stride))) return rc;
     if (is_poa(mode)) {
         // column-0 chain of m0 (global_abpoa.rs:36-46): depends on graph + scores only

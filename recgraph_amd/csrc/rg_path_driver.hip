@@ -268,7 +268,7 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
         if (mode == RG_MODE_PATHWISE) {
             SweepArgs f = sa;
             f.rev = 0; f.track_best = 0; f.dirs = w.fdirs.p; f.dirs_stride = fdirs_stride; f.count_cells = 1;
-            TIMED(T, "k_sweep_fwd", sweep(f, chunk));
+            TIMED(T, use16 ? "k_sweep16_fwd" : "k_sweep_fwd", sweep(f, chunk));
             TIMED(T, "k_seed", launch_seed(se, stream));
         } else {
             if (two_sweep) {
@@ -279,12 +279,12 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
                 f.colmax_out = w.mf.p; f.colarg_out = w.mfarg.p; f.cand = w.fcand.p; f.cand_cap = w.fcap; f.ncand_out = w.nf.p;
                 if (use_rec) { f.cand = nullptr; f.cand_cap = 0; f.frec = w.frec.p; f.frec_cap = w.frec_cap; f.ncand_out = w.nrec.p; }
                 f.dirs = w.fdirs.p; f.dirs_stride = fdirs_stride; f.count_cells = 1;
-                TIMED(T, "k_sweep_fwd", sweep(f, chunk));
+                TIMED(T, use16 ? "k_sweep16_fwd" : "k_sweep_fwd", sweep(f, chunk));
                 TIMED(T, "k_seed", launch_seed(se, stream));
             } else {
                 SweepArgs f1 = sa;
                 f1.rev = 0; f1.track_best = 1; f1.colmax_out = w.mf.p; f1.colarg_out = w.mfarg.p; f1.count_cells = 0;
-                TIMED(T, "k_sweep_fwd_colmax", sweep(f1, chunk));
+                TIMED(T, use16 ? "k_sweep16_fwd_colmax" : "k_sweep_fwd_colmax", sweep(f1, chunk));
                 TIMED(T, "k_seed", launch_seed(se, stream));
             }
             ThrArgs t1{w.state.p, w.mf.p, w.thr.p, wpad, p.base_rec_cost, 0};
@@ -292,7 +292,7 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
             SweepArgs r = sa;
             r.rev = 1; r.track_best = 1; r.thr = w.thr.p; r.colmax_out = w.wr.p; r.colarg_out = w.wrarg.p; r.cand = w.rcand.p; r.cand_cap = w.rcap; r.ncand_out = w.nr.p;
             r.dirs = w.rdirs.p; r.dirs_stride = rdirs_stride; r.count_cells = 1;
-            TIMED(T, "k_sweep_rev", sweep(r, chunk));
+            TIMED(T, use16 ? "k_sweep16_rev" : "k_sweep_rev", sweep(r, chunk));
             BoundArgs ba{gd, w.state.p, off, w.mf.p, w.mfarg.p, w.wr.p, w.wrarg.p, wpad, p.base_rec_cost, p.multi_rec_cost,
                          p.rec_band_width};
             TIMED(T, "k_bound", launch_bound(ba, chunk, stream));
@@ -302,9 +302,10 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
                 SweepArgs f2 = sa;
                 f2.rev = 0; f2.track_best = 1; f2.thr = w.thr.p; f2.cand = w.fcand.p; f2.cand_cap = w.fcap; f2.ncand_out = w.nf.p;
                 f2.dirs = w.fdirs.p; f2.dirs_stride = fdirs_stride; f2.count_cells = 1;
-                TIMED(T, "k_sweep_fwd", sweep(f2, chunk));
+                TIMED(T, use16 ? "k_sweep16_fwd" : "k_sweep_fwd", sweep(f2, chunk));
             }
             if (use_rec) {
+                HIPCHK(hipMemsetAsync(w.nf.p, 0, sizeof(unsigned) * chunk, stream));
                 ExpandArgs ea{w.state.p, w.frec.p, w.frec_cap, w.nrec.p, w.fcand.p, w.fcap, w.nf.p, w.wr.p, wpad, p.base_rec_cost};
                 TIMED(T, "k_expand", launch_expand(ea, chunk, C, stream));
             }

@@ -446,42 +446,41 @@ bool sweep16_admissible(const DevScores& sc, int max_path_rows, int max_n, int C
 
 // Forward (row, lane) records -> Cand list, filtered with the final bound (the same test k_search applies).
 template <int C>
-__global__ __launch_bounds__(64) void k_expand(ExpandArgs a) {
+__global__ __launch_bounds__(256) void k_expand(ExpandArgs a) {
     const int rd = blockIdx.x;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE, nwv = blockDim.x / WAVE;
     ReadState* rs = a.state + rd;
-    if (lane == 0) a.nf[rd] = 0;
-    __syncthreads();
     if (rs->status & (ST_BAD_BASE | ST_WOULD_PANIC)) return;
     const unsigned nrec = a.nrec[rd];
-    if (nrec > a.frec_cap) { if (lane == 0) rs->status |= ST_OVERFLOW; return; }
+    if (nrec > a.frec_cap) { if (threadIdx.x == 0) rs->status |= ST_OVERFLOW; return; }
     const int bound = rs->bound;
     const int* base = a.frec + (long long)rd * a.frec_cap * (4 + C);
     Cand* out = a.fcand + (long long)rd * a.fcap;
     const int* wr = a.wr + (long long)rd * a.wpad;
-    for (unsigned t = lane; t < nrec; t += WAVE) {
+    // C lanes per record (one key each): a wave load touches 64 / C records of 16 + 4 * C contiguous bytes
+    constexpr int RPW = WAVE / C;
+    const int q = lane % C, sub = lane / C;
+    for (unsigned t0 = wv * RPW; t0 < nrec; t0 += nwv * RPW) {      // latency-bound: several waves per read
+        const unsigned t = t0 + sub;
+        if (t >= nrec) continue;
         const int* rp = base + (long long)t * (4 + C);
         const int rl = rp[0];
-        unsigned em = (unsigned)rp[1];
-        const int row = rl >> 6, ln = rl & 63;
-        while (em) {
-            const int q = __ffs((int)em) - 1;
-            em &= em - 1;
-            const int key = rp[4 + q];
-            const int val = key >> 16, col = ln * C + q;
-            if (val + wr[col] - a.brc < bound) continue;
-            const unsigned pos = atomicAdd(&a.nf[rd], 1u);
-            if (pos < a.fcap) { Cand cd; cd.row = row; cd.col = col; cd.val = val; cd.path = key & 0xffff; out[pos] = cd; }
-        }
+        const unsigned em = (unsigned)rp[1];
+        if (!((em >> q) & 1)) continue;
+        const int key = rp[4 + q];
+        const int val = key >> 16, col = (rl & 63) * C + q;
+        if (val + wr[col] - a.brc < bound) continue;
+        const unsigned pos = atomicAdd(&a.nf[rd], 1u);
+        if (pos < a.fcap) { Cand cd; cd.row = rl >> 6; cd.col = col; cd.val = val; cd.path = key & 0xffff; out[pos] = cd; }
     }
 }
 
 void launch_expand(const ExpandArgs& a, int nreads, int C, hipStream_t s) {
     switch (C) {
-        case 4: hipLaunchKernelGGL((k_expand<4>), dim3(nreads), dim3(64), 0, s, a); break;
-        case 8: hipLaunchKernelGGL((k_expand<8>), dim3(nreads), dim3(64), 0, s, a); break;
-        case 16: hipLaunchKernelGGL((k_expand<16>), dim3(nreads), dim3(64), 0, s, a); break;
-        default: hipLaunchKernelGGL((k_expand<32>), dim3(nreads), dim3(64), 0, s, a); break;
+        case 4: hipLaunchKernelGGL((k_expand<4>), dim3(nreads), dim3(256), 0, s, a); break;
+        case 8: hipLaunchKernelGGL((k_expand<8>), dim3(nreads), dim3(256), 0, s, a); break;
+        case 16: hipLaunchKernelGGL((k_expand<16>), dim3(nreads), dim3(256), 0, s, a); break;
+        default: hipLaunchKernelGGL((k_expand<32>), dim3(nreads), dim3(256), 0, s, a); break;
     }
 }
 
