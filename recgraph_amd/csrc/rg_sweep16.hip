@@ -104,7 +104,9 @@ struct RowOps16 {
             row[r] = v;
             vprev = v;
         }
-        src = dpp_shr1(dpp_incl_max((lm & FULL) != FULL ? lane : -1, -1), 0);
+        // nearest lane to the left that owns a non-L column: highest set bit of the ballot below this lane (0 if none)
+        const unsigned long long have = __ballot((lm & FULL) != FULL) & ((1ull << lane) - 1ull);
+        src = have ? 63 - __clzll((long long)have) : 0;
         umask = um; lmask = lm;
     }
 
@@ -146,9 +148,14 @@ struct RowOps16 {
 
 }  // namespace
 
+#ifndef RG_SWEEP16_KRUN
+#define RG_SWEEP16_KRUN 4
+#endif
+
 template <int C>
 __global__ __launch_bounds__(64, 2) void k_sweep16(SweepArgs a) {
     constexpr int H = C / 2;
+    constexpr int KRUN = C <= 16 ? RG_SWEEP16_KRUN : 0;   // rows kept in registers across the inner rows of a segment
     const int rd = blockIdx.x;
     const int lane = threadIdx.x;
     const PathGraphDev& g = a.g;
@@ -182,6 +189,8 @@ __global__ __launch_bounds__(64, 2) void k_sweep16(SweepArgs a) {
     // per-column constants of this lane
     unsigned long long pcode[(H + 7) / 8] = {};   // 8 bits per register: code_lo | code_hi << 3
     int thrk[C];                         // emission threshold << 16 per column (INT32_MAX = never; columns that do not exist)
+    int minthrk = INT32_MAX;             // lowest threshold of the lane
+    const bool tight = a.thr != nullptr; // thresholds from the other sweep's column maxima
     const int oob = max((int)((float)(n + 1) * (1.0f - a.rbw) / 2.0f), 1);
     {
 #pragma unroll
@@ -201,6 +210,8 @@ __global__ __launch_bounds__(64, 2) void k_sweep16(SweepArgs a) {
             thrk[q] = th > 32767 ? INT32_MAX : (th < -32768 ? INT32_MIN : th * 65536);
         }
         // start rows: the gap-only row, identical for every path (uniform gap cost: c * gcost)
+#pragma unroll
+        for (int q = 0; q < C; ++q) minthrk = min(minthrk, thrk[q]);
         for (int k = 0; k < P; ++k) {
 #pragma unroll
             for (int r = 0; r < H; ++r) {
@@ -232,7 +243,19 @@ __global__ __launch_bounds__(64, 2) void k_sweep16(SweepArgs a) {
             const bool better = bkey[q] > max(ckey[q], kthr);
             ckey[q] = better ? bkey[q] : ckey[q];
             crow[q] = better ? i : crow[q];
-            emask |= (bkey[q] >= thrk[q] && bkey[q] > kthr) ? (1u << q) : 0u;
+        }
+        // tight thresholds (reverse sweep): most rows emit nothing; one max3 tree against the lane's lowest threshold
+        // decides for the whole wave whether the per-column test is needed
+        bool test = true;
+        if (tight) {
+            int mx = bkey[0];
+#pragma unroll
+            for (int q = 1; q < C; ++q) mx = max(mx, bkey[q]);
+            test = __any(mx >= minthrk);
+        }
+        if (test) {
+#pragma unroll
+            for (int q = 0; q < C; ++q) emask |= (bkey[q] >= thrk[q] && bkey[q] > kthr) ? (1u << q) : 0u;
         }
         if (a.frec) {
             // one fixed-size record per (row, lane) with any emission: 1 + C/4 16-byte stores instead of a Cand per cell
@@ -300,7 +323,12 @@ __global__ __launch_bounds__(64, 2) void k_sweep16(SweepArgs a) {
         gmask = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(recs.w, idx) << 32) |
                 (unsigned)__builtin_amdgcn_readlane(recs.z, idx);
     };
-    constexpr int F_FIRST = 1, F_LAST = 2;
+    constexpr int F_FIRST = 1, F_LAST = 2, F_INNER = 4;
+    // flags of record tt without consuming it (same or next batch)
+    auto peek_w0 = [&](int tt) -> int {
+        const int idx = tt & (WAVE - 1);
+        return idx == 0 && tt > 0 ? __builtin_amdgcn_readlane(recs_next.x, 0) : __builtin_amdgcn_readlane(recs.x, idx);
+    };
 
     // semiglobal end-row selection (see k_sweep)
     const bool semi_end = a.semi && !rev;
@@ -325,6 +353,13 @@ __global__ __launch_bounds__(64, 2) void k_sweep16(SweepArgs a) {
         }
         rowkey = INT32_MIN;
     };
+    auto set_keys = [&](int (&bkey)[C], const int (&row)[H], int k) {   // first member of a row: no reset + max
+#pragma unroll
+        for (int r = 0; r < H; ++r) {
+            bkey[r] = (int)(((unsigned)row[r] << 16) | (unsigned)k);
+            bkey[r + H] = (int)(((unsigned)row[r] & 0xffff0000u) | (unsigned)k);
+        }
+    };
     auto fold_keys = [&](int (&bkey)[C], const int (&row)[H], int k) {
 #pragma unroll
         for (int r = 0; r < H; ++r) {
@@ -347,13 +382,69 @@ __global__ __launch_bounds__(64, 2) void k_sweep16(SweepArgs a) {
         const int ga = (w0 >> 26) & 63;
         const int slot = w1 & 0xffffff;
         const int nm = __popcll(gmask);
+        if (KRUN > 0 && (flags & F_INNER) && nm <= KRUN) {
+            // ---- inner rows of a segment with a small group: the same paths, one group, predecessor = previous row.
+            // Their rows stay in registers for the whole run: no row load/store latency, no HBM traffic.  The group
+            // alpha of an inner row is its lowest path (alphas[row] == alphas[pred], rg_graph.cpp) = member 0.
+            int mk[KRUN > 0 ? KRUN : 1];
+            {
+                unsigned long long tm = gmask;
+#pragma unroll
+                for (int kk = 0; kk < KRUN; ++kk) { mk[kk] = tm ? __builtin_ctzll(tm) : 0; tm = tm ? (tm & (tm - 1)) : 0; }
+            }
+            int rr[KRUN > 0 ? KRUN : 1][H];
+#pragma unroll
+            for (int kk = 0; kk < KRUN; ++kk)
+                if (kk < nm) {
+#pragma unroll
+                    for (int r = 0; r < H; ++r) rr[kk][r] = rows[(long long)mk[kk] * wrow + r * WAVE + lane];
+                }
+            int ri = i, rli = li, rslot = slot, rw1 = w1;
+            while (true) {
+                const int g_i = __builtin_amdgcn_readfirstlane(sct[rli * 6 + GAP]);
+                const int g0 = a.semi ? 0 : g_i;
+#pragma unroll
+                for (int r = 0; r < H; ++r) s[r] = s2[rli * 64 + (int)((pcode[r / 8] >> (8 * (r % 8))) & 63)];
+                unsigned umask, lmask;
+                int src;
+                RowOps16<C>::alpha(rr[0], s, gcost, g_i, g0, lane, MU, ML, umask, lmask, src);
+                if (dirs) store_dirs(rslot, umask, lmask);
+#pragma unroll
+                for (int kk = 1; kk < KRUN; ++kk)
+                    if (kk < nm) RowOps16<C>::member(rr[kk], s, gcost, g_i, g0, lane, MU, ML, lmask, src);
+                cells += (unsigned long long)nm;
+                if (track) {
+                    set_keys(bkey, rr[0], mk[0]);
+#pragma unroll
+                    for (int kk = 1; kk < KRUN; ++kk) if (kk < nm) fold_keys(bkey, rr[kk], mk[kk]);
+                    row_end(ri, ((rw1 >> 24) & 127) - 1, bkey);
+                }
+                if (semi_end) {
+#pragma unroll
+                    for (int kk = 0; kk < KRUN; ++kk) if (kk < nm) end_fold(mk[kk], ri, rr[kk]);
+                    end_row_done(ri);
+                }
+                ++t;
+                if (t >= nsteps) break;
+                if (!((peek_w0(t) >> 23) & F_INNER)) break;     // next record starts another segment
+                int nw0, nw1;
+                unsigned long long ngm;
+                fetch(t, nw0, nw1, ngm);
+                ri = nw0 & 0xfffff; rli = (nw0 >> 20) & 7; rslot = nw1 & 0xffffff; rw1 = nw1;
+            }
+#pragma unroll
+            for (int kk = 0; kk < KRUN; ++kk)
+                if (kk < nm) {
+#pragma unroll
+                    for (int r = 0; r < H; ++r) rows[(long long)mk[kk] * wrow + r * WAVE + lane] = rr[kk][r];
+                }
+            continue;
+        }
         const int g_i = __builtin_amdgcn_readfirstlane(sct[li * 6 + GAP]);
         const int g0 = a.semi ? 0 : g_i;
         if (flags & F_FIRST) {
 #pragma unroll
             for (int r = 0; r < H; ++r) s[r] = s2[li * 64 + (int)((pcode[r / 8] >> (8 * (r % 8))) & 63)];
-#pragma unroll
-            for (int q = 0; q < C; ++q) bkey[q] = INT32_MIN;
         }
         {
             unsigned long long rest = gmask & ~(1ull << ga);
@@ -373,7 +464,7 @@ __global__ __launch_bounds__(64, 2) void k_sweep16(SweepArgs a) {
             RowOps16<C>::alpha(rowa, s, gcost, g_i, g0, lane, MU, ML, umask, lmask, src);
 #pragma unroll
             for (int r = 0; r < H; ++r) rows[(long long)ga * wrow + r * WAVE + lane] = rowa[r];
-            if (track) fold_keys(bkey, rowa, ga);
+            if (track) { if (flags & F_FIRST) set_keys(bkey, rowa, ga); else fold_keys(bkey, rowa, ga); }
             if (semi_end) end_fold(ga, i, rowa);
             if (dirs) store_dirs(slot, umask, lmask);
             while (knext >= 0) {
