@@ -257,9 +257,17 @@ class Batch:
         arr = None
         if names is not None:
             arr = (C.c_char_p * self.n)(*[x.encode() for x in names])
-        need = lib.rg_batch_format_all(self._h, arr, seq_index_base, None, 0, nthreads)
-        buf = C.create_string_buffer(need + 1)
-        lib.rg_batch_format_all(self._h, arr, seq_index_base, buf, need + 1, nthreads)
+        # one formatting pass when the buffer of the previous call (or the estimate) is large enough
+        cap = getattr(self, "_fmt_cap", 0) or (4096 + 2048 * self.n)
+        while True:
+            buf = C.create_string_buffer(cap)
+            need = lib.rg_batch_format_all(self._h, arr, seq_index_base, buf, cap, nthreads)
+            if need < 0:
+                raise _lib.RecGraphError(need, lib.rg_last_error().decode())
+            if need + 1 <= cap:
+                break
+            cap = need + 4096
+        self._fmt_cap = need + 4096
         return buf.raw[:need]
 
     @property

@@ -143,6 +143,7 @@ struct LayerArgs {
     long long dirs_stride;
     int dir_words;
     int dir_fmt;               // 0: 2 bits per column (k_sweep), 1: U mask | L mask (k_sweep16)
+    int pack16;                // layer stored as packed 16-bit pairs (columns q and q + C/2 of a lane per word)
     int semi;
     int* layer;                // [reads][layer_stride]
     long long layer_stride;
@@ -167,6 +168,7 @@ struct TraceArgs {
     int nreads;
     int mode;
     int semi;
+    int pack16;                // layers hold packed 16-bit pairs (see LayerArgs)
 };
 
 void launch_sweep(const SweepArgs& a, int nreads, int C, bool lds, hipStream_t s);

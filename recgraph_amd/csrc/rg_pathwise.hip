@@ -806,28 +806,56 @@ __global__ __launch_bounds__(64) void k_layer(LayerArgs a) {
     int* layer = a.layer + (long long)rd * a.layer_stride;
     int cur[C];
 #pragma unroll
-    for (int q = 0; q < C; ++q) { cur[q] = act[q] ? GP[q] : NEG; layer[q * WAVE + lane] = cur[q]; }
+    for (int q = 0; q < C; ++q) cur[q] = act[q] ? GP[q] : NEG;
+    // the layer is written once and read by one lane of k_trace: k_layer is bound by these stores, so they are
+    // packed to 16 bits (columns q and q + C/2 of the lane per word) whenever the sweep itself runs packed
+    constexpr int HL = C / 2;
+    auto store_row = [&](long long t) {
+        if (a.pack16) {
+#pragma unroll
+            for (int r = 0; r < HL; ++r)
+                layer[t * (HL * WAVE) + r * WAVE + lane] = (int)(((unsigned)cur[r + HL] << 16) | ((unsigned)cur[r] & 0xffffu));
+        } else {
+#pragma unroll
+            for (int q = 0; q < C; ++q) layer[t * wpad + q * WAVE + lane] = cur[q];
+        }
+    };
+    store_row(0);
     const int* prow = rev ? a.rprow : a.fprow;
     const int* pslot = rev ? a.rpslot : a.fpslot;
     const int* poff = rev ? a.rpoff : a.fpoff;
     const uint32_t* dirs = a.dirs + (long long)rd * a.dirs_stride;
     const int nrows = poff[path + 1] - poff[path];
+    // the row list, base codes and direction words of the next PF rows are fetched ahead: three dependent loads per
+    // row (row/slot -> base code, direction word) would otherwise serialise at full memory latency
+    constexpr int PF = 4;
+    int pf_li[PF];
+    uint32_t pf_w0[PF], pf_w1[PF];
+    auto prefetch = [&](int tt, int& li_o, uint32_t& w0_o, uint32_t& w1_o) {
+        li_o = 4; w0_o = 0; w1_o = 0;
+        if (tt < nrows) {
+            const int ii = prow[poff[path] + tt];
+            const int sl = pslot[poff[path] + tt];
+            li_o = g.lnz[ii];
+            w0_o = dirs[(long long)sl * a.dir_words + lane];
+            if (C > 16) w1_o = dirs[(long long)sl * a.dir_words + WAVE + lane];
+        }
+    };
+#pragma unroll
+    for (int k = 0; k < PF; ++k) prefetch(k, pf_li[k], pf_w0[k], pf_w1[k]);
     for (int t = 0; t < nrows; ++t) {
-        const int i = prow[poff[path] + t];
-        const int slot = pslot[poff[path] + t];
-        const int li = g.lnz[i];
+        const int li = pf_li[0];
+        const uint32_t word0 = pf_w0[0], word1 = pf_w1[0];
+#pragma unroll
+        for (int k = 0; k + 1 < PF; ++k) { pf_li[k] = pf_li[k + 1]; pf_w0[k] = pf_w0[k + 1]; pf_w1[k] = pf_w1[k + 1]; }
+        prefetch(t + PF, pf_li[PF - 1], pf_w0[PF - 1], pf_w1[PF - 1]);
         const int g_i = sct[li * 6 + GAP];
         unsigned dmask = 0, lmask = 0;
         if (a.dir_fmt == 1) {
-            if (C <= 16) {
-                const uint32_t wv = dirs[(long long)slot * a.dir_words + lane];
-                dmask = ~wv & 0xffffu; lmask = wv >> 16;
-            } else {
-                dmask = ~dirs[(long long)slot * a.dir_words + lane];
-                lmask = dirs[(long long)slot * a.dir_words + WAVE + lane];
-            }
+            if (C <= 16) { dmask = ~word0 & 0xffffu; lmask = word0 >> 16; }
+            else { dmask = ~word0; lmask = word1; }
         } else if (C <= 16) {
-            const uint32_t wv = dirs[(long long)slot * a.dir_words + lane];
+            const uint32_t wv = word0;
 #pragma unroll
             for (int q = 0; q < C; ++q) {
                 const uint32_t dc = (wv >> (2 * q)) & 3u;
@@ -837,7 +865,7 @@ __global__ __launch_bounds__(64) void k_layer(LayerArgs a) {
         } else {
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                const uint32_t wv = dirs[(long long)slot * a.dir_words + h * WAVE + lane];
+                const uint32_t wv = h == 0 ? word0 : word1;
 #pragma unroll
                 for (int q = 0; q < 16; ++q) {
                     const uint32_t dc = (wv >> (2 * q)) & 3u;
@@ -867,15 +895,15 @@ __global__ __launch_bounds__(64) void k_layer(LayerArgs a) {
         for (int q = 0; q < C; ++q) {
             if ((lmask >> q) & 1) y[q] = run; else run = y[q];
             cur[q] = act[q] ? y[q] + GP[q] : NEG;
-            layer[(long long)(t + 1) * wpad + q * WAVE + lane] = cur[q];
         }
+        store_row(t + 1);
     }
 }
 
 // ---------------------------------------------------------------------------------
 // Traceback on the rebuilt layers (pathwise_alignment_output.rs:32-138, recombination_output.rs:
 // 391-470, 480-557, 659-736).  One lane per read walks; ops only (rows are re-derived on the host).
-template <int C>
+template <int C, bool kPack>
 __global__ __launch_bounds__(64) void k_trace(TraceArgs a) {
     const int rd = blockIdx.x * blockDim.x + threadIdx.x;
     if (rd >= a.nreads) return;
@@ -895,7 +923,14 @@ __global__ __launch_bounds__(64) void k_trace(TraceArgs a) {
     uint8_t* ops = a.ops + (long long)rd * a.ops_stride;
     int nops = 0;
     const bool recomb = (a.mode == RG_MODE_RECOMBINATION || a.mode == RG_MODE_RECOMBINATION_SEMI) && rs->fwd_path != rs->rev_path;
-    auto at = [&](const int* layer, int idx, int c) { return layer[(long long)idx * wpad + (c % C) * WAVE + c / C]; };
+    auto at = [&](const int* layer, int idx, int c) -> int {
+        if (kPack) {
+            const int q = c % C;
+            const int w = layer[(long long)idx * (C / 2 * WAVE) + (q % (C / 2)) * WAVE + c / C];
+            return q >= C / 2 ? (w >> 16) : (int)(short)(w & 0xffff);
+        }
+        return layer[(long long)idx * wpad + (c % C) * WAVE + c / C];
+    };
     const int* fl = a.flayer + (long long)rd * a.layer_stride;
     // ---- forward walk from (row, j) back to the source on path fp ----
     const int fp = rs->fwd_path;
@@ -1025,14 +1060,19 @@ void launch_layer(const LayerArgs& a, int nreads, int C, hipStream_t s) {
         default: hipLaunchKernelGGL((k_layer<32>), dim3(nreads), dim3(64), 0, s, a); break;
     }
 }
-void launch_trace(const TraceArgs& a, int C, hipStream_t s) {
+template <bool kPack>
+static void launch_trace_p(const TraceArgs& a, int C, hipStream_t s) {
     const dim3 grid((a.nreads + 63) / 64), blk(64);
     switch (C) {
-        case 4: hipLaunchKernelGGL((k_trace<4>), grid, blk, 0, s, a); break;
-        case 8: hipLaunchKernelGGL((k_trace<8>), grid, blk, 0, s, a); break;
-        case 16: hipLaunchKernelGGL((k_trace<16>), grid, blk, 0, s, a); break;
-        default: hipLaunchKernelGGL((k_trace<32>), grid, blk, 0, s, a); break;
+        case 4: hipLaunchKernelGGL((k_trace<4, kPack>), grid, blk, 0, s, a); break;
+        case 8: hipLaunchKernelGGL((k_trace<8, kPack>), grid, blk, 0, s, a); break;
+        case 16: hipLaunchKernelGGL((k_trace<16, kPack>), grid, blk, 0, s, a); break;
+        default: hipLaunchKernelGGL((k_trace<32, kPack>), grid, blk, 0, s, a); break;
     }
+}
+void launch_trace(const TraceArgs& a, int C, hipStream_t s) {
+    if (a.pack16) launch_trace_p<true>(a, C, s);
+    else launch_trace_p<false>(a, C, s);
 }
 
 }  // namespace rg
