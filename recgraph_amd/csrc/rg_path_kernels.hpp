@@ -72,6 +72,7 @@ struct ExpandArgs {
     const int* wr;
     int wpad;
     int brc;
+    const int* knm;            // per row: highest path id NOT through the row (-1 if none)
 };
 
 struct SeedArgs {

@@ -631,6 +631,9 @@ __global__ __launch_bounds__(64) void k_bound(BoundArgs a) {
         const int fa = a.mfarg[o], ra = a.wrarg[o];
         const int fi = fa >> 8, fk = fa & 255, ri = ra >> 8, rk = ra & 255;
         if (fk == rk || g.node_id[fi] == g.node_id[ri]) continue;
+        // the packed sweep records column maxima without the "winner must be a member path" rule: re-check here
+        const int kf = g.knm[fi], kr = g.knm[ri];
+        if ((kf >= 0 && ((m << 16) | fk) <= kf) || (kr >= 0 && ((w << 16) | rk) <= kr)) continue;
         const int disp = abs(g.dfs[fi] - g.dfs[ri]) + abs(g.dfe[fi] - g.dfe[ri]);
         const float sc = __fsub_rn((float)(m + w), __fadd_rn((float)a.brc, __fmul_rn(a.mrc, (float)disp)));
         best = fmaxf(best, sc);

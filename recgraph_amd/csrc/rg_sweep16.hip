@@ -236,11 +236,14 @@ __global__ __launch_bounds__(64, 2) void k_sweep16(SweepArgs a) {
     // exists -> bkey > kthr with kthr = knm (>= 0) or INT32_MIN).  ckey keeps the best usable key per column and the
     // row it came from; emission compares against thr << 16.
     auto row_end = [&](int i, int knm, const int (&bkey)[C]) {
+        // The column maxima ignore that rule (k_bound re-checks the recorded cell; an unusable cell has value <= 0 and
+        // can only raise a non-positive maximum, which loosens thresholds, never tightens them); emissions apply it
+        // (it removes most of the negative-valued cells the loose forward thresholds would let through).
         const int kthr = knm >= 0 ? knm : INT32_MIN;
         unsigned emask = 0;
 #pragma unroll
         for (int q = 0; q < C; ++q) {
-            const bool better = bkey[q] > max(ckey[q], kthr);
+            const bool better = bkey[q] > ckey[q];
             ckey[q] = better ? bkey[q] : ckey[q];
             crow[q] = better ? i : crow[q];
         }
@@ -254,8 +257,9 @@ __global__ __launch_bounds__(64, 2) void k_sweep16(SweepArgs a) {
             test = __any(mx >= minthrk);
         }
         if (test) {
+            // bkey >= thr and bkey > kthr in one compare (kthr + 1 does not overflow: kthr is INT32_MIN or < 64)
 #pragma unroll
-            for (int q = 0; q < C; ++q) emask |= (bkey[q] >= thrk[q] && bkey[q] > kthr) ? (1u << q) : 0u;
+            for (int q = 0; q < C; ++q) emask |= bkey[q] >= max(thrk[q], kthr + 1) ? (1u << q) : 0u;
         }
         if (a.frec) {
             // one fixed-size record per (row, lane) with any emission: 1 + C/4 16-byte stores instead of a Cand per cell
@@ -561,6 +565,8 @@ __global__ __launch_bounds__(256) void k_expand(ExpandArgs a) {
         const int key = rp[4 + q];
         const int val = key >> 16, col = (rl & 63) * C + q;
         if (val + wr[col] - a.brc < bound) continue;
+        const int knm = a.knm[rl >> 6];
+        if (knm >= 0 && key <= knm) continue;        // winner of the cell is not a member path: the reference's entry is 0
         const unsigned pos = atomicAdd(&a.nf[rd], 1u);
         if (pos < a.fcap) { Cand cd; cd.row = rl >> 6; cd.col = col; cd.val = val; cd.path = key & 0xffff; out[pos] = cd; }
     }
