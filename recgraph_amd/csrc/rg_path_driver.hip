@@ -200,7 +200,7 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
         w.nrsteps = (int)st.size();
         w.tables = true;
     }
-    const long long layer_stride = (long long)(h.max_path_rows + 2) * wpad;
+    const long long layer_stride = (long long)(h.max_path_rows + 2) * dir_words;   // traceback decisions: 2 bits per cell
     const long long fdirs_stride = (long long)h.fslots * dir_words;
     const long long rdirs_stride = (long long)h.rslots * dir_words;
     // reads per chunk: bounded by a memory budget for the per-read work buffers
@@ -352,7 +352,7 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
         LayerArgs la;
         memset(&la, 0, sizeof la);
         la.semi = semi ? 1 : 0;
-        la.g = gd; la.sc = sa.sc; la.reads = d_reads; la.read_off = off; la.state = w.state.p; la.dir_words = dir_words; la.dir_fmt = use16 ? 1 : 0; la.pack16 = use16 ? 1 : 0;
+        la.g = gd; la.sc = sa.sc; la.reads = d_reads; la.read_off = off; la.state = w.state.p; la.dir_words = dir_words; la.dir_fmt = use16 ? 1 : 0;
         la.layer_stride = layer_stride; la.fpoff = w.fpoff.p; la.fprow = w.fprow.p; la.fpslot = w.fpslot.p;
         la.rpoff = w.rpoff.p; la.rprow = w.rprow.p; la.rpslot = w.rpslot.p;
         la.rev = 0; la.dirs = w.fdirs.p; la.dirs_stride = fdirs_stride; la.layer = w.flayer.p;
@@ -366,7 +366,7 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
         ta.g = gd; ta.sc = sa.sc; ta.reads = d_reads; ta.read_off = off; ta.state = w.state.p; ta.rec = d_rec + done;
         ta.ops = d_ops + (long long)done * ops_stride; ta.ops_stride = ops_stride; ta.flayer = w.flayer.p;
         ta.rlayer = w.rlayer.p; ta.layer_stride = layer_stride; ta.fpoff = w.fpoff.p; ta.fprow = w.fprow.p;
-        ta.rpoff = w.rpoff.p; ta.rprow = w.rprow.p; ta.nreads = chunk; ta.mode = pmode; ta.semi = semi ? 1 : 0; ta.pack16 = use16 ? 1 : 0;
+        ta.rpoff = w.rpoff.p; ta.rprow = w.rprow.p; ta.nreads = chunk; ta.mode = pmode; ta.semi = semi ? 1 : 0;
         TIMED(T, "k_trace", launch_trace(ta, C, stream));
         if ((rc = T.collect(stats))) return rc;
         HIPCHK(hipMemcpy(&cells_done, d_cells, sizeof cells_done, hipMemcpyDeviceToHost));

@@ -15,6 +15,7 @@ struct ReadState {
     float fscore;
     int bound;         // integer lower bound of the final search maximum (>= s0), tightens the pruning
     int sink_val[64];  // A[sink row][n][k]; semiglobal: best last-column value of path k over its rows >= 1
+    int trace_score;        // value of the forward layer where the traceback starts (written by k_layer)
     int path_end_row[64];   // semiglobal: first row attaining sink_val[k] (ending_node, pathwise_alignment_recombination.rs:885-897)
 };
 
@@ -138,15 +139,14 @@ struct LayerArgs {
     DevScores sc;
     const uint8_t* reads;
     const long long* read_off;
-    const ReadState* state;
+    ReadState* state;
     int rev;
     const uint32_t* dirs;
     long long dirs_stride;
     int dir_words;
     int dir_fmt;               // 0: 2 bits per column (k_sweep), 1: U mask | L mask (k_sweep16)
-    int pack16;                // layer stored as packed 16-bit pairs (columns q and q + C/2 of a lane per word)
     int semi;
-    int* layer;                // [reads][layer_stride]
+    int* layer;                // [reads][layer_stride]: traceback decisions, (rows of the path + 1) x dir_words words
     long long layer_stride;
     const int* fpoff; const int* fprow; const int* fpslot;   // rows of every path, forward order
     const int* rpoff; const int* rprow; const int* rpslot;   // rows of every path, reverse order
@@ -169,7 +169,6 @@ struct TraceArgs {
     int nreads;
     int mode;
     int semi;
-    int pack16;                // layers hold packed 16-bit pairs (see LayerArgs)
 };
 
 void launch_sweep(const SweepArgs& a, int nreads, int C, bool lds, hipStream_t s);

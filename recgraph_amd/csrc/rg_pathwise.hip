@@ -767,19 +767,23 @@ __global__ __launch_bounds__(64) void k_search(SearchArgs a) {
 }
 
 // ---------------------------------------------------------------------------------
-// Rebuild the absolute layer of one path from the direction words (rows of that path only).
-// layer[idx] for idx = 0 (start row) .. number of path rows, stored [q][lane] like the rolling rows.
+// Rebuild the absolute layer of one path from the direction words (rows of that path only) and record, per cell, the
+// move the reference's traceback takes there.  The traceback re-derives d, u, l from the chosen path's own layer
+// (pathwise_alignment_output.rs:32-110, recombination_output.rs:391-470, 659-736): d = A[t-1][j-1] + s(row, read[j]),
+// u = A[t-1][j] + s(row, '-'), l = A[t][j-1] + s('-', read[j]), D if max == d, else U if max == u, else L.  All three
+// are in registers while the row is rebuilt, so the kernel stores 2 bits per cell (tdir[t][lane] words, 1 = D, 2 = U,
+// 3 = L) instead of the layer itself: 16x fewer bytes, and k_trace reads one word per step instead of three values.
 template <int C>
 __global__ __launch_bounds__(64) void k_layer(LayerArgs a) {
     const int rd = blockIdx.x;
     const int lane = threadIdx.x;
     const PathGraphDev& g = a.g;
-    const ReadState* rs = a.state + rd;
+    ReadState* rs = a.state + rd;
     if (rs->status & (ST_BAD_BASE | ST_WOULD_PANIC | ST_OVERFLOW)) return;
     const bool rev = a.rev;
     const int path = rev ? rs->rev_path : rs->fwd_path;
-    if (rev && rs->fwd_path == rs->rev_path) return;  // no recombination: reverse layer not needed
-    const int wpad = C * WAVE;
+    const bool recomb = rs->fwd_path != rs->rev_path;
+    if (rev && !recomb) return;  // no recombination: reverse layer not needed
     const long long ro = a.read_off[rd];
     const int n = (int)(a.read_off[rd + 1] - ro);
     const uint8_t* read = a.reads + ro - 1;
@@ -806,52 +810,45 @@ __global__ __launch_bounds__(64) void k_layer(LayerArgs a) {
 #pragma unroll
         for (int q = 0; q < C; ++q) GP[q] += pre;
     }
-    int* layer = a.layer + (long long)rd * a.layer_stride;
+    int gl[C];                     // s('-', read base of the column): row-invariant
+#pragma unroll
+    for (int q = 0; q < C; ++q) gl[q] = sct[GAP * 6 + er[q]];
+    uint32_t* tdir = reinterpret_cast<uint32_t*>(a.layer) + (long long)rd * a.layer_stride;
     int cur[C];
 #pragma unroll
     for (int q = 0; q < C; ++q) cur[q] = act[q] ? GP[q] : NEG;
-    // the layer is written once and read by one lane of k_trace: k_layer is bound by these stores, so they are
-    // packed to 16 bits (columns q and q + C/2 of the lane per word) whenever the sweep itself runs packed
-    constexpr int HL = C / 2;
-    auto store_row = [&](long long t) {
-        if (a.pack16) {
-#pragma unroll
-            for (int r = 0; r < HL; ++r)
-                layer[t * (HL * WAVE) + r * WAVE + lane] = (int)(((unsigned)cur[r + HL] << 16) | ((unsigned)cur[r] & 0xffffu));
-        } else {
-#pragma unroll
-            for (int q = 0; q < C; ++q) layer[t * wpad + q * WAVE + lane] = cur[q];
-        }
-    };
-    store_row(0);
     const int* prow = rev ? a.rprow : a.fprow;
     const int* pslot = rev ? a.rpslot : a.fpslot;
     const int* poff = rev ? a.rpoff : a.fpoff;
     const uint32_t* dirs = a.dirs + (long long)rd * a.dirs_stride;
     const int nrows = poff[path + 1] - poff[path];
+    // forward layer: the score the record reports is the layer value where the walk starts
+    const int start_row = recomb ? rs->fen : rs->end_row;
+    const int start_col = recomb ? rs->rec_col : n;
     // the row list, base codes and direction words of the next PF rows are fetched ahead: three dependent loads per
     // row (row/slot -> base code, direction word) would otherwise serialise at full memory latency
     constexpr int PF = 4;
-    int pf_li[PF];
+    int pf_li[PF], pf_row[PF];
     uint32_t pf_w0[PF], pf_w1[PF];
-    auto prefetch = [&](int tt, int& li_o, uint32_t& w0_o, uint32_t& w1_o) {
-        li_o = 4; w0_o = 0; w1_o = 0;
+    auto prefetch = [&](int tt, int& li_o, int& row_o, uint32_t& w0_o, uint32_t& w1_o) {
+        li_o = 4; row_o = -1; w0_o = 0; w1_o = 0;
         if (tt < nrows) {
             const int ii = prow[poff[path] + tt];
             const int sl = pslot[poff[path] + tt];
+            row_o = ii;
             li_o = g.lnz[ii];
             w0_o = dirs[(long long)sl * a.dir_words + lane];
             if (C > 16) w1_o = dirs[(long long)sl * a.dir_words + WAVE + lane];
         }
     };
 #pragma unroll
-    for (int k = 0; k < PF; ++k) prefetch(k, pf_li[k], pf_w0[k], pf_w1[k]);
+    for (int k = 0; k < PF; ++k) prefetch(k, pf_li[k], pf_row[k], pf_w0[k], pf_w1[k]);
     for (int t = 0; t < nrows; ++t) {
-        const int li = pf_li[0];
+        const int li = pf_li[0], irow = pf_row[0];
         const uint32_t word0 = pf_w0[0], word1 = pf_w1[0];
 #pragma unroll
-        for (int k = 0; k + 1 < PF; ++k) { pf_li[k] = pf_li[k + 1]; pf_w0[k] = pf_w0[k + 1]; pf_w1[k] = pf_w1[k + 1]; }
-        prefetch(t + PF, pf_li[PF - 1], pf_w0[PF - 1], pf_w1[PF - 1]);
+        for (int k = 0; k + 1 < PF; ++k) { pf_li[k] = pf_li[k + 1]; pf_row[k] = pf_row[k + 1]; pf_w0[k] = pf_w0[k + 1]; pf_w1[k] = pf_w1[k + 1]; }
+        prefetch(t + PF, pf_li[PF - 1], pf_row[PF - 1], pf_w0[PF - 1], pf_w1[PF - 1]);
         const int g_i = sct[li * 6 + GAP];
         unsigned dmask = 0, lmask = 0;
         if (a.dir_fmt == 1) {
@@ -883,12 +880,16 @@ __global__ __launch_bounds__(64) void k_layer(LayerArgs a) {
         const bool any_nonl = ((~lmask) & actmask) != 0;
         const int src = dpp_shr1(dpp_incl_max(any_nonl ? lane : -1, -1), 0);
         const int pk = dpp_shr1(cur[C - 1], NEG);
+        int old[C];
         int y[C];
+        int sq[C];
         int last = NEG;
 #pragma unroll
         for (int q = 0; q < C; ++q) {
+            old[q] = cur[q];
+            sq[q] = sct[li * 6 + er[q]];
             const int om1 = q == 0 ? pk : cur[q - 1];
-            const int base = ((dmask >> q) & 1) ? om1 + sct[li * 6 + er[q]] : cur[q] + ((a.semi && q == 0 && lane == 0) ? 0 : g_i);
+            const int base = ((dmask >> q) & 1) ? om1 + sq[q] : cur[q] + ((a.semi && q == 0 && lane == 0) ? 0 : g_i);
             y[q] = base - GP[q];
             if (!((lmask >> q) & 1) && act[q]) last = y[q];
         }
@@ -899,42 +900,59 @@ __global__ __launch_bounds__(64) void k_layer(LayerArgs a) {
             if ((lmask >> q) & 1) y[q] = run; else run = y[q];
             cur[q] = act[q] ? y[q] + GP[q] : NEG;
         }
-        store_row(t + 1);
+        // ---- traceback decisions of this row ----
+        // the reverse matrix keeps its start row (row L-1) delta-encoded in the reference (absolute_scores skips it):
+        // path 0 reads its absolute value there, every other path reads 0 (pathwise_alignment_recombination.rs:748)
+        const bool zero_prev = rev && t == 0 && path != 0;
+        const int nk = dpp_shr1(cur[C - 1], NEG);          // new value of column c-1 for the lane's first column
+        uint32_t tw[C <= 16 ? 1 : 2] = {};
+#pragma unroll
+        for (int q = 0; q < C; ++q) {
+            const int o1 = zero_prev ? 0 : (q == 0 ? pk : old[q - 1]);
+            const int o0 = zero_prev ? 0 : old[q];
+            const int d = o1 + sq[q];
+            const int u = o0 + g_i;
+            const int l = (q == 0 ? nk : cur[q - 1]) + gl[q];   // key ('-', seq[j])
+            const int mx = max(max(d, u), l);
+            const uint32_t code = mx == d ? 1u : (mx == u ? 2u : 3u);
+            tw[q / 16] |= code << (2 * (q % 16));
+        }
+        tdir[(long long)(t + 1) * a.dir_words + lane] = tw[0];
+        if (C > 16) tdir[(long long)(t + 1) * a.dir_words + WAVE + lane] = tw[C <= 16 ? 0 : 1];
+        if (!rev && irow == start_row) {
+            int v = 0;
+#pragma unroll
+            for (int q = 0; q < C; ++q) if (q == start_col % C) v = cur[q];
+            if (lane == start_col / C) rs->trace_score = v;
+        }
     }
 }
 
 // ---------------------------------------------------------------------------------
-// Traceback on the rebuilt layers (pathwise_alignment_output.rs:32-138, recombination_output.rs:
-// 391-470, 480-557, 659-736).  One lane per read walks; ops only (rows are re-derived on the host).
-template <int C, bool kPack>
+// Traceback over the decisions recorded by k_layer.  One lane per read walks; ops only (rows are re-derived on the
+// host).
+template <int C>
 __global__ __launch_bounds__(64) void k_trace(TraceArgs a) {
     const int rd = blockIdx.x * blockDim.x + threadIdx.x;
     if (rd >= a.nreads) return;
-    const PathGraphDev& g = a.g;
     ReadState* rs = a.state + rd;
     DevRecord* rec = a.rec + rd;
     if (rs->status & (ST_BAD_BASE | ST_WOULD_PANIC | ST_OVERFLOW)) {
         rec->status = rs->status; rec->n_ops = 0; rec->n_fwd_ops = 0; rec->score = 0;
         return;
     }
-    const int wpad = C * WAVE;
     const long long ro = a.read_off[rd];
     const int n = (int)(a.read_off[rd + 1] - ro);
-    const uint8_t* read = a.reads + ro - 1;
-    const int GAP = 5;
-    const int L = g.L;
     uint8_t* ops = a.ops + (long long)rd * a.ops_stride;
     int nops = 0;
     const bool recomb = (a.mode == RG_MODE_RECOMBINATION || a.mode == RG_MODE_RECOMBINATION_SEMI) && rs->fwd_path != rs->rev_path;
-    auto at = [&](const int* layer, int idx, int c) -> int {
-        if (kPack) {
-            const int q = c % C;
-            const int w = layer[(long long)idx * (C / 2 * WAVE) + (q % (C / 2)) * WAVE + c / C];
-            return q >= C / 2 ? (w >> 16) : (int)(short)(w & 0xffff);
-        }
-        return layer[(long long)idx * wpad + (c % C) * WAVE + c / C];
+    const int dw = WAVE * (C <= 16 ? 1 : 2);
+    // decision of layer row idx at (mirrored) column c
+    auto move = [&](const uint32_t* td, int idx, int c) -> uint32_t {
+        const int q = c % C;
+        return (td[(long long)idx * dw + (q / 16) * WAVE + c / C] >> (2 * (q % 16))) & 3u;
     };
-    const int* fl = a.flayer + (long long)rd * a.layer_stride;
+    const uint32_t* fl = reinterpret_cast<const uint32_t*>(a.flayer) + (long long)rd * a.layer_stride;
     // ---- forward walk from (row, j) back to the source on path fp ----
     const int fp = rs->fwd_path;
     const int fbeg = a.fpoff[fp], fnr = a.fpoff[fp + 1] - fbeg;
@@ -945,53 +963,35 @@ __global__ __launch_bounds__(64) void k_trace(TraceArgs a) {
     while (lo <= hi) { int mid = (lo + hi) >> 1; int r = a.fprow[fbeg + mid]; if (r == start_row) { idx = mid; break; } if (r < start_row) lo = mid + 1; else hi = mid - 1; }
     if (idx < 0) { rec->status = ST_WOULD_PANIC; rec->n_ops = 0; return; }
     int t = idx + 1;  // layer index of the current row (0 = row 0)
-    const int score = at(fl, t, j);
+    const int score = rs->trace_score;
     while (t > 0 && j > 0) {
-        const int i = a.fprow[fbeg + t - 1];
-        const int li = g.lnz[i];
-        const int d = at(fl, t - 1, j - 1) + a.sc.t[li * 6 + read[j]];
-        const int u = at(fl, t - 1, j) + a.sc.t[li * 6 + GAP];
-        const int l = at(fl, t, j - 1) + a.sc.t[GAP * 6 + read[j]];   // key ('-', seq[j])
-        const int mx = max(max(d, u), l);
-        if (mx == d) { ops[nops++] = OP_D; t -= 1; j -= 1; }
-        else if (mx == u) { ops[nops++] = OP_U; t -= 1; }
+        const uint32_t mv = move(fl, t, j);
+        if (mv == 1u) { ops[nops++] = OP_D; t -= 1; j -= 1; }
+        else if (mv == 2u) { ops[nops++] = OP_U; t -= 1; }
         else { ops[nops++] = OP_L; j -= 1; }
     }
     while (j > 0) { ops[nops++] = OP_L; j -= 1; }
     while (!a.semi && t > 0) { ops[nops++] = OP_U; t -= 1; }   // semiglobal: the alignment may start inside the graph
     const int nfwd = nops;
     if (recomb) {
-        // ---- reverse walk from (rsn, rec_col) forward to the sink on path rp ----
+        // ---- reverse walk from (rsn, rec_col) forward to the sink on path rp (mirrored columns c' = n - jj) ----
         const int rp = rs->rev_path;
-        const int* rl = a.rlayer + (long long)rd * a.layer_stride;
+        const uint32_t* rl = reinterpret_cast<const uint32_t*>(a.rlayer) + (long long)rd * a.layer_stride;
         const int rbeg = a.rpoff[rp], rnr = a.rpoff[rp + 1] - rbeg;
         // rows of the reverse program are descending
         int lo2 = 0, hi2 = rnr - 1, ridx = -1;
         while (lo2 <= hi2) { int mid = (lo2 + hi2) >> 1; int r = a.rprow[rbeg + mid]; if (r == rs->rsn) { ridx = mid; break; } if (r > rs->rsn) lo2 = mid + 1; else hi2 = mid - 1; }
         if (ridx < 0) { rec->status = ST_WOULD_PANIC; rec->n_ops = 0; return; }
         int tt = ridx + 1;          // layer index (0 = row L-1)
-        int jj = rs->rec_col;       // real column; mirrored column c' = n - jj
-        // row L-1 of w stays delta-encoded in the reference (absolute_scores skips it): path 0 keeps its
-        // absolute value, every other path reads 0 (pathwise_alignment_recombination.rs:748)
-        auto wat = [&](int lidx, int col) -> int {
-            if (lidx == 0) return rp == 0 ? at(rl, 0, n - col) : 0;
-            return at(rl, lidx, n - col);
-        };
+        int jj = rs->rec_col;       // real column
         while (tt > 0 && jj < n) {
-            const int i = a.rprow[rbeg + tt - 1];
-            const int li = g.lnz[i];
-            const int rc = read[jj + 1];                       // r_seq[jj]
-            const int d = wat(tt - 1, jj + 1) + a.sc.t[li * 6 + rc];
-            const int u = wat(tt - 1, jj) + a.sc.t[li * 6 + GAP];
-            const int l = wat(tt, jj + 1) + a.sc.t[GAP * 6 + rc];
-            const int mx = max(max(d, u), l);
-            if (mx == d) { ops[nops++] = OP_D; tt -= 1; jj += 1; }
-            else if (mx == u) { ops[nops++] = OP_U; tt -= 1; }
+            const uint32_t mv = move(rl, tt, n - jj);
+            if (mv == 1u) { ops[nops++] = OP_D; tt -= 1; jj += 1; }
+            else if (mv == 2u) { ops[nops++] = OP_U; tt -= 1; }
             else { ops[nops++] = OP_L; jj += 1; }
         }
         while (jj < n) { ops[nops++] = OP_L | OP_CONT; jj += 1; }
         while (!a.semi && tt > 0) { ops[nops++] = OP_U | OP_CONT; tt -= 1; }
-        (void)L;
     }
     rec->status = rs->status;
     rec->score = score;
@@ -1063,19 +1063,14 @@ void launch_layer(const LayerArgs& a, int nreads, int C, hipStream_t s) {
         default: hipLaunchKernelGGL((k_layer<32>), dim3(nreads), dim3(64), 0, s, a); break;
     }
 }
-template <bool kPack>
-static void launch_trace_p(const TraceArgs& a, int C, hipStream_t s) {
+void launch_trace(const TraceArgs& a, int C, hipStream_t s) {
     const dim3 grid((a.nreads + 63) / 64), blk(64);
     switch (C) {
-        case 4: hipLaunchKernelGGL((k_trace<4, kPack>), grid, blk, 0, s, a); break;
-        case 8: hipLaunchKernelGGL((k_trace<8, kPack>), grid, blk, 0, s, a); break;
-        case 16: hipLaunchKernelGGL((k_trace<16, kPack>), grid, blk, 0, s, a); break;
-        default: hipLaunchKernelGGL((k_trace<32, kPack>), grid, blk, 0, s, a); break;
+        case 4: hipLaunchKernelGGL((k_trace<4>), grid, blk, 0, s, a); break;
+        case 8: hipLaunchKernelGGL((k_trace<8>), grid, blk, 0, s, a); break;
+        case 16: hipLaunchKernelGGL((k_trace<16>), grid, blk, 0, s, a); break;
+        default: hipLaunchKernelGGL((k_trace<32>), grid, blk, 0, s, a); break;
     }
-}
-void launch_trace(const TraceArgs& a, int C, hipStream_t s) {
-    if (a.pack16) launch_trace_p<true>(a, C, s);
-    else launch_trace_p<false>(a, C, s);
 }
 
 }  // namespace rg
