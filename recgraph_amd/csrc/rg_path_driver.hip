@@ -47,9 +47,9 @@ struct PathWorkImpl {
     Buf<int> roll, mf, wr, mfarg, wrarg, thr, flayer, rlayer;
     Buf<uint32_t> fdirs, rdirs;
     Buf<Cand> fcand, rcand;
-    Buf<unsigned> nf, nr, ridx, nrec;
-    Buf<int> frec;
-    unsigned frec_cap = 0;
+    Buf<unsigned> nf, nr, ridx, nrec, nrrec;
+    Buf<int> frec, rrec;
+    unsigned frec_cap = 0, rrec_cap = 0;
     Buf<int> lb;
     Buf<int4> fsteps, rsteps;
     int nfsteps = 0, nrsteps = 0;
@@ -225,7 +225,7 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
     // (row, lane) records that k_expand filters with the final bound; k_sweep writes plain Cand entries
     const bool use_rec = two_sweep && use16 && !getenv("RG_NO_FREC");
     const int recw = 4 + C;
-    if (w.fcap == 0) { w.fcap = (two_sweep && !use_rec) ? 1u << 20 : 1u << 15; w.rcap = 1u << 19; w.frec_cap = 1u << 16; }
+    if (w.fcap == 0) { w.fcap = (two_sweep && !use_rec) ? 1u << 20 : 1u << 15; w.rcap = 1u << 19; w.frec_cap = 1u << 16; w.rrec_cap = 1u << 14; }
     stats.clear();
     HIPCHK(hipMemsetAsync(d_cells, 0, sizeof(unsigned long long), stream));
     Timer T{&w, stream};
@@ -233,7 +233,7 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
     unsigned long long cells_done = 0;
     while (done < nreads) {
         const size_t per_read_all = per_read + (mode == RG_MODE_RECOMBINATION ? ((size_t)w.fcap * sizeof(Cand) + (size_t)w.rcap * (sizeof(Cand) + 4) +
-                                                                                     (use_rec ? (size_t)w.frec_cap * recw * 4 : 0)) : 0);
+                                                                                     (use_rec ? (size_t)(w.frec_cap + w.rrec_cap) * recw * 4 : 0)) : 0);
         int maxchunk = (int)std::min<size_t>(8192, std::max<size_t>(1, budget / per_read_all));
         const int left = nreads - done;
         const int nchunks = (left + maxchunk - 1) / maxchunk;
@@ -250,7 +250,9 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
                 (rc = w.rcand.alloc((size_t)chunk * w.rcap)) || (rc = w.ridx.alloc((size_t)chunk * w.rcap)) ||
                 (rc = w.nf.alloc(chunk)) || (rc = w.nr.alloc(chunk)) || (rc = w.lb.alloc(chunk)) || (rc = w.nrec.alloc(chunk)))
                 return rc;
-            if (use_rec && (rc = w.frec.alloc((size_t)chunk * w.frec_cap * recw))) return rc;
+            if (use_rec && ((rc = w.frec.alloc((size_t)chunk * w.frec_cap * recw)) || (rc = w.rrec.alloc((size_t)chunk * w.rrec_cap * recw)) ||
+                            (rc = w.nrrec.alloc(chunk))))
+                return rc;
         }
         const uint8_t* bad = d_bad + done;
         const long long* off = d_off + done;
@@ -291,6 +293,7 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
             TIMED(T, "k_threshold", launch_threshold(t1, chunk, stream));
             SweepArgs r = sa;
             r.rev = 1; r.track_best = 1; r.thr = w.thr.p; r.colmax_out = w.wr.p; r.colarg_out = w.wrarg.p; r.cand = w.rcand.p; r.cand_cap = w.rcap; r.ncand_out = w.nr.p;
+            if (use_rec) { r.cand = nullptr; r.cand_cap = 0; r.frec = w.rrec.p; r.frec_cap = w.rrec_cap; r.ncand_out = w.nrrec.p; }
             r.dirs = w.rdirs.p; r.dirs_stride = rdirs_stride; r.count_cells = 1;
             TIMED(T, use16 ? "k_sweep16_rev" : "k_sweep_rev", sweep(r, chunk));
             BoundArgs ba{gd, w.state.p, off, w.mf.p, w.mfarg.p, w.wr.p, w.wrarg.p, wpad, p.base_rec_cost, p.multi_rec_cost,
@@ -306,8 +309,11 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
             }
             if (use_rec) {
                 HIPCHK(hipMemsetAsync(w.nf.p, 0, sizeof(unsigned) * chunk, stream));
-                ExpandArgs ea{w.state.p, w.frec.p, w.frec_cap, w.nrec.p, w.fcand.p, w.fcap, w.nf.p, w.wr.p, wpad, p.base_rec_cost, gd.knm};
+                HIPCHK(hipMemsetAsync(w.nr.p, 0, sizeof(unsigned) * chunk, stream));
+                ExpandArgs ea{w.state.p, w.frec.p, w.frec_cap, w.nrec.p, w.fcand.p, w.fcap, w.nf.p, w.wr.p, wpad, p.base_rec_cost, gd.knm, 0, off};
                 TIMED(T, "k_expand", launch_expand(ea, chunk, C, stream));
+                ExpandArgs er{w.state.p, w.rrec.p, w.rrec_cap, w.nrrec.p, w.rcand.p, w.rcap, w.nr.p, w.mf.p, wpad, p.base_rec_cost, gd.knm, 1, off};
+                TIMED(T, "k_expand", launch_expand(er, chunk, C, stream));
             }
             SearchArgs sr{gd, w.state.p, w.fcand.p, w.rcand.p, w.nf.p, w.nr.p, w.ridx.p, w.fcap, w.rcap, w.wr.p, wpad, p.base_rec_cost,
                           p.multi_rec_cost};
@@ -325,6 +331,18 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
                 unsigned long long sc = 0;
                 for (int i = 0; i < chunk; ++i) { needrec = std::max(needrec, hc[i]); sc += hc[i]; }
                 if (getenv("RG_DEBUG")) fprintf(stderr, "[rg] forward records mean %.1f max %u (cap %u)\n", (double)sc / chunk, needrec, w.frec_cap);
+                HIPCHK(hipMemcpy(hc.data(), w.nrrec.p, sizeof(unsigned) * chunk, hipMemcpyDeviceToHost));
+                unsigned needrrec = 0;
+                sc = 0;
+                for (int i = 0; i < chunk; ++i) { needrrec = std::max(needrrec, hc[i]); sc += hc[i]; }
+                if (getenv("RG_DEBUG")) fprintf(stderr, "[rg] reverse records mean %.1f max %u (cap %u)\n", (double)sc / chunk, needrrec, w.rrec_cap);
+                if (needrrec > w.rrec_cap) {
+                    const unsigned long long fullrec = (unsigned long long)L * WAVE;
+                    if (w.rrec_cap >= fullrec) return fail(RG_ERR_CAPACITY, "reverse record list overflow at full size");
+                    while (w.rrec_cap < needrrec) w.rrec_cap = (unsigned)std::min<unsigned long long>(2ull * w.rrec_cap, fullrec);
+                    HIPCHK(hipMemcpy(d_cells, &cells_done, sizeof cells_done, hipMemcpyHostToDevice));
+                    continue;
+                }
                 if (needrec > w.frec_cap) {
                     const unsigned long long fullrec = (unsigned long long)L * WAVE;
                     if (w.frec_cap >= fullrec) return fail(RG_ERR_CAPACITY, "forward record list overflow at full size");

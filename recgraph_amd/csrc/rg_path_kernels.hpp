@@ -54,8 +54,7 @@ struct SweepArgs {
     unsigned long long* cells;
     int count_cells;
     int oob;                   // unused (computed per read from rbw)
-    // k_sweep16, forward sweep of the two-sweep pipeline: loose emissions go out as one record per (row, lane) instead
-    // of one Cand per cell: (4 + C) ints = {row << 6 | lane, column mask, 0, 0, key[C]} with key = value << 16 | path
+    // k_sweep16, two-sweep pipeline: emissions go out as one record per (row, lane) instead of one Cand per cell: (4 + C) ints = {row << 6 | lane, column mask, 0, 0, key[C]} with key = value << 16 | path
     int* frec;                 // [reads][frec_cap][4 + C] or null
     unsigned frec_cap;
 };
@@ -64,16 +63,18 @@ struct SweepArgs {
 // the final bound with the best reverse partner of their column
 struct ExpandArgs {
     ReadState* state;
-    const int* frec;
+    const int* frec;           // records of this sweep
     unsigned frec_cap;
     const unsigned* nrec;
-    Cand* fcand;
+    Cand* fcand;               // out: Cand list of this sweep
     unsigned fcap;
     unsigned* nf;
-    const int* wr;
+    const int* wr;             // [reads][wpad] column maxima of the OTHER sweep (best possible partner per column)
     int wpad;
     int brc;
     const int* knm;            // per row: highest path id NOT through the row (-1 if none)
+    int rev;                   // records of the reverse sweep: lane columns are mirrored (real column = n - c)
+    const long long* read_off;
 };
 
 struct SeedArgs {

@@ -549,6 +549,7 @@ __global__ __launch_bounds__(256) void k_expand(ExpandArgs a) {
     const unsigned nrec = a.nrec[rd];
     if (nrec > a.frec_cap) { if (threadIdx.x == 0) rs->status |= ST_OVERFLOW; return; }
     const int bound = rs->bound;
+    const int nread = (int)(a.read_off[rd + 1] - a.read_off[rd]);
     const int* base = a.frec + (long long)rd * a.frec_cap * (4 + C);
     Cand* out = a.fcand + (long long)rd * a.fcap;
     const int* wr = a.wr + (long long)rd * a.wpad;
@@ -563,7 +564,8 @@ __global__ __launch_bounds__(256) void k_expand(ExpandArgs a) {
         const unsigned em = (unsigned)rp[1];
         if (!((em >> q) & 1)) continue;
         const int key = rp[4 + q];
-        const int val = key >> 16, col = (rl & 63) * C + q;
+        const int val = key >> 16, cc = (rl & 63) * C + q;
+        const int col = a.rev ? nread - cc : cc;
         if (val + wr[col] - a.brc < bound) continue;
         const int knm = a.knm[rl >> 6];
         if (knm >= 0 && key <= knm) continue;        // winner of the cell is not a member path: the reference's entry is 0
