@@ -75,6 +75,7 @@ struct ExpandArgs {
     const int* knm;            // per row: highest path id NOT through the row (-1 if none)
     int rev;                   // records of the reverse sweep: lane columns are mirrored (real column = n - c)
     const long long* read_off;
+    float rbw;                 // -B
 };
 
 struct SeedArgs {

@@ -256,27 +256,34 @@ __global__ __launch_bounds__(64, 2) void k_sweep16(SweepArgs a) {
             for (int q = 1; q < C; ++q) mx = max(mx, bkey[q]);
             test = __any(mx >= minthrk);
         }
-        if (test) {
-            // bkey >= thr and bkey > kthr in one compare (kthr + 1 does not overflow: kthr is INT32_MIN or < 64)
-#pragma unroll
-            for (int q = 0; q < C; ++q) emask |= bkey[q] >= max(thrk[q], kthr + 1) ? (1u << q) : 0u;
-        }
         if (a.frec) {
-            // one fixed-size record per (row, lane) with any emission: 1 + C/4 16-byte stores instead of a Cand per cell
-            if (__any(emask != 0)) {
-                const int has = emask != 0 ? 1 : 0;
-                const int incl = dpp_incl_sum(has);
-                const int total = __shfl(incl, WAVE - 1, WAVE);
-                const unsigned pos = ncand + (unsigned)(incl - has);
-                if (has && pos < a.frec_cap) {
+            // One fixed-size record per (row, lane) with any column above its threshold (1 + C/4 16-byte stores);
+            // k_expand re-tests every key with the final bound, which implies the threshold, so no per-lane column
+            // mask is needed: the compares only feed a ballot (VALU compare + scalar OR per column).
+            unsigned long long has = 0;
+            if (test) {
+                // bkey >= thr and bkey > kthr in one compare (kthr + 1 does not overflow: kthr is INT32_MIN or < 64)
+#pragma unroll
+                for (int q = 0; q < C; ++q) has |= __ballot(bkey[q] >= max(thrk[q], kthr + 1));
+            }
+            if (has) {
+                const unsigned before = __builtin_amdgcn_mbcnt_hi((unsigned)(has >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)has, 0u));
+                const unsigned pos = ncand + before;
+                if (((has >> lane) & 1ull) && pos < a.frec_cap) {
                     int4* rp = reinterpret_cast<int4*>(a.frec + ((long long)rd * a.frec_cap + pos) * (4 + C));
-                    rp[0] = make_int4((i << 6) | lane, (int)emask, 0, 0);
+                    rp[0] = make_int4((i << 6) | lane, 0, 0, 0);
 #pragma unroll
                     for (int q4 = 0; q4 < C / 4; ++q4) rp[1 + q4] = make_int4(bkey[4 * q4], bkey[4 * q4 + 1], bkey[4 * q4 + 2], bkey[4 * q4 + 3]);
                 }
-                ncand += (unsigned)total;
+                ncand += (unsigned)__popcll(has);
             }
-        } else if (cand && __any(emask != 0)) {
+            return;
+        }
+        if (test) {
+#pragma unroll
+            for (int q = 0; q < C; ++q) emask |= bkey[q] >= max(thrk[q], kthr + 1) ? (1u << q) : 0u;
+        }
+        if (cand && __any(emask != 0)) {
             const int cnt = __popc(emask);
             const int incl = dpp_incl_sum(cnt);
             const int total = __shfl(incl, WAVE - 1, WAVE);
@@ -550,6 +557,7 @@ __global__ __launch_bounds__(256) void k_expand(ExpandArgs a) {
     if (nrec > a.frec_cap) { if (threadIdx.x == 0) rs->status |= ST_OVERFLOW; return; }
     const int bound = rs->bound;
     const int nread = (int)(a.read_off[rd + 1] - a.read_off[rd]);
+    const int oob = max((int)((float)(nread + 1) * (1.0f - a.rbw) / 2.0f), 1);
     const int* base = a.frec + (long long)rd * a.frec_cap * (4 + C);
     Cand* out = a.fcand + (long long)rd * a.fcap;
     const int* wr = a.wr + (long long)rd * a.wpad;
@@ -561,12 +569,12 @@ __global__ __launch_bounds__(256) void k_expand(ExpandArgs a) {
         if (t >= nrec) continue;
         const int* rp = base + (long long)t * (4 + C);
         const int rl = rp[0];
-        const unsigned em = (unsigned)rp[1];
-        if (!((em >> q) & 1)) continue;
         const int key = rp[4 + q];
         const int val = key >> 16, cc = (rl & 63) * C + q;
+        if (cc >= (a.rev ? nread : nread + 1)) continue;               // column does not exist: the key is garbage
         const int col = a.rev ? nread - cc : cc;
-        if (val + wr[col] - a.brc < bound) continue;
+        if (col < oob || col >= nread + 1 - oob) continue;             // outside the recombination band (-B)
+        if (val + wr[col] - a.brc < bound) continue;                   // implies the sweep's emission threshold
         const int knm = a.knm[rl >> 6];
         if (knm >= 0 && key <= knm) continue;        // winner of the cell is not a member path: the reference's entry is 0
         const unsigned pos = atomicAdd(&a.nf[rd], 1u);
