@@ -19,9 +19,11 @@ using namespace rg;
 #define HIPCHK(x)                                                                                       \
     do {                                                                                                \
         hipError_t e_ = (x);                                                                            \
-        if (e_ != hipSuccess)                                                                           \
+        if (e_ != hipSuccess) {                                                                         \
+            (void)hipGetLastError(); /* clears the sticky error: the handle stays usable after a failed call */ \
             return fail(e_ == hipErrorNoDevice || e_ == hipErrorInvalidDevice ? RG_ERR_NO_DEVICE : RG_ERR_HIP, \
                         std::string(#x) + ": " + hipGetErrorString(e_));                                \
+        }                                                                                               \
     } while (0)
 
 template <typename T>

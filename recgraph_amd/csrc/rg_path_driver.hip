@@ -16,7 +16,7 @@ namespace rg {
 #define HIPCHK(x)                                                                            \
     do {                                                                                     \
         hipError_t e_ = (x);                                                                 \
-        if (e_ != hipSuccess) return fail(RG_ERR_HIP, std::string(#x) + ": " + hipGetErrorString(e_)); \
+        if (e_ != hipSuccess) { (void)hipGetLastError(); /* clears the sticky error */ return fail(RG_ERR_HIP, std::string(#x) + ": " + hipGetErrorString(e_)); } \
     } while (0)
 
 template <typename T>
@@ -225,7 +225,7 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
     // (row, lane) records that k_expand filters with the final bound; k_sweep writes plain Cand entries
     const bool use_rec = two_sweep && use16 && !getenv("RG_NO_FREC");
     const int recw = 4 + C;
-    if (w.fcap == 0) { w.fcap = (two_sweep && !use_rec) ? 1u << 20 : 1u << 15; w.rcap = 1u << 19; w.frec_cap = 1u << 16; w.rrec_cap = 1u << 14; }
+    if (w.fcap == 0) { w.fcap = (two_sweep && !use_rec) ? 1u << 20 : 1u << 15; w.rcap = use_rec ? 1u << 16 : 1u << 19; w.frec_cap = 1u << 16; w.rrec_cap = 1u << 14; }
     stats.clear();
     HIPCHK(hipMemsetAsync(d_cells, 0, sizeof(unsigned long long), stream));
     Timer T{&w, stream};
