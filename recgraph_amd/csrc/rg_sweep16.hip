@@ -364,14 +364,20 @@ __global__ __launch_bounds__(64, 2) void k_sweep16(SweepArgs a) {
         }
         rowkey = INT32_MIN;
     };
-    auto set_keys = [&](int (&bkey)[C], const int (&row)[H], int k) {   // first member of a row: no reset + max
+    // The path id goes through a VGPR: a gfx9 VALU instruction takes one scalar operand, so (row & 0xffff0000) | k
+    // is a single v_and_or_b32 only if the mask is the scalar and k a vector register.
+    auto set_keys = [&](int (&bkey)[C], const int (&row)[H], int ks) {   // first member of a row: no reset + max
+        int k = ks;
+        asm volatile("" : "+v"(k));
 #pragma unroll
         for (int r = 0; r < H; ++r) {
             bkey[r] = (int)(((unsigned)row[r] << 16) | (unsigned)k);
             bkey[r + H] = (int)(((unsigned)row[r] & 0xffff0000u) | (unsigned)k);
         }
     };
-    auto fold_keys = [&](int (&bkey)[C], const int (&row)[H], int k) {
+    auto fold_keys = [&](int (&bkey)[C], const int (&row)[H], int ks) {
+        int k = ks;
+        asm volatile("" : "+v"(k));
 #pragma unroll
         for (int r = 0; r < H; ++r) {
             // key = value << 16 | path: one v_lshl_or_b32 / v_and_or_b32 per column
