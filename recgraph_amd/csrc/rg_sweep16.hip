@@ -567,24 +567,29 @@ __global__ __launch_bounds__(256) void k_expand(ExpandArgs a) {
     const int* base = a.frec + (long long)rd * a.frec_cap * (4 + C);
     Cand* out = a.fcand + (long long)rd * a.fcap;
     const int* wr = a.wr + (long long)rd * a.wpad;
-    // C lanes per record (one key each): a wave load touches 64 / C records of 16 + 4 * C contiguous bytes
-    constexpr int RPW = WAVE / C;
-    const int q = lane % C, sub = lane / C;
+    // C / 4 lanes per record, one 16-byte load of four keys each: a wave iteration covers 256 / C records
+    constexpr int LPR = C / 4, RPW = WAVE / LPR;
+    const int part = lane % LPR, sub = lane / LPR;
     for (unsigned t0 = wv * RPW; t0 < nrec; t0 += nwv * RPW) {      // latency-bound: several waves per read
         const unsigned t = t0 + sub;
         if (t >= nrec) continue;
         const int* rp = base + (long long)t * (4 + C);
         const int rl = rp[0];
-        const int key = rp[4 + q];
-        const int val = key >> 16, cc = (rl & 63) * C + q;
-        if (cc >= (a.rev ? nread : nread + 1)) continue;               // column does not exist: the key is garbage
-        const int col = a.rev ? nread - cc : cc;
-        if (col < oob || col >= nread + 1 - oob) continue;             // outside the recombination band (-B)
-        if (val + wr[col] - a.brc < bound) continue;                   // implies the sweep's emission threshold
+        const int4 k4 = *reinterpret_cast<const int4*>(rp + 4 + 4 * part);
+        const int keys[4] = {k4.x, k4.y, k4.z, k4.w};
         const int knm = a.knm[rl >> 6];
-        if (knm >= 0 && key <= knm) continue;        // winner of the cell is not a member path: the reference's entry is 0
-        const unsigned pos = atomicAdd(&a.nf[rd], 1u);
-        if (pos < a.fcap) { Cand cd; cd.row = rl >> 6; cd.col = col; cd.val = val; cd.path = key & 0xffff; out[pos] = cd; }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int key = keys[e];
+            const int val = key >> 16, cc = (rl & 63) * C + 4 * part + e;
+            if (cc >= (a.rev ? nread : nread + 1)) continue;               // column does not exist: the key is garbage
+            const int col = a.rev ? nread - cc : cc;
+            if (col < oob || col >= nread + 1 - oob) continue;             // outside the recombination band (-B)
+            if (val + wr[col] - a.brc < bound) continue;                   // implies the sweep's emission threshold
+            if (knm >= 0 && key <= knm) continue;        // winner of the cell is not a member path: the reference's entry is 0
+            const unsigned pos = atomicAdd(&a.nf[rd], 1u);
+            if (pos < a.fcap) { Cand cd; cd.row = rl >> 6; cd.col = col; cd.val = val; cd.path = key & 0xffff; out[pos] = cd; }
+        }
     }
 }
 
