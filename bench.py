@@ -3,9 +3,10 @@
 
 Workload (BASELINE.json configs[4], the configuration the north-star target is quoted on):
 -m 8 recombination alignment (R=4 r=0.1 B=1) of synthetic 1 kbp reads against a fixed synthetic
-~10 k-row / 32-path graph.  A "step" is one pass of the hot path (three DP sweeps, search, layer rebuild,
-traceback on the device, record fetch and GAF formatting on the host) over one batch of reads already
-resident in HBM.  Reads shard across ranks (one process per GPU, no data-path collective); the GAF text
+~10 k-row / 32-path graph.  A "step" is one pass of the hot path (two DP sweeps, candidate expansion, search,
+layer rebuild and traceback on the device, record fetch and GAF formatting on the host) over one batch of reads
+already resident in HBM; consecutive steps alternate between two batch handles so that the device part of one step
+overlaps the host formatting of the previous one.  Reads shard across ranks (one process per GPU, no data-path collective); the GAF text
 of every rank is gathered to rank 0 once at the end over RCCL.
 
 Prints ONE JSON line on rank 0.
