@@ -86,6 +86,18 @@ __device__ __forceinline__ int dpp_incl_sum(int v) {
     return v;
 }
 
+// Wave-uniform load of read-only data through the scalar cache (s_load_dword): on gfx9 vector loads and stores share
+// one in-order counter (vmcnt), so a uniform table lookup issued as a vector load makes the wave wait for all of its
+// earlier stores.  Only for memory no kernel in flight writes (graph tables, score-derived tables).
+__device__ __forceinline__ int uload(const int* p) {
+    return *reinterpret_cast<const __attribute__((address_space(4))) int*>(reinterpret_cast<uintptr_t>(p));
+}
+__device__ __forceinline__ int uload_u8(const uint8_t* base, int i) {
+    const uintptr_t a = reinterpret_cast<uintptr_t>(base) + (uintptr_t)i;
+    const int w = *reinterpret_cast<const __attribute__((address_space(4))) int*>(a & ~(uintptr_t)3);
+    return (w >> (8 * (int)(a & 3))) & 0xff;
+}
+
 __device__ __forceinline__ long long wave_max_ll(long long v) {
 #pragma unroll
     for (int d = WAVE / 2; d >= 1; d >>= 1) {

@@ -62,6 +62,7 @@ __device__ __forceinline__ int m_at(const M0Ctx& x, int p, int c) {
     return x.min_score;
 }
 
+template <bool kLdsRead>
 __global__ __launch_bounds__(64) void k_m0_simd(PoaArgs a) {
     const int rd = blockIdx.x;
     const int lane = threadIdx.x;
@@ -69,7 +70,18 @@ __global__ __launch_bounds__(64) void k_m0_simd(PoaArgs a) {
     const int L = g.L;
     const long long ro = a.read_off[rd];
     const int n = (int)(a.read_off[rd + 1] - ro);
-    const uint8_t* read = a.reads + ro - 1;  // read[j], j = 1..n
+    const uint8_t* gread = a.reads + ro - 1;  // read_at(j), j = 1..n
+    // Score table and (when it fits) the read's base codes live in LDS: both are indexed per lane every row, and as
+    // kernel-argument / global loads each lookup was a dependent memory round trip (78 % of the wave cycles waiting).
+    extern __shared__ int m0_lds[];
+    int* sct = m0_lds;                                       // [36]
+    uint8_t* lread = reinterpret_cast<uint8_t*>(m0_lds + 36);   // [n + 1] when a.lds_read
+    if (lane < 36) sct[lane] = a.sc.t[lane];
+    if (kLdsRead)
+        for (int j = 1 + lane; j <= n; j += WAVE) lread[j] = gread[j];
+    __syncthreads();
+    // (a run-time choice between the two pointers would turn every access into a FLAT load)
+    auto read_at = [&](int j) -> int { return kLdsRead ? (int)lread[j] : (int)gread[j]; };
     DevRecord* rec = a.rec + rd;
     const int W = n + 1;
     if (a.bad[rd]) {
@@ -81,12 +93,14 @@ __global__ __launch_bounds__(64) void k_m0_simd(PoaArgs a) {
     int4* rinfo = a.rinfo + (long long)rd * L;
     const unsigned long long bta = (unsigned long long)a.bta[rd];
     const int GAP = 5;
-    M0Ctx cx{am, rinfo, a.col0, 2 * W * sc_at(a.sc, read[1], GAP)};  // global_abpoa.rs:20
+    M0Ctx cx{am, rinfo, a.col0, 2 * W * sct[read_at(1) * 6 + GAP]};  // global_abpoa.rs:20
     long long off = 0;
     unsigned long long ncells = 0;
     bool overflow = false;
 
     // ---- row 0 (global_abpoa.rs:47-61) ----
+    unsigned long long rinfo_right0 = 0;
+    int row0_val[4] = {};           // m[0][64 k + lane] for the first four chunks of row 0
     {
         unsigned long long left, right;
         band_simd(0, 0, 0, g.r_values[0], (unsigned long long)W, bta, left, right);
@@ -95,26 +109,66 @@ __global__ __launch_bounds__(64) void k_m0_simd(PoaArgs a) {
             int carry = 0;
             for (int cb = 0; cb < (int)right; cb += WAVE) {
                 int c = cb + lane;
-                int gc = (c >= 1 && c < (int)right) ? sc_at(a.sc, read[c], GAP) : 0;
+                int gc = (c >= 1 && c < (int)right) ? sct[read_at(c) * 6 + GAP] : 0;
                 int s = wave_incl_sum(gc, lane) + carry;
                 if (c < (int)right) { am[c] = s; apw[c] = (c == 0) ? 0u : 3u; }  // path 0.3 -> (pred 0, L)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) if (cb == k * WAVE) row0_val[k] = s;
                 carry = __shfl(s, WAVE - 1, WAVE);
             }
         }
         if (lane == 0) rinfo[0] = make_int4(0, 0, (int)right, 0);
         off = (long long)right;
+        rinfo_right0 = right;
     }
-    __syncthreads();
+    // The previous row travels in registers (chunk k, lane l holds column p_start + 64 k + l) whenever it fits KC chunks: a row whose only
+    // predecessor is the row above - all rows inside a segment - then needs no load at all, its stores are fire and
+    // forget, and the per-row metadata is fetched one row ahead.  Rows with listed predecessors (segment starts) and bands
+    // wider than 64 columns take the memory path below; a barrier orders this wave's earlier stores before those loads.
+    constexpr int KC = 4;           // up to 256 band columns per row
+    int pv[KC] = {};                // values of the previous row
+    int p_start = 0, p_right = (int)rinfo_right0, p_best = 0;
+    bool p_valid = (int)rinfo_right0 <= KC * WAVE;
+#pragma unroll
+    for (int k = 0; k < KC; ++k) pv[k] = row0_val[k];
+    // chunk k of the previous row (k is wave-uniform; a select chain instead of a dynamically indexed register array)
+    auto pv_chunk = [&](int k) -> int {
+        int r = pv[0];
+#pragma unroll
+        for (int kk = 1; kk < KC; ++kk) r = k == kk ? pv[kk] : r;
+        return r;
+    };
+    // m[i-1][col] of the reference's full-width matrix for this lane's column `col` (chunk base k0 is wave-uniform)
+    auto prev_at = [&](int col, int k0, int lo, int hi) -> int {
+        const int idx = col - p_start;
+        const int sh_lo = __shfl(lo, idx & (WAVE - 1), WAVE), sh_hi = __shfl(hi, idx & (WAVE - 1), WAVE);
+        const int v = (idx >> 6) == k0 ? sh_lo : sh_hi;
+        return (col >= p_start && col < p_right) ? v : cx.min_score;
+    };
+    bool dirty = true;              // stores issued since the last barrier
+    int c0_prev = 0;                // col0[i - 1]
+    // metadata of the next row, loaded one iteration ahead
+    int n_pb = uload(g.pred_off + 1), n_pe = L > 2 ? uload(g.pred_off + 2) : n_pb;
+    int n_li = L > 2 ? uload_u8(g.lnz, 1) : 4, n_rv = L > 2 ? uload(g.r_values + 1) : 0, n_c0 = L > 2 ? uload(a.col0 + 1) : 0;
+    int n_p0 = n_pe > n_pb ? uload(g.pred_rows + n_pb) : -1;   // first listed predecessor of the next row
 
     // ---- rows 1..L-2 (global_abpoa.rs:63-226) ----
     for (int i = 1; i + 1 < L && !overflow; ++i) {
-        const int pb = g.pred_off[i], pe = g.pred_off[i + 1];
+        const int pb = n_pb, pe = n_pe, li = n_li, rv = n_rv, c0_cur = n_c0, p0_cur = n_p0;
+        if (i + 2 < L) {
+            n_pb = pe; n_pe = uload(g.pred_off + i + 2); n_li = uload_u8(g.lnz, i + 1); n_rv = uload(g.r_values + i + 1);
+            n_c0 = uload(a.col0 + i + 1);
+            n_p0 = n_pe > n_pb ? uload(g.pred_rows + n_pb) : -1;
+        }
         const bool nwp = pe > pb;
+        // a listed predecessor list that is just {i - 1} (chains of single-base segments) behaves like an inner row
+        const bool only_prev = !nwp || (pe - pb == 1 && p0_cur == i - 1);
         unsigned long long ms, me;
-        if (!nwp) {
-            unsigned long long pl = (unsigned long long)rinfo[i - 1].w;
+        if (only_prev) {
+            const unsigned long long pl = (unsigned long long)p_best;   // best_scoring_pos of row i - 1
             ms = pl + 1; me = pl + 1;
         } else {
+            if (dirty) { __syncthreads(); dirty = false; }
             unsigned long long pl = 0, pr = 0;
             for (int e = pb; e < pe; ++e) {
                 unsigned long long cb = (unsigned long long)rinfo[g.pred_rows[e]].w;
@@ -125,59 +179,73 @@ __global__ __launch_bounds__(64) void k_m0_simd(PoaArgs a) {
             ms = pl + 1; me = pr + 1;
         }
         unsigned long long left64, right64;
-        band_simd(i, ms, me, g.r_values[i], (unsigned long long)W, bta, left64, right64);
+        band_simd(i, ms, me, rv, (unsigned long long)W, bta, left64, right64);
         const int left = (int)left64, right = (int)right64;
         const int start = left == 0 ? 1 : left;
         const int end = right == W ? ((right - start) / 8) * 8 + start : right;
         const int width = right - start;
         if (off + width > a.cap_cells) { overflow = true; break; }
-        const int li = g.lnz[i];
-        const int g_row = sc_at(a.sc, li, GAP);
+        const int g_row = sct[li * 6 + GAP];
+        const bool fast = only_prev && p_valid && width <= KC * WAVE;
+        if (!fast && dirty) { __syncthreads(); dirty = false; }
         // running state of the left sweep: z = v - G (see DESIGN.md "m0 left sweep as a scan")
-        int carry_z = (start - 1 == 0) ? a.col0[i] : cx.min_score;
+        int carry_z = (start - 1 == 0) ? c0_cur : cx.min_score;
         int carry_G = 0;
-        long long best_key = left == 0 ? (((long long)a.col0[i] << 32) | 0u) : (((long long)INT32_MIN << 32) | (unsigned)left);
-        for (int cb = start; cb < right; cb += WAVE) {
+        int best_v = left == 0 ? c0_cur : INT32_MIN, best_c = left == 0 ? 0 : left;
+        int v_keep[KC] = {};
+        int ci = 0;
+        for (int cb = start; cb < right; cb += WAVE, ++ci) {
             const int c = cb + lane;
             const bool act = c < right;
             const bool simd = c < end;
             int b = INT32_MIN / 2, gc = 0;
             uint32_t pw = 0;
+            int bu = 0, bd = 0, pu = i - 1, pd = i - 1;
+            if (fast) {
+                // m[i-1][c] and m[i-1][c-1] of the reference's full-width matrix, from the registers of the row above
+                // columns cb-1 .. cb+63 of the row above lie in at most two of its chunks: k0 and k0 + 1
+                const int k0 = (cb - 1 - p_start) >> 6;             // arithmetic shift: -1 when cb - 1 < p_start
+                const int lo = pv_chunk(k0 < 0 ? 0 : k0), hi = pv_chunk(k0 + 1 < KC ? k0 + 1 : KC - 1);
+                bu = prev_at(c, k0, lo, hi);
+                const int dprev = prev_at(c - 1, k0, lo, hi);     // (the shuffles inside must run with all lanes enabled)
+                bd = (c - 1 == 0 && i - 1 > 0) ? c0_prev : dprev;
+            }
             if (act) {
-                const int rc = read[c];
-                int bu, bd, pu, pd;
-                if (!nwp) {
-                    bu = m_at(cx, i - 1, c); bd = m_at(cx, i - 1, c - 1); pu = pd = i - 1;
-                } else {
-                    int p0 = g.pred_rows[pb];
-                    bu = m_at(cx, p0, c); bd = m_at(cx, p0, c - 1); pu = pd = p0;
-                    for (int e = pb + 1; e < pe; ++e) {  // strict '>' : first predecessor wins ties (:127-139)
-                        int p = g.pred_rows[e];
-                        int u = m_at(cx, p, c), d = m_at(cx, p, c - 1);
-                        if (u > bu) { bu = u; pu = p; }
-                        if (d > bd) { bd = d; pd = p; }
+                const int rc = read_at(c);
+                if (!fast) {
+                    if (!nwp) {
+                        bu = m_at(cx, i - 1, c); bd = m_at(cx, i - 1, c - 1);
+                    } else {
+                        int p0 = g.pred_rows[pb];
+                        bu = m_at(cx, p0, c); bd = m_at(cx, p0, c - 1); pu = pd = p0;
+                        for (int e = pb + 1; e < pe; ++e) {  // strict '>' : first predecessor wins ties (:127-139)
+                            int p = g.pred_rows[e];
+                            int u = m_at(cx, p, c), d = m_at(cx, p, c - 1);
+                            if (u > bu) { bu = u; pu = p; }
+                            if (d > bd) { bd = d; pd = p; }
+                        }
                     }
                 }
                 const int us = bu + g_row;
                 if (simd) {
-                    const int ds = bd + sc_at(a.sc, li, rc);
+                    const int ds = bd + sct[li * 6 + rc];
                     const bool isd = ds > us;                      // ties -> up (:144)
                     b = isd ? ds : us;
                     pw = isd ? ((uint32_t)pd << 2 | 1u) : ((uint32_t)pu << 2 | 2u);
                     const int head = start + ((c - start) / 8) * 8;
-                    gc = sc_at(a.sc, read[head], GAP);           // gap key of the chunk head (:157)
+                    gc = sct[read_at(head) * 6 + GAP];           // gap key of the chunk head (:157)
                 } else {
-                    const int ds = bd + (nwp ? sc_at(a.sc, rc, li) : sc_at(a.sc, li, rc));  // swapped key (:206)
+                    const int ds = bd + (nwp ? sct[rc * 6 + li] : sct[li * 6 + rc]);  // swapped key (:206)
                     const bool isd = ds >= us;                     // tail: D > U > L (:175-181)
                     b = isd ? ds : us;
                     pw = isd ? ((uint32_t)pd << 2 | 1u) : ((uint32_t)pu << 2 | 2u);
-                    gc = sc_at(a.sc, rc, GAP);
+                    gc = sct[rc * 6 + GAP];
                 }
             }
-            const int G = wave_incl_sum(gc, lane) + carry_G;
+            const int G = dpp_incl_sum(gc) + carry_G;
             const int y = act ? b - G : INT32_MIN / 2;
-            const int zi = wave_incl_max(y, lane);
-            int zprev = __shfl_up(zi, 1, WAVE);
+            const int zi = dpp_incl_max(y, INT32_MIN / 2);
+            int zprev = dpp_shr1(zi, INT32_MIN / 2);
             zprev = lane == 0 ? carry_z : max(zprev, carry_z);
             int v = b;
             if (act) {
@@ -185,18 +253,28 @@ __global__ __launch_bounds__(64) void k_m0_simd(PoaArgs a) {
                 am[off + (c - start)] = v;
                 apw[off + (c - start)] = pw;
             }
+#pragma unroll
+            for (int k = 0; k < KC; ++k) v_keep[k] = ci == k ? v : v_keep[k];
             // best_col: last column attaining the row maximum (:162-164, :220-222)
-            long long key = act ? (((long long)v << 32) | (unsigned)c) : (((long long)INT32_MIN << 32));
-            key = wave_max_ll(key);
-            if ((int)(key >> 32) >= (int)(best_key >> 32)) best_key = key;
-            carry_z = max(carry_z, __shfl(zi, WAVE - 1, WAVE));
-            carry_G = __shfl(G, WAVE - 1, WAVE);
+            const int vm = act ? v : INT32_MIN;
+            const int cmx = __builtin_amdgcn_readlane(dpp_incl_max(vm, INT32_MIN), WAVE - 1);
+            if (cmx >= best_v) {
+                const unsigned long long at = __ballot(act && v == cmx);
+                best_v = cmx; best_c = cb + 63 - __clzll((long long)at);
+            }
+            carry_z = max(carry_z, __builtin_amdgcn_readlane(zi, WAVE - 1));
+            carry_G = __builtin_amdgcn_readlane(G, WAVE - 1);
         }
-        if (lane == 0) rinfo[i] = make_int4((int)off, start, right, (int)(best_key & 0xffffffffll));
+        if (lane == 0) rinfo[i] = make_int4((int)off, start, right, best_c);
         off += width;
         ncells += (unsigned long long)width;
-        __syncthreads();
+        dirty = true;
+        p_best = best_c; p_start = start; p_right = right; p_valid = width <= KC * WAVE;
+#pragma unroll
+        for (int k = 0; k < KC; ++k) pv[k] = v_keep[k];
+        c0_prev = c0_cur;
     }
+    __syncthreads();
 
     if (overflow) {
         if (lane == 0) { rec->status = ST_OVERFLOW; rec->n_ops = 0; }
@@ -259,7 +337,9 @@ __global__ __launch_bounds__(64) void k_m0_simd(PoaArgs a) {
 }
 
 void launch_m0_simd(const PoaArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(k_m0_simd, dim3(a.nreads), dim3(64), 0, s, a);
+    const size_t bytes = 36 * sizeof(int) + (a.lds_read ? (((size_t)a.max_n + 2 + 3) & ~(size_t)3) : 0);
+    if (a.lds_read) hipLaunchKernelGGL((k_m0_simd<true>), dim3(a.nreads), dim3(64), bytes, s, a);
+    else hipLaunchKernelGGL((k_m0_simd<false>), dim3(a.nreads), dim3(64), bytes, s, a);
 }
 
 }  // namespace rg

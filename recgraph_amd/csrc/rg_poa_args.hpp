@@ -13,6 +13,8 @@ struct PoaArgs {
     const int* bta;            // per read bases_to_add (main.rs:57)
     const int* col0;           // m0: m[i][0] per row (global_abpoa.rs:36-46), depends on scores only
     int nreads;
+    int max_n;                 // longest read of the batch
+    int lds_read;              // m0: the read's base codes are staged in LDS (max_n + 2 bytes per wave)
     int read_base;             // local modes: first read of this launch (arena slots are launch-relative)
     int gap_open, gap_ext;     // m2
     long long cap_cells;       // arena capacity per read (cells)
