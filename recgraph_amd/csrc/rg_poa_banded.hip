@@ -46,7 +46,7 @@ enum : uint32_t { PD_O = 0, PD_D = 1, PD_d = 2, PD_L = 3, PD_U = 4 };
 
 // kGap = false: scalar -m 0;  kGap = true: -m 2.
 // Arena planes per read (cap_cells each): m | y (m2) ; path words: w0 = pred<<3 | dir | X<<31, w1 = predY<<1 | Y.
-template <bool kGap>
+template <bool kGap, bool kLdsRead>
 __global__ __launch_bounds__(64) void k_poa_banded(PoaArgs a) {
     const int rd = blockIdx.x;
     const int lane = threadIdx.x;
@@ -54,9 +54,19 @@ __global__ __launch_bounds__(64) void k_poa_banded(PoaArgs a) {
     const int L = g.L;
     const long long ro = a.read_off[rd];
     const int n = (int)(a.read_off[rd + 1] - ro);
-    const uint8_t* read = a.reads + ro - 1;
+    const uint8_t* gread = a.reads + ro - 1;
     DevRecord* rec = a.rec + rd;
     const int W = n + 1;
+    // score table and read codes in LDS (per-lane lookups every row; as kernel-argument / global loads each one is a
+    // dependent memory round trip), wave-uniform graph tables through the scalar cache (uload)
+    extern __shared__ int pb_lds[];
+    int* sct = pb_lds;
+    uint8_t* lread = reinterpret_cast<uint8_t*>(pb_lds + 36);
+    if (lane < 36) sct[lane] = a.sc.t[lane];
+    if (kLdsRead)
+        for (int jj = 1 + lane; jj <= n; jj += WAVE) lread[jj] = gread[jj];
+    __syncthreads();
+    auto read_at = [&](int jj) -> int { return kLdsRead ? (int)lread[jj] : (int)gread[jj]; };
     if (a.bad[rd]) {
         if (lane == 0) { rec->status = ST_BAD_BASE; rec->n_ops = 0; rec->score = 0; }
         return;
@@ -77,7 +87,7 @@ __global__ __launch_bounds__(64) void k_poa_banded(PoaArgs a) {
     bool overflow = false;
 
     for (int i = 0; i + 1 < L; ++i) {
-        const int pb = g.pred_off[i], pe = g.pred_off[i + 1];
+        const int pb = uload(g.pred_off + i), pe = uload(g.pred_off + i + 1);
         const bool nwp = pe > pb;
         unsigned long long ms = 0, me = 0;
         if (i > 0) {
@@ -94,12 +104,12 @@ __global__ __launch_bounds__(64) void k_poa_banded(PoaArgs a) {
             }
         }
         int left, right;
-        band_plain(ms, me, g.r_values[i], (unsigned long long)W, bta, left, right);
+        band_plain(ms, me, uload(g.r_values + i), (unsigned long long)W, bta, left, right);
         if (right <= left) { status |= ST_WOULD_PANIC; break; }   // empty row: m[i][best_val_pos] out of range
         const int width = right - left;
         if (off + width > a.cap_cells) { overflow = true; break; }
-        const int li = i > 0 ? g.lnz[i] : 4;
-        const int minp = i > 0 ? g.min_pred[i] : 0;
+        const int li = i > 0 ? uload_u8(g.lnz, i) : 4;
+        const int minp = i > 0 ? uload(g.min_pred + i) : 0;
         // carries of the scans across 64-column chunks
         int carry_z = NEGB;       // running prefix max (exclusive) of the scan variable
         int carry_G = 0;          // m0 scalar: prefix sum of gap costs
@@ -110,7 +120,7 @@ __global__ __launch_bounds__(64) void k_poa_banded(PoaArgs a) {
             const int j = cb + lane;
             const bool act = j < width;
             const int c = left + j;
-            const int rc = (act && c >= 1) ? read[c] : 4;
+            const int rc = (act && c >= 1) ? read_at(c) : 4;
             // ---- candidates from the predecessor rows ----
             int d = 0, u = 0, dp = minp, up = minp;
             bool have_d = false, have_u = false;
@@ -131,7 +141,7 @@ __global__ __launch_bounds__(64) void k_poa_banded(PoaArgs a) {
                     if (kGap) { mval = o + e * (minp + 1); w0 = ((uint32_t)minp << 3) | PD_U; }
                     else {
                         const int4 rp = rinfo[minp];
-                        mval = am[rp.x] + scb(a.sc, GAP, li);       // m[best_p][0] band-relative (:316)
+                        mval = am[rp.x] + sct[(GAP) * 6 + (li)];       // m[best_p][0] band-relative (:316)
                         w0 = ((uint32_t)minp << 3) | PD_U;
                     }
                 } else {
@@ -165,16 +175,16 @@ __global__ __launch_bounds__(64) void k_poa_banded(PoaArgs a) {
                 bool chain = false;           // cell takes part in the left chain
                 int lfb = NEGB;               // left fallback of a band-left cell (:337-339)
                 if (act && !fixed) {
-                    if (i == 0) { chain = true; gc = scb(a.sc, GAP, rc); tval = NEGB; }   // key ('-', base) (:307)
+                    if (i == 0) { chain = true; gc = sct[(GAP) * 6 + (rc)]; tval = NEGB; }   // key ('-', base) (:307)
                     else {
-                        const int dv = have_d ? d + scb(a.sc, li, rc) : scb(a.sc, li, GAP) * (i + left);
-                        const int uv = have_u ? u + scb(a.sc, li, GAP) : scb(a.sc, li, GAP) * (i + left + j);
+                        const int dv = have_d ? d + sct[(li) * 6 + (rc)] : sct[(li) * 6 + (GAP)] * (i + left);
+                        const int uv = have_u ? u + sct[(li) * 6 + (GAP)] : sct[(li) * 6 + (GAP)] * (i + left + j);
                         const int dpp = have_d ? dp : minp, upp = have_u ? up : minp;
                         if (dv < uv) { tval = uv; tw0 = ((uint32_t)(upp & 0xffff) << 3) | PD_U; }
                         else { tval = dv; tw0 = ((uint32_t)(dpp & 0xffff) << 3) | (rc != li ? PD_d : PD_D); }
-                        gc = scb(a.sc, rc, GAP);
+                        gc = sct[(rc) * 6 + (GAP)];
                         if (j > 0) chain = true;
-                        else lfb = scb(a.sc, rc, GAP) * (i + left + j);
+                        else lfb = sct[(rc) * 6 + (GAP)] * (i + left + j);
                     }
                 }
                 // scan: z = value - G
@@ -214,7 +224,7 @@ __global__ __launch_bounds__(64) void k_poa_banded(PoaArgs a) {
                         if (uy > u) { yval = uy + e; up_pred = uyp; fromy = true; }
                         else { yval = u + e; up_pred = up; }
                     } else { yval = 2 * o + e * (minp + 1) + e * c; up_pred = minp; }   // (:139)
-                    if (have_d) dv = d + scb(a.sc, li, rc);
+                    if (have_d) dv = d + sct[(li) * 6 + (rc)];
                     tcur = max(dv, yval);
                     if (j == 0) xb = 2 * o + e * (minp + 1) + e * c;                    // (:117)
                 }
@@ -425,11 +435,13 @@ __global__ __launch_bounds__(64) void k_poa_banded(PoaArgs a) {
     atomicAdd(a.cells, ncells);
 }
 
-void launch_m2(const PoaArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL((k_poa_banded<true>), dim3(a.nreads), dim3(64), 0, s, a);
+template <bool kGap>
+static void launch_banded(const PoaArgs& a, hipStream_t s) {
+    const size_t bytes = 36 * sizeof(int) + (a.lds_read ? (((size_t)a.max_n + 2 + 3) & ~(size_t)3) : 0);
+    if (a.lds_read) hipLaunchKernelGGL((k_poa_banded<kGap, true>), dim3(a.nreads), dim3(64), bytes, s, a);
+    else hipLaunchKernelGGL((k_poa_banded<kGap, false>), dim3(a.nreads), dim3(64), bytes, s, a);
 }
-void launch_m0_scalar(const PoaArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL((k_poa_banded<false>), dim3(a.nreads), dim3(64), 0, s, a);
-}
+void launch_m2(const PoaArgs& a, hipStream_t s) { launch_banded<true>(a, s); }
+void launch_m0_scalar(const PoaArgs& a, hipStream_t s) { launch_banded<false>(a, s); }
 
 }  // namespace rg
