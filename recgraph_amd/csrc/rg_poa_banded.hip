@@ -86,13 +86,35 @@ __global__ __launch_bounds__(64) void k_poa_banded(PoaArgs a) {
     uint32_t status = 0;
     bool overflow = false;
 
+    // The previous row travels in registers (chunk k, lane l holds band cell 64 k + l = column p_left + 64 k + l) when it
+    // fits KC chunks: a row whose only predecessor is the row above then needs no load, no barrier, and its stores are
+    // fire and forget.  Rows with other predecessors take the memory path; a barrier orders the earlier stores first.
+    constexpr int KC = 8;
+    int pvm[KC] = {}, pvy[kGap ? KC : 1] = {};
+    int p_left = 0, p_right = 0, p_best = 0, p_off = 0;
+    bool p_valid = false, dirty = false;
+    auto chunk_of = [&](const int (&arr)[KC], int k) -> int {
+        int r = arr[0];
+#pragma unroll
+        for (int kk = 1; kk < KC; ++kk) r = k == kk ? arr[kk] : r;
+        return r;
+    };
+    // stored cell of the row above at absolute column `col` (band-relative index col - p_left; chunk base k0 uniform)
+    auto prev_at = [&](int col, int k0, int lo, int hi) -> int {
+        const int idx = col - p_left;
+        const int sh_lo = __shfl(lo, idx & (WAVE - 1), WAVE), sh_hi = __shfl(hi, idx & (WAVE - 1), WAVE);
+        return (idx >> 6) == k0 ? sh_lo : sh_hi;
+    };
+
     for (int i = 0; i + 1 < L; ++i) {
         const int pb = uload(g.pred_off + i), pe = uload(g.pred_off + i + 1);
         const bool nwp = pe > pb;
+        const bool only_prev = i > 0 && (!nwp || (pe - pb == 1 && uload(g.pred_rows + pb) == i - 1));
         unsigned long long ms = 0, me = 0;
         if (i > 0) {
-            if (!nwp) { unsigned long long pl = (unsigned long long)rinfo[i - 1].w; ms = pl + 1; me = pl + 1; }
+            if (only_prev) { unsigned long long pl = (unsigned long long)p_best; ms = pl + 1; me = pl + 1; }
             else {
+                if (dirty) { __syncthreads(); dirty = false; }
                 unsigned long long pl = 0, pr = 0;
                 for (int ee = pb; ee < pe; ++ee) {
                     unsigned long long cb = (unsigned long long)rinfo[g.pred_rows[ee]].w;
@@ -110,17 +132,37 @@ __global__ __launch_bounds__(64) void k_poa_banded(PoaArgs a) {
         if (off + width > a.cap_cells) { overflow = true; break; }
         const int li = i > 0 ? uload_u8(g.lnz, i) : 4;
         const int minp = i > 0 ? uload(g.min_pred + i) : 0;
+        const bool fast = only_prev && p_valid && width <= KC * WAVE;
+        if (i > 0 && !fast && dirty) { __syncthreads(); dirty = false; }
+        int keep_m[KC] = {}, keep_y[kGap ? KC : 1] = {};
+        int ci = 0;
         // carries of the scans across 64-column chunks
         int carry_z = NEGB;       // running prefix max (exclusive) of the scan variable
         int carry_G = 0;          // m0 scalar: prefix sum of gap costs
         int carry_t = NEGB;       // m2: t of the last column of the previous chunk (for the X flag)
         int carry_zprev = NEGB;   // m2: exclusive prefix max at the previous chunk's last column
         long long best_key = ((long long)INT32_MIN) * 4294967296ll;
-        for (int cb = 0; cb < width; cb += WAVE) {
+        for (int cb = 0; cb < width; cb += WAVE, ++ci) {
             const int j = cb + lane;
             const bool act = j < width;
             const int c = left + j;
             const int rc = (act && c >= 1) ? read_at(c) : 4;
+            // fast path: m[i-1] at columns c-1 and c (and y[i-1] at c) from the registers of the row above
+            int f_md = 0, f_mu = 0, f_yu = 0;
+            if (fast) {
+                const int k0 = (left + cb - 1 - p_left) >> 6;          // columns c-1 .. c of this chunk span chunks k0, k0+1
+                const int ka = k0 < 0 ? 0 : (k0 < KC ? k0 : KC - 1), kb = k0 + 1 < 0 ? 0 : (k0 + 1 < KC ? k0 + 1 : KC - 1);
+                const int mlo = chunk_of(pvm, ka), mhi = chunk_of(pvm, kb);
+                f_md = prev_at(c - 1, k0, mlo, mhi);
+                f_mu = prev_at(c, k0, mlo, mhi);
+                if (kGap) {
+                    int ylo = pvy[0], yhi = pvy[0];
+#pragma unroll
+                    for (int kk = 1; kk < (kGap ? KC : 1); ++kk) { ylo = ka == kk ? pvy[kGap ? kk : 0] : ylo; yhi = kb == kk ? pvy[kGap ? kk : 0] : yhi; }
+                    f_yu = prev_at(c, k0, ylo, yhi);
+                }
+            }
+            const int first_prev = __builtin_amdgcn_readlane(pvm[0], 0);   // first stored cell of the row above
             // ---- candidates from the predecessor rows ----
             int d = 0, u = 0, dp = minp, up = minp;
             bool have_d = false, have_u = false;
@@ -140,9 +182,17 @@ __global__ __launch_bounds__(64) void k_poa_banded(PoaArgs a) {
                     fixed = true;
                     if (kGap) { mval = o + e * (minp + 1); w0 = ((uint32_t)minp << 3) | PD_U; }
                     else {
-                        const int4 rp = rinfo[minp];
-                        mval = am[rp.x] + sct[(GAP) * 6 + (li)];       // m[best_p][0] band-relative (:316)
+                        const int first = (fast && minp == i - 1) ? first_prev : am[rinfo[minp].x];
+                        mval = first + sct[(GAP) * 6 + (li)];       // m[best_p][0] band-relative (:316)
                         w0 = ((uint32_t)minp << 3) | PD_U;
+                    }
+                } else if (fast) {
+                    const int p = i - 1;
+                    if (c > p_left && c <= p_right) { d = f_md; dp = p; have_d = true; }     // diagonal: left_p < c <= right_p
+                    if (c >= p_left && c < p_right) {                                         // up: left_p <= c < right_p
+                        if (kGap) { u = f_mu + o; up = p; uy = f_yu; uyp = p; }
+                        else { u = f_mu; up = p; }
+                        have_u = true;
                     }
                 } else {
                     const int np = nwp ? pe - pb : 1;
@@ -188,7 +238,7 @@ __global__ __launch_bounds__(64) void k_poa_banded(PoaArgs a) {
                     }
                 }
                 // scan: z = value - G
-                const int G = wave_incl_sum(act ? gc : 0, lane) + carry_G;
+                const int G = dpp_incl_sum(act ? gc : 0) + carry_G;
                 int v0 = tval;                // value of a cell as a chain SOURCE
                 uint32_t v0w = tw0;
                 if (fixed) { v0 = mval; v0w = w0; }
@@ -196,8 +246,8 @@ __global__ __launch_bounds__(64) void k_poa_banded(PoaArgs a) {
                     if (lfb > tval) { v0 = lfb; v0w = ((uint32_t)(minp & 0xffff) << 3) | PD_L; }
                 }
                 const int y = act ? v0 - G : NEGB;
-                const int zi = wave_incl_max(y, lane);
-                int zprev = __shfl_up(zi, 1, WAVE);
+                const int zi = dpp_incl_max(y, NEGB);
+                int zprev = dpp_shr1(zi, NEGB);
                 zprev = lane == 0 ? carry_z : max(zprev, carry_z);
                 if (act) {
                     int v = v0;
@@ -209,8 +259,10 @@ __global__ __launch_bounds__(64) void k_poa_banded(PoaArgs a) {
                     mval = v;
                     if (!fixed && i > 0) ncells += 0;  // counted below per wave
                 }
-                carry_z = max(carry_z, __shfl(zi, WAVE - 1, WAVE));
-                carry_G = __shfl(G, WAVE - 1, WAVE);
+                carry_z = max(carry_z, __builtin_amdgcn_readlane(zi, WAVE - 1));
+                carry_G = __builtin_amdgcn_readlane(G, WAVE - 1);
+#pragma unroll
+                for (int k = 0; k < KC; ++k) keep_m[k] = ci == k ? mval : keep_m[k];
             } else {
                 // ---------------- m2 (gap_global_abpoa.rs:67-196) ----------------
                 const bool fixed0 = act && i > 0 && j == 0 && left == 0;   // first column (:78-92)
@@ -231,13 +283,13 @@ __global__ __launch_bounds__(64) void k_poa_banded(PoaArgs a) {
                 // x[j] - e*j = max over k < j of max(t[k] + o, xb[k]) - e*k   (x[j] = e + max(x[j-1], m[j-1] + o), o <= 0)
                 int zsrc = NEGB;
                 if (fixed0 || general) zsrc = max(tcur > NEGB ? tcur + o : NEGB, xb) - e * j;
-                const int zi = wave_incl_max(zsrc, lane);
-                int ze = __shfl_up(zi, 1, WAVE);
+                const int zi = dpp_incl_max(zsrc, NEGB);
+                int ze = dpp_shr1(zi, NEGB);
                 ze = lane == 0 ? carry_z : max(ze, carry_z);
                 int xval = NEGB;
                 if (fixed0 || general) xval = j == 0 ? xb : ze + e * j;
                 // path_x = 'X' iff x[j-1] > m[j-1] + o, i.e. (o < 0) x[j-1] > t[j-1] + o   (:350-368)
-                int xprev = __shfl_up(xval, 1, WAVE), tprev = __shfl_up(tcur, 1, WAVE);
+                int xprev = dpp_shr1(xval, NEGB), tprev = dpp_shr1(tcur, NEGB);
                 if (lane == 0) { xprev = carry_zprev; tprev = carry_t; }
                 const bool xflag = general && j > 0 && o != 0 && xprev > (tprev > NEGB ? tprev + o : NEGB);
                 if (general) {
@@ -268,14 +320,21 @@ __global__ __launch_bounds__(64) void k_poa_banded(PoaArgs a) {
                     pw0[off + j] = w0;
                     pw1[off + j] = w1;
                 }
-                carry_zprev = __shfl(xval, WAVE - 1, WAVE);     // x of the chunk's last column
-                carry_t = __shfl(tcur, WAVE - 1, WAVE);
-                carry_z = max(carry_z, __shfl(zi, WAVE - 1, WAVE));
+                carry_zprev = __builtin_amdgcn_readlane(xval, WAVE - 1);     // x of the chunk's last column
+                carry_t = __builtin_amdgcn_readlane(tcur, WAVE - 1);
+                carry_z = max(carry_z, __builtin_amdgcn_readlane(zi, WAVE - 1));
+#pragma unroll
+                for (int k = 0; k < KC; ++k) {
+                    keep_m[k] = ci == k ? mval : keep_m[k];
+                    if (kGap) keep_y[kGap ? k : 0] = ci == k ? yval : keep_y[kGap ? k : 0];
+                }
             }
             // best_scoring_pos: last column attaining the row maximum
-            long long key = act ? ((long long)mval * 4294967296ll + (long long)(unsigned)j) : ((long long)INT32_MIN) * 4294967296ll;
-            key = wave_max_ll(key);
-            if ((int)(key >> 32) >= (int)(best_key >> 32)) best_key = key;
+            const int cmx = __builtin_amdgcn_readlane(dpp_incl_max(act ? mval : INT32_MIN, INT32_MIN), WAVE - 1);
+            if (cmx >= (int)(best_key >> 32)) {
+                const unsigned long long at = __ballot(act && mval == cmx);
+                best_key = (long long)cmx * 4294967296ll + (long long)(unsigned)(cb + 63 - __clzll((long long)at));
+            }
         }
         // general cells of this row (reference's unit of work)
         {
@@ -284,9 +343,14 @@ __global__ __launch_bounds__(64) void k_poa_banded(PoaArgs a) {
             ncells += (unsigned long long)general;
         }
         if (lane == 0) rinfo[i] = make_int4((int)off, left, right, (int)(best_key & 0xffffffffll) + left);
+        p_best = (int)(best_key & 0xffffffffll) + left; p_left = left; p_right = right; p_off = (int)off;
+        p_valid = width <= KC * WAVE;
+#pragma unroll
+        for (int k = 0; k < KC; ++k) { pvm[k] = keep_m[k]; if (kGap) pvy[kGap ? k : 0] = keep_y[kGap ? k : 0]; }
         off += width;
-        __syncthreads();
+        dirty = true;
     }
+    __syncthreads();
     // combine status bits raised by any lane
     for (int dd = WAVE / 2; dd >= 1; dd >>= 1) status |= __shfl_xor(status, dd, WAVE);
     if (overflow) {
