@@ -53,11 +53,7 @@ __device__ __forceinline__ int lo16(int v) { return (int)(short)(v & 0xffff); }
 __device__ __forceinline__ int hi16(int v) { return v >> 16; }
 // per half: mask ? a : b   (mask halves are 0 or 0xffff)
 __device__ __forceinline__ int bfi(int mask, int a, int b) {
-#ifdef RG16_OLD_BFI
-    return (mask & a) | (~mask & b);
-#else
     return __builtin_amdgcn_bitop3_b32(mask, a, b, 0xCA);   // (mask & a) | (~mask & b) in ONE v_bitop3_b32
-#endif
 }
 
 // Row operators on packed rows.  MU / ML: per register, 0xffff in the halves whose column took U (not D) / L.
