@@ -1,0 +1,18 @@
+"""Short randomised parity campaign (tools/fuzz_parity.py): random graphs, reads, score matrices and parameters over
+every mode, GPU vs oracle.  The long runs are recorded in profiles/r01_notes.md."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("seed", [11, 12])
+def test_fuzz_parity_short(seed):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_parity.py"), "20", str(seed)], capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "failures 0" in r.stdout
