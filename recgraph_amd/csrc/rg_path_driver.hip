@@ -293,9 +293,18 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
             TIMED(T, "k_threshold", launch_threshold(t1, chunk, stream));
             SweepArgs r = sa;
             r.rev = 1; r.track_best = 1; r.thr = w.thr.p; r.colmax_out = w.wr.p; r.colarg_out = w.wrarg.p; r.cand = w.rcand.p; r.cand_cap = w.rcap; r.ncand_out = w.nr.p;
-            if (use_rec) { r.cand = nullptr; r.cand_cap = 0; r.frec = w.rrec.p; r.frec_cap = w.rrec_cap; r.ncand_out = w.nrrec.p; }
+            if (use_rec) {
+                // records instead of Cand entries; the reverse column maxima come from those records (k_colmax_rec)
+                r.cand = nullptr; r.cand_cap = 0; r.frec = w.rrec.p; r.frec_cap = w.rrec_cap; r.ncand_out = w.nrrec.p;
+                r.colmax_out = nullptr; r.colarg_out = nullptr;
+            }
             r.dirs = w.rdirs.p; r.dirs_stride = rdirs_stride; r.count_cells = 1;
             TIMED(T, use16 ? "k_sweep16_rev" : "k_sweep_rev", sweep(r, chunk));
+            if (use_rec) {
+                ExpandArgs ec{w.state.p, w.rrec.p, w.rrec_cap, w.nrrec.p, nullptr, 0, nullptr, nullptr, wpad, p.base_rec_cost, gd.knm, 1, off,
+                              p.rec_band_width};
+                TIMED(T, "k_colmax_rec", launch_colmax_rec(ec, w.wr.p, w.wrarg.p, chunk, C, stream));
+            }
             BoundArgs ba{gd, w.state.p, off, w.mf.p, w.mfarg.p, w.wr.p, w.wrarg.p, wpad, p.base_rec_cost, p.multi_rec_cost,
                          p.rec_band_width};
             TIMED(T, "k_bound", launch_bound(ba, chunk, stream));

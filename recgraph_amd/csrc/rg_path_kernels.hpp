@@ -178,6 +178,7 @@ void launch_sweep_reg(const SweepArgs& a, int nreads, int C, hipStream_t s);
 void launch_sweep16(const SweepArgs& a, int nreads, int C, hipStream_t s);   // packed 16-bit rows (rg_sweep16.hip)
 bool sweep16_admissible(const DevScores& sc, int max_path_rows, int max_n, int C);
 void launch_expand(const ExpandArgs& a, int nreads, int C, hipStream_t s);
+void launch_colmax_rec(const ExpandArgs& a, int* colmax_out, int* colarg_out, int nreads, int C, hipStream_t s);
 void launch_seed(const SeedArgs& a, hipStream_t s);
 void launch_opt0(const Opt0Args& a, int nreads, int C, hipStream_t s);
 void launch_threshold(const ThrArgs& a, int nreads, hipStream_t s);

@@ -148,7 +148,9 @@ struct RowOps16 {
 #define RG_SWEEP16_KRUN 4
 #endif
 
-template <int C>
+// kColmax = false: no per-column maxima (the reverse sweep of the record pipeline: its maxima and their cells are
+// taken from its own records by k_colmax_rec)
+template <int C, bool kColmax>
 __global__ __launch_bounds__(64, 2) void k_sweep16(SweepArgs a) {
     constexpr int H = C / 2;
     constexpr int KRUN = C <= 16 ? RG_SWEEP16_KRUN : 0;   // rows kept in registers across the inner rows of a segment
@@ -218,9 +220,9 @@ __global__ __launch_bounds__(64, 2) void k_sweep16(SweepArgs a) {
     }
     __syncthreads();
 
-    int ckey[C], crow[C];               // best usable (value << 16 | path) per column and its row
+    int ckey[kColmax ? C : 1], crow[kColmax ? C : 1];   // best (value << 16 | path) per column and its row
 #pragma unroll
-    for (int q = 0; q < C; ++q) { ckey[q] = INT32_MIN; crow[q] = 0; }
+    for (int q = 0; q < (kColmax ? C : 1); ++q) { ckey[q] = INT32_MIN; crow[q] = 0; }
     unsigned ncand = 0;
     unsigned long long cells = 0;
     Cand* cand = a.cand ? a.cand + (long long)rd * a.cand_cap : nullptr;
@@ -237,11 +239,13 @@ __global__ __launch_bounds__(64, 2) void k_sweep16(SweepArgs a) {
         // (it removes most of the negative-valued cells the loose forward thresholds would let through).
         const int kthr = knm >= 0 ? knm : INT32_MIN;
         unsigned emask = 0;
+        if (kColmax) {
 #pragma unroll
-        for (int q = 0; q < C; ++q) {
-            const bool better = bkey[q] > ckey[q];
-            ckey[q] = better ? bkey[q] : ckey[q];
-            crow[q] = better ? i : crow[q];
+            for (int q = 0; q < C; ++q) {
+                const bool better = bkey[q] > ckey[kColmax ? q : 0];
+                ckey[kColmax ? q : 0] = better ? bkey[q] : ckey[kColmax ? q : 0];
+                crow[kColmax ? q : 0] = better ? i : crow[kColmax ? q : 0];
+            }
         }
         // tight thresholds (reverse sweep): most rows emit nothing; one max3 tree against the lane's lowest threshold
         // decides for the whole wave whether the per-column test is needed
@@ -504,13 +508,13 @@ __global__ __launch_bounds__(64, 2) void k_sweep16(SweepArgs a) {
     }
 
     // ---- outputs ----
-    if (a.colmax_out) {
+    if (kColmax && a.colmax_out) {
 #pragma unroll
         for (int q = 0; q < C; ++q) {
             const int c = lane * C + q;
             if (c < ncols) {
-                a.colmax_out[(long long)rd * wpad + (rev ? n - c : c)] = ckey[q] == INT32_MIN ? NEG32 : ckey[q] >> 16;
-                if (a.colarg_out) a.colarg_out[(long long)rd * wpad + (rev ? n - c : c)] = (crow[q] << 8) | (ckey[q] & 63);
+                a.colmax_out[(long long)rd * wpad + (rev ? n - c : c)] = ckey[kColmax ? q : 0] == INT32_MIN ? NEG32 : ckey[kColmax ? q : 0] >> 16;
+                if (a.colarg_out) a.colarg_out[(long long)rd * wpad + (rev ? n - c : c)] = (crow[kColmax ? q : 0] << 8) | (ckey[kColmax ? q : 0] & 63);
             }
         }
     }
@@ -598,14 +602,67 @@ void launch_expand(const ExpandArgs& a, int nreads, int C, hipStream_t s) {
     }
 }
 
-void launch_sweep16(const SweepArgs& a, int nreads, int C, hipStream_t s) {
+// Column maxima of a sweep and the cells attaining them, from the sweep's own records: per column the best member-winner
+// key (value << 16 | path) and its row.  Only cells above the emission threshold are in the records: for every other
+// cell of that sweep no partner can reach the seed, so pruning against these maxima stays exact.
+template <int C>
+__global__ __launch_bounds__(256) void k_colmax_rec(ExpandArgs a, int* colmax_out, int* colarg_out) {
+    const int rd = blockIdx.x;
+    extern __shared__ unsigned long long cm_best[];      // [wpad]: (key + 2^31) << 32 | row
+    const int nread = (int)(a.read_off[rd + 1] - a.read_off[rd]);
+    for (int j = threadIdx.x; j < a.wpad; j += blockDim.x) cm_best[j] = 0ull;
+    __syncthreads();
+    const ReadState* rs = a.state + rd;
+    const unsigned nrec = a.nrec[rd];
+    if (!(rs->status & (ST_BAD_BASE | ST_WOULD_PANIC)) && nrec <= a.frec_cap) {
+        const int oob = max((int)((float)(nread + 1) * (1.0f - a.rbw) / 2.0f), 1);
+        const int* base = a.frec + (long long)rd * a.frec_cap * (4 + C);
+        for (unsigned t = threadIdx.x / C; t < nrec; t += blockDim.x / C) {
+            const int* rp = base + (long long)t * (4 + C);
+            const int rl = rp[0], q = threadIdx.x % C;
+            const int key = rp[4 + q];
+            const int cc = (rl & 63) * C + q;
+            if (cc >= (a.rev ? nread : nread + 1)) continue;
+            const int col = a.rev ? nread - cc : cc;
+            if (col < oob || col >= nread + 1 - oob) continue;
+            const int knm = a.knm[rl >> 6];
+            if (knm >= 0 && key <= knm) continue;
+            atomicMax(&cm_best[col], ((unsigned long long)((unsigned)key ^ 0x80000000u) << 32) | (unsigned)(rl >> 6));
+        }
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < a.wpad; j += blockDim.x) {
+        const unsigned long long b = cm_best[j];
+        const int key = (int)((unsigned)(b >> 32) ^ 0x80000000u);
+        colmax_out[(long long)rd * a.wpad + j] = b ? key >> 16 : NEG32;
+        colarg_out[(long long)rd * a.wpad + j] = b ? (int)(((unsigned)b << 8) | ((unsigned)key & 63u)) : 0;
+    }
+}
+
+void launch_colmax_rec(const ExpandArgs& a, int* colmax_out, int* colarg_out, int nreads, int C, hipStream_t s) {
+    const size_t bytes = (size_t)a.wpad * sizeof(unsigned long long);
+    switch (C) {
+        case 4: hipLaunchKernelGGL((k_colmax_rec<4>), dim3(nreads), dim3(256), bytes, s, a, colmax_out, colarg_out); break;
+        case 8: hipLaunchKernelGGL((k_colmax_rec<8>), dim3(nreads), dim3(256), bytes, s, a, colmax_out, colarg_out); break;
+        case 16: hipLaunchKernelGGL((k_colmax_rec<16>), dim3(nreads), dim3(256), bytes, s, a, colmax_out, colarg_out); break;
+        default: hipLaunchKernelGGL((k_colmax_rec<32>), dim3(nreads), dim3(256), bytes, s, a, colmax_out, colarg_out); break;
+    }
+}
+
+template <bool kColmax>
+static void launch_sweep16_c(const SweepArgs& a, int nreads, int C, hipStream_t s) {
     const size_t bytes = (size_t)(192 + 5 * 64) * sizeof(int);
     switch (C) {
-        case 4: hipLaunchKernelGGL((k_sweep16<4>), dim3(nreads), dim3(64), bytes, s, a); break;
-        case 8: hipLaunchKernelGGL((k_sweep16<8>), dim3(nreads), dim3(64), bytes, s, a); break;
-        case 16: hipLaunchKernelGGL((k_sweep16<16>), dim3(nreads), dim3(64), bytes, s, a); break;
-        default: hipLaunchKernelGGL((k_sweep16<32>), dim3(nreads), dim3(64), bytes, s, a); break;
+        case 4: hipLaunchKernelGGL((k_sweep16<4, kColmax>), dim3(nreads), dim3(64), bytes, s, a); break;
+        case 8: hipLaunchKernelGGL((k_sweep16<8, kColmax>), dim3(nreads), dim3(64), bytes, s, a); break;
+        case 16: hipLaunchKernelGGL((k_sweep16<16, kColmax>), dim3(nreads), dim3(64), bytes, s, a); break;
+        default: hipLaunchKernelGGL((k_sweep16<32, kColmax>), dim3(nreads), dim3(64), bytes, s, a); break;
     }
+}
+void launch_sweep16(const SweepArgs& a, int nreads, int C, hipStream_t s) {
+    // a sweep that writes records and is not asked for column maxima skips their tracking
+    if (a.frec && !a.colmax_out) launch_sweep16_c<false>(a, nreads, C, s);
+    else launch_sweep16_c<true>(a, nreads, C, s);
 }
 
 }  // namespace rg
