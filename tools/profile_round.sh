@@ -29,7 +29,11 @@ for d in sorted(glob.glob(O + '/pmc_*/')):
 with open(O + '/%s_c5_pmc_b2048.csv' % TAG, 'w') as f:
     f.write('kernel,counter,sum_over_launches,launches\n')
     for r in rows: f.write('"%s",%s,%.1f,%d\n' % r)
-sw = {c: (v, n) for k, c, v, n in rows if 'k_sweep16' in k}
+sw = {}
+for k, c, v, n in rows:
+    if 'k_sweep16' in k:
+        pv, pn = sw.get(c, (0.0, 0))
+        sw[c] = (pv + v, pn + n)
 if 'FETCH_SIZE' in sw and 'WRITE_SIZE' in sw:
     fb = sw['FETCH_SIZE'][0] * 1024 / sw['FETCH_SIZE'][1]; wb = sw['WRITE_SIZE'][0] * 1024 / sw['WRITE_SIZE'][1]
     json.dump({"kernel": "rg::k_sweep16<16>", "reads_per_launch": 2048, "fetch_bytes_per_launch_raw": fb, "write_bytes_per_launch_raw": wb,
