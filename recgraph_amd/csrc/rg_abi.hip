@@ -230,7 +230,7 @@ int run_local(rg_batch* b) {
     a.g = DevLnz{h.L, g->d_lnz.p, g->d_pred_off.p, g->d_pred_rows.p, g->d_r_values.p, g->d_min_pred.p};
     for (int i = 0; i < 36; ++i) a.sc.t[i] = b->p.scores[i];
     a.reads = b->d_reads.p; a.read_off = b->d_off.p; a.bad = b->d_bad.p; a.bta = b->d_bta.p; a.col0 = b->d_col0.p;
-    a.gap_open = b->p.gap_open; a.gap_ext = b->p.gap_ext; a.max_n = b->max_n; a.lds_read = 0;
+    a.gap_open = b->p.gap_open; a.gap_ext = b->p.gap_ext; a.max_n = b->max_n; a.lds_read = b->max_n <= 16000 ? 1 : 0;
     a.cap_cells = b->cap_cells; a.arena_m = b->d_arena_m.p; a.arena_pw = b->d_arena_pw.p; a.rinfo = b->d_rinfo.p;
     a.rec = b->d_rec.p; a.ops = b->d_ops.p; a.oprows = b->d_oprows.p; a.ops_stride = b->ops_stride;
     a.cells = b->d_cells.p;

@@ -29,7 +29,7 @@ enum : uint32_t { LD_O = 0, LD_D = 1, LD_d = 2, LD_L = 3, LD_U = 4 };
 
 // kVar 0: -m 1 AVX2 semantics (f32 values are integers < 2^24: int32 is exact);  1: -m 1 scalar;  2: -m 3.
 // Planes per read (cap_cells each): m | y (kVar 2);  path words: w0 = pred << 3 | dir | X << 31,  w1 = predY << 1 | Y.
-template <int kVar>
+template <int kVar, bool kLdsRead>
 __global__ __launch_bounds__(64) void k_poa_local(PoaArgs a) {
     const int slot = blockIdx.x;
     const int rd = a.read_base + slot;
@@ -38,9 +38,18 @@ __global__ __launch_bounds__(64) void k_poa_local(PoaArgs a) {
     const int L = g.L;
     const long long ro = a.read_off[rd];
     const int n = (int)(a.read_off[rd + 1] - ro);
-    const uint8_t* read = a.reads + ro - 1;   // read[c], c = 1..n
+    const uint8_t* gread = a.reads + ro - 1;   // read_at(c), c = 1..n
     DevRecord* rec = a.rec + rd;
     const int W = n + 1;
+    // score table and read codes in LDS, wave-uniform graph tables through the scalar cache (see rg_poa.hip)
+    extern __shared__ int pl_lds[];
+    int* sct = pl_lds;
+    uint8_t* lread = reinterpret_cast<uint8_t*>(pl_lds + 36);
+    if (lane < 36) sct[lane] = a.sc.t[lane];
+    if (kLdsRead)
+        for (int jj = 1 + lane; jj <= n; jj += WAVE) lread[jj] = gread[jj];
+    __syncthreads();
+    auto read_at = [&](int jj) -> int { return kLdsRead ? (int)lread[jj] : (int)gread[jj]; };
     if (a.bad[rd]) {
         if (lane == 0) { rec->status = ST_BAD_BASE; rec->n_ops = 0; rec->score = 0; }
         return;
@@ -69,22 +78,51 @@ __global__ __launch_bounds__(64) void k_poa_local(PoaArgs a) {
     // kVar 1/2 take the FIRST ('>', all cells, start (0,0))
     long long best_key = kVar == 0 ? 0ll : IDX_SPAN - 1;
 
+    // The row above travels in registers (chunk k, lane l = column 64 k + l: local rows are full width, so chunks line
+    // up) when W <= 64 KC: a row whose only predecessor is the row above needs no load and no barrier.
+    constexpr int KC = 8;
+    int pvm[KC] = {}, pvy[kVar == 2 ? KC : 1] = {};
+    const bool p_fit = W <= KC * WAVE;
+    bool dirty = false;
+
     for (int i = 1; i + 1 < L; ++i) {
-        const int pb = g.pred_off[i], pe = g.pred_off[i + 1];
+        const int pb = uload(g.pred_off + i), pe = uload(g.pred_off + i + 1);
         const bool nwp = pe > pb;
-        const int li = g.lnz[i];
+        const bool fast = p_fit && !nwp;         // (rows with a listed predecessor take the reference's other code path)
+        if (!fast && dirty) { __syncthreads(); dirty = false; }
+        const int li = uload_u8(g.lnz, i);
         const long long rowoff = (long long)i * W;
+        int keep_m[KC] = {}, keep_y[kVar == 2 ? KC : 1] = {};
+        int ci = 0;
         int carry_z = NEGL, carry_G = 0;
         int carry_x = 0, carry_t = 0;          // kVar 2: x and t' of the previous chunk's last column
-        for (int cb = 0; cb < W; cb += WAVE) {
+        for (int cb = 0; cb < W; cb += WAVE, ++ci) {
             const int c = cb + lane;
             const bool act = c < W;
             const bool cell = act && c >= 1;
-            const int rc = cell ? read[c] : 4;
+            // fast path: m[i-1][c], m[i-1][c-1] (and y[i-1][c]) from the registers of the row above
+            int f_u = 0, f_d = 0, f_y = 0;
+            if (fast) {
+                int cur_m = pvm[0], prv_m = 0, cur_y = pvy[0];
+#pragma unroll
+                for (int k = 1; k < KC; ++k) {
+                    cur_m = ci == k ? pvm[k] : cur_m;
+                    prv_m = ci == k ? pvm[k - 1] : prv_m;
+                    if (kVar == 2) cur_y = ci == k ? pvy[kVar == 2 ? k : 0] : cur_y;
+                }
+                f_u = cur_m; f_y = cur_y;
+                f_d = dpp_shr1(cur_m, 0);
+                const int edge = __builtin_amdgcn_readlane(prv_m, WAVE - 1);
+                if (lane == 0) f_d = edge;
+            }
+            const int rc = cell ? read_at(c) : 4;
             int d = 0, u = 0, dp = 0, up = 0;
             int uy = 0, uyp = 0;                 // kVar 2: y candidate
             if (cell) {
-                if (!nwp) {
+                if (fast) {
+                    d = f_d; u = f_u; dp = up = i - 1;
+                    if (kVar == 2) { uy = f_y; uyp = i - 1; }
+                } else if (!nwp) {
                     const long long po = (long long)(i - 1) * W + c;
                     d = am[po - 1]; u = am[po]; dp = up = i - 1;
                     if (kVar == 2) { uy = ay[po]; uyp = i - 1; }
@@ -127,17 +165,17 @@ __global__ __launch_bounds__(64) void k_poa_local(PoaArgs a) {
                 int b = 0, gk = 0;
                 bool isd = false, clamp = true;
                 if (cell) {
-                    const int us = u + scl(a.sc, li, GAP);
+                    const int us = u + sct[(li) * 6 + (GAP)];
                     if (simd) {
-                        const int ds = d + scl(a.sc, li, rc);
+                        const int ds = d + sct[(li) * 6 + (rc)];
                         isd = ds > us;                                  // ties -> up (:47, :80)
                         b = isd ? ds : us;
-                        gk = scl(a.sc, read[((c - 1) / 8) * 8 + 1], GAP);  // gap key of the chunk head (:94)
+                        gk = sct[(read_at(((c - 1) / 8) * 8 + 1)) * 6 + (GAP)];  // gap key of the chunk head (:94)
                     } else {
-                        const int ds = d + (nwp ? scl(a.sc, rc, li) : scl(a.sc, li, rc));   // swapped key (:147)
+                        const int ds = d + (nwp ? sct[(rc) * 6 + (li)] : sct[(li) * 6 + (rc)]);   // swapped key (:147)
                         isd = ds >= us;                                 // D > U > L (:119-127, :150-156)
                         b = isd ? ds : us;
-                        gk = scl(a.sc, rc, GAP);
+                        gk = sct[(rc) * 6 + (GAP)];
                         clamp = !nwp;                                   // the multi-predecessor tail never clamps
                     }
                 }
@@ -157,15 +195,15 @@ __global__ __launch_bounds__(64) void k_poa_local(PoaArgs a) {
                     const long long key = (long long)v * IDX_SPAN + (rowoff + c);
                     if (key > best_key) best_key = key;
                 }
-                carry_z = max(carry_z, __shfl(zi, WAVE - 1, WAVE));
-                carry_G = __shfl(G, WAVE - 1, WAVE);
+                carry_z = max(carry_z, __builtin_amdgcn_readlane(zi, WAVE - 1));
+                carry_G = __builtin_amdgcn_readlane(G, WAVE - 1);
             } else if (kVar == 1) {
                 // ---------------- scalar flavour ----------------
                 int dv = 0, uv = 0, gk = 0;
                 if (cell) {
-                    dv = d + scl(a.sc, rc, li);            // key (sequence[j], lnz[i]) (:205, :213)
-                    uv = u + scl(a.sc, GAP, li);           // key ('-', lnz[i])
-                    gk = scl(a.sc, rc, GAP);
+                    dv = d + sct[(rc) * 6 + (li)];            // key (sequence[j], lnz[i]) (:205, :213)
+                    uv = u + sct[(GAP) * 6 + (li)];           // key ('-', lnz[i])
+                    gk = sct[(rc) * 6 + (GAP)];
                 }
                 const int bsrc = !act ? NEGL : (!cell ? 0 : max(max(dv, uv), 0));
                 const int G = dpp_incl_sum(gk) + carry_G;
@@ -186,14 +224,14 @@ __global__ __launch_bounds__(64) void k_poa_local(PoaArgs a) {
                     const long long key = (long long)mval * IDX_SPAN + (IDX_SPAN - 1 - (rowoff + c));
                     if (key > best_key) best_key = key;
                 }
-                carry_z = max(carry_z, __shfl(zi, WAVE - 1, WAVE));
-                carry_G = __shfl(G, WAVE - 1, WAVE);
+                carry_z = max(carry_z, __builtin_amdgcn_readlane(zi, WAVE - 1));
+                carry_G = __builtin_amdgcn_readlane(G, WAVE - 1);
             } else {
                 // ---------------- -m 3 ----------------
                 int dv = 0, yval = 0, ypred = 0, tcur = 0;
                 bool fromy = false;
                 if (cell) {
-                    dv = d + scl(a.sc, rc, li);
+                    dv = d + sct[(rc) * 6 + (li)];
                     if (!nwp) {
                         const int u_y = uy + e, u_m = u + o + e;          // (:53-66)
                         fromy = u_y > u_m;
@@ -232,15 +270,22 @@ __global__ __launch_bounds__(64) void k_poa_local(PoaArgs a) {
                     if (key > best_key) best_key = key;
                 }
                 if (act) ay[rowoff + c] = cell ? yval : 0;
+#pragma unroll
+                for (int k = 0; k < KC; ++k) keep_y[kVar == 2 ? k : 0] = ci == k ? (cell ? yval : 0) : keep_y[kVar == 2 ? k : 0];
                 if (act) pw1[rowoff + c] = w1;
-                carry_x = __shfl(xval, WAVE - 1, WAVE);
-                carry_t = __shfl(tcur, WAVE - 1, WAVE);
-                carry_z = max(carry_z, __shfl(zi, WAVE - 1, WAVE));
+                carry_x = __builtin_amdgcn_readlane(xval, WAVE - 1);
+                carry_t = __builtin_amdgcn_readlane(tcur, WAVE - 1);
+                carry_z = max(carry_z, __builtin_amdgcn_readlane(zi, WAVE - 1));
             }
             if (act) { am[rowoff + c] = mval; pw0[rowoff + c] = w0; }
+#pragma unroll
+            for (int k = 0; k < KC; ++k) keep_m[k] = ci == k ? mval : keep_m[k];
         }
-        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < KC; ++k) { pvm[k] = keep_m[k]; if (kVar == 2) pvy[kVar == 2 ? k : 0] = keep_y[kVar == 2 ? k : 0]; }
+        dirty = true;
     }
+    __syncthreads();
     best_key = wave_max_ll(best_key);
     if (lane != 0) return;
 
@@ -309,10 +354,16 @@ __global__ __launch_bounds__(64) void k_poa_local(PoaArgs a) {
     atomicAdd(a.cells, (unsigned long long)(L - 2) * (unsigned long long)(W - 1));
 }
 
+template <int kVar>
+static void launch_local_v(const PoaArgs& a, hipStream_t s) {
+    const size_t bytes = 36 * sizeof(int) + (a.lds_read ? (((size_t)a.max_n + 2 + 3) & ~(size_t)3) : 0);
+    if (a.lds_read) hipLaunchKernelGGL((k_poa_local<kVar, true>), dim3(a.nreads), dim3(64), bytes, s, a);
+    else hipLaunchKernelGGL((k_poa_local<kVar, false>), dim3(a.nreads), dim3(64), bytes, s, a);
+}
 void launch_local(const PoaArgs& a, int variant, hipStream_t s) {
-    if (variant == 0) hipLaunchKernelGGL((k_poa_local<0>), dim3(a.nreads), dim3(64), 0, s, a);
-    else if (variant == 1) hipLaunchKernelGGL((k_poa_local<1>), dim3(a.nreads), dim3(64), 0, s, a);
-    else hipLaunchKernelGGL((k_poa_local<2>), dim3(a.nreads), dim3(64), 0, s, a);
+    if (variant == 0) launch_local_v<0>(a, s);
+    else if (variant == 1) launch_local_v<1>(a, s);
+    else launch_local_v<2>(a, s);
 }
 
 }  // namespace rg
