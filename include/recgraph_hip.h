@@ -6,8 +6,10 @@
  * pointers and sizes only; no C++/torch types cross this boundary.  All functions return
  * RG_OK (0) or a negative rg_status; none of them aborts (the reference panics instead).
  *
- * Thread-safety: a graph handle is immutable after creation and may be shared; a batch handle
- * must be used by one thread at a time.
+ * Thread-safety: a graph handle is immutable after creation and may be shared by threads and by
+ * devices (its device tables are uploaded once per HIP device, under a lock, by the first batch
+ * created on that device); a batch handle is bound to the device that was current when it was
+ * created (every call on it selects that device) and must be used by one thread at a time.
  */
 #ifndef RECGRAPH_HIP_H
 #define RECGRAPH_HIP_H
@@ -97,6 +99,12 @@ int32_t rg_graph_create_path(const char* lnz, int64_t L, int32_t P, const uint64
                              const int64_t* edge_off, const int64_t* edge_pred, const uint64_t* edge_mask,
                              const uint64_t* node_id, rg_graph** out);
 void rg_graph_destroy(rg_graph* g);
+/* A GFA whose P lines cannot be turned into a PathGraph (more than 64 paths, '-' path steps, a step on an unknown
+ * segment, steps against the id order, a segment on no path: pathwise_graph.rs:182) still yields the LnzGraph view, which
+ * is all modes 0-3 need (main.rs:29); the reason is returned here ("" when the PathGraph view exists or the GFA has no
+ * P lines) and by rg_batch_create (RG_ERR_GRAPH) when a pathwise mode is requested on such a graph.
+ * Limits of the pathwise kernels: at most 64 paths; reads of at most 2047 bases. */
+const char* rg_graph_path_error(const rg_graph* g);
 int64_t rg_graph_rows(const rg_graph* g);   /* lnz.len() of the LnzGraph (or PathGraph if only that exists) */
 int32_t rg_graph_paths(const rg_graph* g);  /* paths_number, 0 without P lines */
 /* text dumps of the flattened arrays (same `which` codes as the test oracle) for construction tests */
@@ -116,6 +124,10 @@ int64_t rg_graph_dump(const rg_graph* g, int32_t which, char* buf, int64_t cap);
  */
 int32_t rg_batch_create(const rg_graph* g, const rg_params* p, const char* reads, const int64_t* read_off,
                         int64_t nreads, rg_batch** out);
+/* Replaces the reads of an existing batch handle (same graph, same parameters) and uploads them: a streaming caller
+ * keeps one or two handles and their HBM work buffers for the whole read set instead of re-creating them per chunk of
+ * the reference's read loop (main.rs:56,174,257,297).  Results of the previous reads are discarded. */
+int32_t rg_batch_set_reads(rg_batch* b, const char* reads, const int64_t* read_off, int64_t nreads);
 int32_t rg_batch_run(rg_batch* b);
 int32_t rg_batch_fetch(rg_batch* b);
 void rg_batch_destroy(rg_batch* b);

@@ -53,6 +53,15 @@ def lib():
         l.orc_bench.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.POINTER(C.c_longlong), C.c_longlong,
                                 C.POINTER(C.c_int), C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_float,
                                 C.c_float, C.c_int, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]
+        l.orc_bench_text.restype = C.c_double
+        l.orc_bench_text.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.POINTER(C.c_longlong), C.c_longlong,
+                                     C.POINTER(C.c_int), C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_float,
+                                     C.c_float, C.c_int, C.c_char_p, C.c_longlong, C.c_char_p, C.c_longlong,
+                                     C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(C.c_ulonglong)]
+        l.orc_bench_faithful.restype = C.c_double
+        l.orc_bench_faithful.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_longlong), C.c_longlong, C.POINTER(C.c_int),
+                                         C.c_int, C.c_float, C.c_float, C.c_int, C.c_int, C.POINTER(C.c_double),
+                                         C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
         l.orc_scores_match_mis.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]
         l.orc_scores_from_mtx.argtypes = [C.c_char_p, C.POINTER(C.c_int)]
         l.orc_missing_value.restype = C.c_int
@@ -216,3 +225,44 @@ class Graph:
         secs = lib().orc_bench(self.h, mode, blob, offa, len(reads), sc, o, e, b, f, R, r, B, nthreads,
                                C.byref(cells), C.byref(chk))
         return secs, cells.value, chk.value
+
+    def bench_text(self, mode, reads, scores=None, o=-4, e=-2, b=1.0, f=0.01, R=4, r=0.1, B=1.0, nthreads=1,
+                   name_prefix="read", idx_base=1):
+        """Like ``bench`` but returns (seconds, cells, [stdout text per read]); read i is named
+        ``name_prefix + str(i)`` with seq index ``idx_base + i`` (what ``rg_batch_format_all`` uses by default)."""
+        if scores is None:
+            scores = scores_match_mis(2, -4)
+        blob = "".join(reads).encode()
+        offs = [0]
+        for rd in reads:
+            offs.append(offs[-1] + len(rd))
+        offa = (C.c_longlong * len(offs))(*offs)
+        sc = (C.c_int * 36)(*scores)
+        cells = C.c_ulonglong(0)
+        need = C.c_longlong(0)
+        cap = 4096 * len(reads) + 65536
+        buf = C.create_string_buffer(cap)
+        toff = (C.c_longlong * (len(reads) + 1))()
+        secs = lib().orc_bench_text(self.h, mode, blob, offa, len(reads), sc, o, e, b, f, R, r, B, nthreads,
+                                    name_prefix.encode(), idx_base, buf, cap, toff, C.byref(need), C.byref(cells))
+        if need.value > cap:
+            raise RuntimeError("orc_bench_text: output larger than the buffer (%d > %d)" % (need.value, cap))
+        raw = buf.raw
+        return secs, cells.value, [raw[toff[i]:toff[i + 1]] for i in range(len(reads))]
+
+    def bench_faithful(self, reads, scores=None, R=4, r=0.1, B=1.0, nthreads=1, col_stride=1):
+        """FAITHFUL -m 8 (literal DP + unpruned O(L^2 n) scan) with the scan sampled on every ``col_stride``-th
+        column.  Returns dict(wall, dp_secs, scan_secs, cols_visited, cols_total); sums over the reads."""
+        if scores is None:
+            scores = scores_match_mis(2, -4)
+        blob = "".join(reads).encode()
+        offs = [0]
+        for rd in reads:
+            offs.append(offs[-1] + len(rd))
+        offa = (C.c_longlong * len(offs))(*offs)
+        sc = (C.c_int * 36)(*scores)
+        dp, scan = C.c_double(0), C.c_double(0)
+        cv, ct = C.c_longlong(0), C.c_longlong(0)
+        wall = lib().orc_bench_faithful(self.h, blob, offa, len(reads), sc, R, r, B, nthreads, col_stride,
+                                        C.byref(dp), C.byref(scan), C.byref(cv), C.byref(ct))
+        return dict(wall=wall, dp_secs=dp.value, scan_secs=scan.value, cols_visited=cv.value, cols_total=ct.value)

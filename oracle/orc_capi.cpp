@@ -1,5 +1,6 @@
 // ORACLE — TEST INFRASTRUCTURE ONLY (see orc_common.hpp header).
 // extern "C" surface used by tests/ (through oracle/oracle.py) and by bench.py's cpu_baseline leg.
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <cstdio>
@@ -221,6 +222,89 @@ double orc_bench(void* h, int mode, const char* reads_concat, const long long* o
     double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     if (cells_out) *cells_out = cells.load();
     if (checksum_out) *checksum_out = checksum.load();
+    return secs;
+}
+
+// Same sharded run, returning every read's stdout text (read r is named "<name_prefix><r>" with seq index
+// idx_base + r, like rg_batch_format_all with names == NULL): text_out holds the texts back to back in read order,
+// text_off[r] .. text_off[r + 1] is read r.  Used by bench.py's in-run parity gate and by the full-size GPU tests.
+// Returns wall seconds; *need = bytes required (nothing is written past `cap`).
+double orc_bench_text(void* h, int mode, const char* reads_concat, const long long* offsets, long long nreads,
+                      const int* scores36, int o, int e, float b, float f, int brc, float mrc, float rbw, int nthreads,
+                      const char* name_prefix, long long idx_base, char* text_out, long long cap, long long* text_off,
+                      long long* need, unsigned long long* cells_out) {
+    auto* g = (OrcGraph*)h;
+    Scores sc0 = scores_from(scores36);
+    std::atomic<long long> next{0};
+    std::atomic<unsigned long long> cells{0};
+    std::vector<std::string> outs((size_t)nreads);
+    auto t0 = std::chrono::steady_clock::now();
+    auto work = [&]() {
+        Scores sc = sc0;
+        while (true) {
+            long long r = next.fetch_add(1);
+            if (r >= nreads) break;
+            std::string rd = "$";
+            for (const char* p = reads_concat + offsets[r]; p < reads_concat + offsets[r + 1]; ++p)
+                rd += (*p == '-') ? 'N' : (char)std::toupper(*p);
+            size_t bta = (size_t)(b + f * (float)rd.size());  // main.rs:57
+            uint64_t c = 0;
+            Result res = run_one(g, mode, rd, std::string(name_prefix) + std::to_string(r), (size_t)(idx_base + r), sc, o, e, bta,
+                                 brc, mrc, rbw, &c);
+            cells += c;
+            outs[(size_t)r] = res.would_panic ? std::string("<would panic>\n") : res.out;
+        }
+    };
+    std::vector<std::thread> th;
+    for (int t = 0; t < nthreads; ++t) th.emplace_back(work);
+    for (auto& t : th) t.join();
+    double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    long long total = 0;
+    for (long long r = 0; r < nreads; ++r) {
+        if (text_off) text_off[r] = total;
+        if (text_out && total + (long long)outs[(size_t)r].size() <= cap) memcpy(text_out + total, outs[(size_t)r].data(), outs[(size_t)r].size());
+        total += (long long)outs[(size_t)r].size();
+    }
+    if (text_off) text_off[nreads] = total;
+    if (need) *need = total;
+    if (cells_out) *cells_out = cells.load();
+    return secs;
+}
+
+// FAITHFUL -m 8 timing (the literal transliteration with the UNPRUNED best_alignment scan,
+// pathwise_alignment_recombination.rs:808-864), one read per worker at a time, the scan sampled on every
+// `col_stride`-th column (FaithfulProbe).  Outputs are sums over the reads; the caller extrapolates
+// scan_secs * cols_total / cols_visited.  Returns wall seconds.
+double orc_bench_faithful(void* h, const char* reads_concat, const long long* offsets, long long nreads, const int* scores36,
+                          int brc, float mrc, float rbw, int nthreads, int col_stride, double* dp_secs, double* scan_secs,
+                          long long* cols_visited, long long* cols_total) {
+    auto* g = (OrcGraph*)h;
+    Scores sc0 = scores_from(scores36);
+    std::atomic<long long> next{0};
+    std::vector<FaithfulProbe> probes((size_t)std::max(1, nthreads));
+    auto t0 = std::chrono::steady_clock::now();
+    auto work = [&](int t) {
+        Scores sc = sc0;
+        probes[(size_t)t].col_stride = std::max(1, col_stride);
+        g_faithful_probe = &probes[(size_t)t];
+        while (true) {
+            long long r = next.fetch_add(1);
+            if (r >= nreads) break;
+            std::string rd = "$" + std::string(reads_concat + offsets[r], reads_concat + offsets[r + 1]);
+            (void)m8_literal(rd, "r", g->pg, g->rpg, g->dfs, g->dfe, sc, brc, mrc, rbw, false);
+        }
+        g_faithful_probe = nullptr;
+    };
+    std::vector<std::thread> th;
+    for (int t = 0; t < std::max(1, nthreads); ++t) th.emplace_back(work, t);
+    for (auto& t : th) t.join();
+    double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    double dp = 0, sc = 0; long long cv = 0, ct = 0;
+    for (auto& p : probes) { dp += p.dp_secs; sc += p.scan_secs; cv += p.cols_visited; ct += p.cols_total; }
+    if (dp_secs) *dp_secs = dp;
+    if (scan_secs) *scan_secs = sc;
+    if (cols_visited) *cols_visited = cv;
+    if (cols_total) *cols_total = ct;
     return secs;
 }
 

@@ -131,6 +131,17 @@ struct GAF {
 // pathwise_alignment_output.rs:471-556
 std::string build_cigar(const std::vector<char>& cigar);
 
+// Timing probe of the FAITHFUL (unpruned) best_alignment scan of m8_literal, for bench.py's cpu_baseline leg: the scan
+// is O(L^2 n) (~1e11 iterations per read at config 5), so the bench visits every `col_stride`-th column of the band,
+// times that part on its own and extrapolates (said so in the bench line).  col_stride == 1 is the real thing; a
+// result produced with col_stride > 1 is NOT an alignment and is never compared with anything.
+struct FaithfulProbe {
+    int col_stride = 1;
+    double dp_secs = 0, scan_secs = 0;      // DP fill + absolute_scores / the (j, i, ri) scan incl. the per-column fp/rp
+    long long cols_visited = 0, cols_total = 0;
+};
+extern thread_local FaithfulProbe* g_faithful_probe;
+
 struct Result {
     int score = 0;            // what the reference's exec returns as .0 (POA modes)
     bool would_panic = false; // reference would abort (index OOB / unwrap on None / ...)

@@ -6,9 +6,13 @@
 //   -m 8: src/pathwise_alignment_recombination.rs:23-883 + src/recombination_output.rs:363-782
 #include <algorithm>
 
+#include <chrono>
+
 #include "orc_common.hpp"
 
 namespace orc {
+
+thread_local FaithfulProbe* g_faithful_probe = nullptr;
 
 namespace {
 
@@ -380,6 +384,8 @@ Result m8_literal(const std::string& seq, const std::string& name, const PathGra
     const size_t L = lnz.size(), W = seq.size(), P = g.paths_number;
     const auto& ids = g.nodes_id_pos;
     const auto& np = g.paths_nodes;
+    FaithfulProbe* probe = g_faithful_probe;
+    const auto t_start = std::chrono::steady_clock::now();
     Dpm m(L, W, P), w(L, W, P);
     fill(m, seq, g, sc, true);
     absolute_scores(m, g);
@@ -390,6 +396,8 @@ Result m8_literal(const std::string& seq, const std::string& name, const PathGra
         if (a == b) return 0;
         return (int)(std::llabs(dfs[a] - dfs[b]) + std::llabs(dfe[a] - dfe[b]));
     };
+    const auto t_dp = std::chrono::steady_clock::now();
+    if (probe) probe->dp_secs += std::chrono::duration<double>(t_dp - t_start).count();
 
     // ---- best_alignment :759-873 (aln_mode 8) ----
     size_t fen = 0, rsn = 0, rec_col = 0;
@@ -408,6 +416,11 @@ Result m8_literal(const std::string& seq, const std::string& name, const PathGra
     int rec_penalty = 0;
     std::vector<size_t> fp(L), rp(L);
     for (size_t j = (size_t)oob; j + (size_t)oob < W; ++j) {
+        if (probe) {   // timing probe only (see FaithfulProbe): sample the columns of the scan
+            probe->cols_total += 1;
+            if ((j - (size_t)oob) % (size_t)probe->col_stride != 0) continue;
+            probe->cols_visited += 1;
+        }
         for (size_t i = 0; i < L; ++i) {
             size_t bf = 0, br = 0;
             for (size_t k = 0; k < P; ++k) {
@@ -454,6 +467,8 @@ Result m8_literal(const std::string& seq, const std::string& name, const PathGra
             }
         }
     }
+
+    if (probe) probe->scan_secs += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_dp).count();
 
     std::vector<char> cigar, pseq;
     std::vector<uint64_t> hia;

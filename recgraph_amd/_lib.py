@@ -35,8 +35,8 @@ def build_library(force=False):
 
 # every symbol include/recgraph_hip.h declares
 SYMBOLS = ["rg_params_default", "rg_scores_match_mis", "rg_graph_from_gfa", "rg_graph_create_lnz",
-           "rg_graph_create_path", "rg_graph_destroy", "rg_graph_rows", "rg_graph_paths", "rg_graph_dump",
-           "rg_batch_create", "rg_batch_run", "rg_batch_fetch", "rg_batch_destroy", "rg_batch_size",
+           "rg_graph_create_path", "rg_graph_destroy", "rg_graph_path_error", "rg_graph_rows", "rg_graph_paths", "rg_graph_dump",
+           "rg_batch_create", "rg_batch_set_reads", "rg_batch_run", "rg_batch_fetch", "rg_batch_destroy", "rg_batch_size",
            "rg_result_status", "rg_result_score", "rg_result_gaf", "rg_batch_format_all", "rg_batch_cell_updates", "rg_batch_kernel_count",
            "rg_batch_kernel_name", "rg_batch_kernel_ms", "rg_batch_kernel_launches", "rg_align_batch", "rg_last_error",
            "rg_device_count", "rg_set_device"]
@@ -61,12 +61,15 @@ def load():
     l.rg_graph_create_lnz.argtypes = [C.c_char_p, i64, P(i64), P(i64), P(u64), P(vp)]
     l.rg_graph_create_path.argtypes = [C.c_char_p, i64, i32, P(u64), P(i64), P(i64), P(u64), P(u64), P(vp)]
     l.rg_graph_destroy.argtypes = [vp]
+    l.rg_graph_path_error.argtypes = [vp]
+    l.rg_graph_path_error.restype = C.c_char_p
     l.rg_graph_rows.argtypes = [vp]
     l.rg_graph_rows.restype = i64
     l.rg_graph_paths.argtypes = [vp]
     l.rg_graph_dump.argtypes = [vp, i32, C.c_char_p, i64]
     l.rg_graph_dump.restype = i64
     l.rg_batch_create.argtypes = [vp, P(Params), C.c_char_p, P(i64), i64, P(vp)]
+    l.rg_batch_set_reads.argtypes = [vp, C.c_char_p, P(i64), i64]
     l.rg_align_batch.argtypes = [vp, P(Params), C.c_char_p, P(i64), i64, P(vp)]
     for f in ("rg_batch_run", "rg_batch_fetch"):
         getattr(l, f).argtypes = [vp]

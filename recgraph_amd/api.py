@@ -175,6 +175,11 @@ class Graph:
     def paths_number(self):
         return _lib.load().rg_graph_paths(self._h)
 
+    @property
+    def path_error(self):
+        """Why a GFA with P lines has no PathGraph view ('' when it has one): modes 0-3 still work on such a graph."""
+        return _lib.load().rg_graph_path_error(self._h).decode()
+
     def dump(self, which):
         lib = _lib.load()
         n = lib.rg_graph_dump(self._h, which, None, 0)
@@ -224,6 +229,14 @@ class Batch:
         self._h = C.c_void_p()
         check(lib.rg_batch_create(graph._h, C.byref(params), blob, offs.ctypes.data_as(C.POINTER(C.c_int64)), self.n,
                                   C.byref(self._h)))
+
+    def set_reads(self, reads):
+        """Replace the reads of this handle (work buffers in HBM are kept): rg_batch_set_reads."""
+        self.n = len(reads)
+        blob = "".join(reads).encode()
+        offs = np.zeros(self.n + 1, dtype=np.int64)
+        np.cumsum([len(x) for x in reads], out=offs[1:])
+        check(_lib.load().rg_batch_set_reads(self._h, blob, offs.ctypes.data_as(C.POINTER(C.c_int64)), self.n))
 
     def __del__(self):
         try:

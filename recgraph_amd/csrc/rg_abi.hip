@@ -7,7 +7,9 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <map>
 #include <memory>
+#include <mutex>
 #include <thread>
 
 #include "rg_host.hpp"
@@ -48,8 +50,10 @@ struct DevBuf {
     }
 };
 
-struct rg_graph {
-    HostGraph h;
+// Device copy of the flattened graph: one per HIP device that has a batch on this graph (built on first use, under the
+// graph's mutex; the host arrays are immutable after creation, so a graph handle is shareable across threads and devices).
+struct GraphTables {
+    int dev = 0;
     // LnzGraph view
     DevBuf<uint8_t> d_lnz;
     DevBuf<int> d_pred_off, d_pred_rows, d_r_values, d_min_pred;
@@ -61,7 +65,18 @@ struct rg_graph {
     DevBuf<int> d_eoff, d_epred, d_roff, d_rsucc;
     DevBuf<uint64_t> d_emask, d_rmask;
     DevBuf<uint8_t> d_pnwp, d_rnwp;
-    bool on_device = false;
+};
+
+struct rg_graph {
+    HostGraph h;
+    std::mutex mu;
+    std::map<int, std::unique_ptr<GraphTables>> tables;   // by device id
+    ~rg_graph() {
+        int cur = 0;
+        (void)hipGetDevice(&cur);
+        for (auto& kv : tables) { (void)hipSetDevice(kv.first); kv.second.reset(); }
+        (void)hipSetDevice(cur);
+    }
 };
 
 static int base_code(char c) {
@@ -71,11 +86,18 @@ static int base_code(char c) {
     }
 }
 
-static int upload_graph(rg_graph* g) {
-    if (g->on_device) return RG_OK;
+// tables of `g` on the CURRENT device (uploaded once per device)
+static int upload_graph(rg_graph* gr, GraphTables** out) {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(RG_ERR_NO_DEVICE, "no HIP device");
-    const HostGraph& h = g->h;
+    int dev = 0;
+    HIPCHK(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(gr->mu);
+    auto it = gr->tables.find(dev);
+    if (it != gr->tables.end()) { *out = it->second.get(); return RG_OK; }
+    auto g = std::make_unique<GraphTables>();
+    g->dev = dev;
+    const HostGraph& h = gr->h;
     std::vector<uint8_t> codes(h.L, 0);
     for (int i = 1; i + 1 < h.L; ++i) {
         int c = base_code(h.lnz[i]);
@@ -107,7 +129,8 @@ static int upload_graph(rg_graph* g) {
             (rc = g->d_rmask.upload(h.rmask)) || (rc = g->d_pnwp.upload(h.pnwp)) || (rc = g->d_rnwp.upload(h.rnwp)))
             return rc;
     }
-    g->on_device = true;
+    *out = g.get();
+    gr->tables[dev] = std::move(g);
     return RG_OK;
 }
 
@@ -118,7 +141,8 @@ struct KernelStat {
 };
 
 struct rg_batch {
-    rg_graph* g = nullptr;
+    const rg_graph* g = nullptr;
+    GraphTables* gt = nullptr;         // the graph's tables on this batch's device
     rg_params p;
     int64_t nreads = 0;
     std::string reads;                 // upper-cased bases, '-' -> 'N'
@@ -127,6 +151,7 @@ struct rg_batch {
     std::vector<int> bta;
     int max_n = 0;
     hipStream_t stream = nullptr;
+    int dev = 0;                       // device the handle was created on (graph tables are bound to it too)
     // device inputs
     DevBuf<uint8_t> d_reads, d_bad;
     DevBuf<long long> d_off;
@@ -205,8 +230,8 @@ bool is_poa(int mode) {
 
 // Local modes fill full (L-1) x W matrices: reads are processed in launches of as many reads as fit the free HBM.
 int run_local(rg_batch* b) {
-    rg_graph* g = b->g;
-    const HostGraph& h = g->h;
+    const GraphTables* g = b->gt;
+    const HostGraph& h = b->g->h;
     const int mode = b->p.mode;
     const int planes = mode == RG_MODE_GAP_LOCAL_POA ? 2 : 1;
     const int variant = mode == RG_MODE_LOCAL_POA ? 0 : mode == RG_MODE_LOCAL_POA_SCALAR ? 1 : 2;
@@ -247,8 +272,8 @@ int run_local(rg_batch* b) {
 }
 
 int run_poa(rg_batch* b) {
-    rg_graph* g = b->g;
-    const HostGraph& h = g->h;
+    const GraphTables* g = b->gt;
+    const HostGraph& h = b->g->h;
     if (!h.has_lnz) return fail(RG_ERR_ARG, "graph has no LnzGraph view");
     const int mode = b->p.mode;
     if (is_local(mode)) return run_local(b);
@@ -369,6 +394,7 @@ int32_t rg_graph_create_path(const char* lnz, int64_t L, int32_t P, const uint64
     return RG_OK;
 }
 void rg_graph_destroy(rg_graph* g) { delete g; }
+const char* rg_graph_path_error(const rg_graph* g) { return g ? g->h.path_error.c_str() : ""; }
 int64_t rg_graph_rows(const rg_graph* g) { return g ? g->h.L : 0; }
 int32_t rg_graph_paths(const rg_graph* g) { return g && g->h.has_path ? g->h.P : 0; }
 int64_t rg_graph_dump(const rg_graph* g, int32_t which, char* buf, int64_t cap) {
@@ -377,33 +403,13 @@ int64_t rg_graph_dump(const rg_graph* g, int32_t which, char* buf, int64_t cap) 
     return (int64_t)s.size();
 }
 
-int32_t rg_batch_create(const rg_graph* gc, const rg_params* p, const char* reads, const int64_t* read_off, int64_t nreads,
-                        rg_batch** out) {
-    if (!gc || !p || !reads || !read_off || !out || nreads < 1) return fail(RG_ERR_ARG, "null/empty argument");
-    rg_graph* g = const_cast<rg_graph*>(gc);
+// Reads of a batch: canonicalised (sequences.rs:13-22), coded, uploaded; every per-read buffer is (re)sized.
+// Work buffers of a previous run are kept when they are large enough, so a streaming caller re-uses one handle.
+static int load_reads(rg_batch* b, const char* reads, const int64_t* read_off, int64_t nreads) {
+    const rg_graph* g = b->g;
+    const rg_params* p = &b->p;
     const int mode = p->mode;
-    if (!(is_poa(mode) || mode == RG_MODE_PATHWISE || mode == RG_MODE_RECOMBINATION || mode == RG_MODE_PATHWISE_SEMI ||
-          mode == RG_MODE_RECOMBINATION_SEMI))
-        return fail(RG_ERR_ARG, "unsupported mode");
-    if ((mode == RG_MODE_GAP_POA || mode == RG_MODE_GAP_LOCAL_POA) && (p->gap_open > 0 || p->gap_ext > 0))
-        return fail(RG_ERR_ARG, "gap penalties must be <= 0");
-    if (is_poa(mode) && !g->h.has_lnz) return fail(RG_ERR_ARG, "graph has no LnzGraph view");
-    if (!is_poa(mode) && !g->h.has_path) return fail(RG_ERR_ARG, "graph has no paths (P lines)");
-    if ((mode == RG_MODE_RECOMBINATION || mode == RG_MODE_RECOMBINATION_SEMI) && (p->base_rec_cost < 0 || p->multi_rec_cost < 0))
-        return fail(RG_ERR_ARG, "recombination costs must be non-negative");
-    if ((mode == RG_MODE_GLOBAL_POA || mode == RG_MODE_LOCAL_POA) && g->h.L >= (1 << 20))
-        return fail(RG_ERR_GRAPH, "rows >= 2^20 break the reference's f32 path-cell decoding (gaf_output.rs:664-668, 783-786)");
-    if ((mode == RG_MODE_GAP_POA || mode == RG_MODE_GLOBAL_POA_SCALAR || mode == RG_MODE_LOCAL_POA_SCALAR ||
-         mode == RG_MODE_GAP_LOCAL_POA) && g->h.L > 65536)
-        return fail(RG_ERR_GRAPH, "rows >= 65536 are truncated by the reference's u16 path cells (bitfield_path.rs:41)");
-    if (p->amb_mode & ~3) return fail(RG_ERR_ARG, "amb_mode: only bits 0 and 1 are defined");
-    if (p->amb_mode && !is_poa(mode)) return fail(RG_ERR_ARG, "amb_mode applies to the POA modes only (main.rs:82,132,188,229)");
-    if (p->amb_mode & 1) build_rev_ids(g->h);
-    int rc = upload_graph(g);
-    if (rc) return rc;
-    auto b = std::make_unique<rg_batch>();
-    b->g = g;
-    b->p = *p;
+    b->fetched = false;
     b->nreads = nreads;
     b->off.resize(nreads + 1);
     const long long base = read_off[0];
@@ -412,6 +418,7 @@ int32_t rg_batch_create(const rg_graph* gc, const rg_params* p, const char* read
     b->codes.resize(b->reads.size());
     b->bad.assign(nreads, 0);
     b->bta.resize(nreads);
+    b->max_n = 0;
     for (int64_t r = 0; r < nreads; ++r) {
         const long long n = b->off[r + 1] - b->off[r];
         if (n < 1) return fail(RG_ERR_ARG, "empty read");
@@ -429,7 +436,7 @@ int32_t rg_batch_create(const rg_graph* gc, const rg_params* p, const char* read
         long long bt = p->bta_override >= 0 ? p->bta_override : (v > 0 ? (long long)v : 0);
         b->bta[r] = (int)std::min<long long>(bt, 1 << 28);
     }
-    HIPCHK(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
+    int rc;
     if ((rc = b->d_reads.upload(b->codes)) || (rc = b->d_off.upload(b->off)) || (rc = b->d_bad.upload(b->bad)) ||
         (rc = b->d_bta.upload(b->bta)))
         return rc;
@@ -441,32 +448,79 @@ int32_t rg_batch_create(const rg_graph* gc, const rg_params* p, const char* read
                                  : std::min<long long>((long long)h.L + b->max_n + 8, 2ll * (h.max_path_rows + b->max_n) + 16);
     if ((rc = b->d_ops.alloc((size_t)nreads * b->ops_stride))) return rc;
     if (is_poa(mode)) {
+        if ((rc = b->d_oprows.alloc((size_t)nreads * b->ops_stride)) || (rc = b->d_rinfo.alloc((size_t)nreads * h.L))) return rc;
+        long long maxbta = 0;
+        for (int v : b->bta) maxbta = std::max<long long>(maxbta, v);
+        const long long per_row = std::min<long long>(b->max_n + 1, 2 * maxbta + 40);
+        b->cap_cells = std::max(b->cap_cells, (long long)h.L * per_row);   // keeps an arena regrown by an earlier run
+    }
+    return RG_OK;
+}
+
+int32_t rg_batch_create(const rg_graph* gc, const rg_params* p, const char* reads, const int64_t* read_off, int64_t nreads,
+                        rg_batch** out) {
+    if (!gc || !p || !reads || !read_off || !out || nreads < 1) return fail(RG_ERR_ARG, "null/empty argument");
+    const rg_graph* g = gc;
+    const int mode = p->mode;
+    if (!(is_poa(mode) || mode == RG_MODE_PATHWISE || mode == RG_MODE_RECOMBINATION || mode == RG_MODE_PATHWISE_SEMI ||
+          mode == RG_MODE_RECOMBINATION_SEMI))
+        return fail(RG_ERR_ARG, "unsupported mode");
+    if ((mode == RG_MODE_GAP_POA || mode == RG_MODE_GAP_LOCAL_POA) && (p->gap_open > 0 || p->gap_ext > 0))
+        return fail(RG_ERR_ARG, "gap penalties must be <= 0");
+    if (is_poa(mode) && !g->h.has_lnz) return fail(RG_ERR_ARG, "graph has no LnzGraph view");
+    if (!is_poa(mode) && !g->h.has_path)
+        return fail(g->h.path_error.empty() ? RG_ERR_ARG : RG_ERR_GRAPH,
+                    g->h.path_error.empty() ? "graph has no paths (P lines)" : "graph has no PathGraph view: " + g->h.path_error);
+    if ((mode == RG_MODE_RECOMBINATION || mode == RG_MODE_RECOMBINATION_SEMI) && (p->base_rec_cost < 0 || p->multi_rec_cost < 0))
+        return fail(RG_ERR_ARG, "recombination costs must be non-negative");
+    if ((mode == RG_MODE_GLOBAL_POA || mode == RG_MODE_LOCAL_POA) && g->h.L >= (1 << 20))
+        return fail(RG_ERR_GRAPH, "rows >= 2^20 break the reference's f32 path-cell decoding (gaf_output.rs:664-668, 783-786)");
+    if ((mode == RG_MODE_GAP_POA || mode == RG_MODE_GLOBAL_POA_SCALAR || mode == RG_MODE_LOCAL_POA_SCALAR ||
+         mode == RG_MODE_GAP_LOCAL_POA) && g->h.L > 65536)
+        return fail(RG_ERR_GRAPH, "rows >= 65536 are truncated by the reference's u16 path cells (bitfield_path.rs:41)");
+    if (p->amb_mode & ~3) return fail(RG_ERR_ARG, "amb_mode: only bits 0 and 1 are defined");
+    if (p->amb_mode && !is_poa(mode)) return fail(RG_ERR_ARG, "amb_mode applies to the POA modes only (main.rs:82,132,188,229)");
+    GraphTables* gt = nullptr;
+    int rc = upload_graph(const_cast<rg_graph*>(g), &gt);   // per-device tables, under the graph's mutex
+    if (rc) return rc;
+    auto b = std::make_unique<rg_batch>();
+    b->g = g;
+    b->gt = gt;
+    b->p = *p;
+    HIPCHK(hipGetDevice(&b->dev));
+    HIPCHK(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
+    if (is_poa(mode)) {
         // column-0 chain of m0 (global_abpoa.rs:36-46): depends on graph + scores only
+        const HostGraph& h = g->h;
         std::vector<int> col0(h.L, 0);
         for (int i = 1; i + 1 < h.L; ++i) {
             int c = base_code(h.lnz[i]);
             col0[i] = col0[h.min_pred[i]] + p->scores[c * 6 + 5];
         }
         if ((rc = b->d_col0.upload(col0))) return rc;
-        if ((rc = b->d_oprows.alloc((size_t)nreads * b->ops_stride)) || (rc = b->d_rinfo.alloc((size_t)nreads * h.L))) return rc;
-        long long maxbta = 0;
-        for (int v : b->bta) maxbta = std::max<long long>(maxbta, v);
-        const long long per_row = std::min<long long>(b->max_n + 1, 2 * maxbta + 40);
-        b->cap_cells = (long long)h.L * per_row;
     }
+    if ((rc = load_reads(b.get(), reads, read_off, nreads))) return rc;
     *out = b.release();
     return RG_OK;
+}
+
+int32_t rg_batch_set_reads(rg_batch* b, const char* reads, const int64_t* read_off, int64_t nreads) {
+    if (!b || !reads || !read_off || nreads < 1) return fail(RG_ERR_ARG, "null/empty argument");
+    HIPCHK(hipSetDevice(b->dev));
+    return load_reads(b, reads, read_off, nreads);
 }
 
 int32_t rg_batch_run(rg_batch* b) {
     if (!b) return fail(RG_ERR_ARG, "null batch");
     b->fetched = false;
+    HIPCHK(hipSetDevice(b->dev));   // the handle is bound to the device it was created on
     if (is_poa(b->p.mode)) return run_poa(b);
     return rg_run_pathwise(b);
 }
 
 int32_t rg_batch_fetch(rg_batch* b) {
     if (!b) return fail(RG_ERR_ARG, "null batch");
+    HIPCHK(hipSetDevice(b->dev));
     b->rec.resize(b->nreads);
     HIPCHK(hipMemcpy(b->rec.data(), b->d_rec.p, sizeof(DevRecord) * b->nreads, hipMemcpyDeviceToHost));
     b->ops.resize((size_t)b->nreads * b->ops_stride);
@@ -574,8 +628,8 @@ int32_t rg_align_batch(const rg_graph* g, const rg_params* p, const char* reads,
 
 // ---- pathwise modes: buffers are owned by PathWork, kernels by rg_path_driver.hip ----
 int rg_run_pathwise(rg_batch* b) {
-    rg_graph* g = b->g;
-    const HostGraph& h = g->h;
+    const GraphTables* g = b->gt;
+    const HostGraph& h = b->g->h;
     PathGraphDev gd;
     gd.L = h.L; gd.P = h.P; gd.lnz = g->d_lnz.p; gd.row_mask = g->d_row_mask.p; gd.knm = g->d_knm.p;
     gd.dfs = g->d_dfs.p; gd.dfe = g->d_dfe.p; gd.fgoff = g->d_fgoff.p; gd.rgoff = g->d_rgoff.p;

@@ -202,6 +202,7 @@ int build_from_gfa(const char* text, int64_t len, HostGraph& g) {
     std::vector<Segment> segs;
     std::vector<std::pair<uint64_t, uint64_t>> links;
     std::vector<std::vector<uint64_t>> paths;
+    std::string path_error;
     const char* p = text;
     const char* end = text + len;
     while (p < end) {
@@ -230,15 +231,17 @@ int build_from_gfa(const char* text, int64_t len, HostGraph& g) {
                 if (*f[2].first != '+' || *f[4].first != '+') return fail(RG_ERR_GFA, "only '+' orientations are supported");
                 links.emplace_back(a, b);
             } else if (kind == 'P' && f.size() >= 3) {
+                // A P line the PathGraph view cannot take does not fail the graph: modes 0-3 only need graph::read_graph
+                // (main.rs:29); the reason is kept and reported when a pathwise mode is requested.
                 std::vector<uint64_t> steps;
                 const char* a = f[2].first;
                 while (a < f[2].second) {
                     const char* c = (const char*)memchr(a, ',', (size_t)(f[2].second - a));
                     const char* se = c ? c : f[2].second;
                     if (se > a) {
-                        if (se[-1] != '+') return fail(RG_ERR_GFA, "only '+' path steps are supported");
-                        uint64_t v;
-                        if (!parse_u64(a, se - 1, v)) return fail(RG_ERR_GFA, "bad P line");
+                        uint64_t v = 0;
+                        if (se[-1] != '+') { if (path_error.empty()) path_error = "only '+' path steps are supported"; }
+                        else if (!parse_u64(a, se - 1, v)) { if (path_error.empty()) path_error = "bad P line"; }
                         steps.push_back(v);
                     }
                     a = se + 1;
@@ -267,6 +270,11 @@ int build_from_gfa(const char* text, int64_t len, HostGraph& g) {
     for (auto& l : links) {
         auto a = idx.find(l.first), b = idx.find(l.second);
         if (a == idx.end() || b == idx.end()) return fail(RG_ERR_GFA, "link to unknown segment");
+        // every DP row reads rows above it only: a link into the same or an earlier segment (ids are the topological
+        // order, graph.rs:32-33) would make the kernels read rows not yet written
+        if (segs[a->second].last >= segs[b->second].first)
+            return fail(RG_ERR_GRAPH, "link " + std::to_string(l.first) + " -> " + std::to_string(l.second) +
+                                          " does not follow the id order (graph not topological)");
         left[b->second].push_back(segs[a->second].last);  // L-line order (graph.rs:75)
         has_out[a->second] = 1;
     }
@@ -287,9 +295,17 @@ int build_from_gfa(const char* text, int64_t len, HostGraph& g) {
     }
     compute_r_values(g);
     g.has_lnz = true;
+    build_rev_ids(g);
     // ---- PathGraph view ----
     if (!paths.empty()) {
-        if (paths.size() > 64) return fail(RG_ERR_GRAPH, "more than 64 paths are not supported");
+        auto no_path_view = [&](const std::string& why) {
+            g.has_path = false;
+            g.P = 0;
+            g.path_error = why;
+            return RG_OK;       // LnzGraph view stays usable (modes 0-3); rg_batch_create reports `why` for modes 4+
+        };
+        if (!path_error.empty()) return no_path_view(path_error);
+        if (paths.size() > 64) return no_path_view("more than 64 paths are not supported by the pathwise kernels");
         g.P = (int32_t)paths.size();
         g.row_mask.assign(L, 0);
         const uint64_t all = g.P == 64 ? ~0ull : ((1ull << g.P) - 1);
@@ -300,13 +316,13 @@ int build_from_gfa(const char* text, int64_t len, HostGraph& g) {
             const auto& st = paths[k];
             for (size_t s = 0; s < st.size(); ++s) {
                 auto it = idx.find(st[s]);
-                if (it == idx.end()) return fail(RG_ERR_GFA, "path step on unknown segment");
+                if (it == idx.end()) return no_path_view("path step on unknown segment");
                 const Segment& sg = segs[it->second];
                 for (int32_t r = sg.first; r <= sg.last; ++r) g.row_mask[r] |= 1ull << k;
                 if (s == 0) ed[sg.first][0] |= 1ull << k;
                 else {
                     const Segment& pv = segs[idx[st[s - 1]]];
-                    if (pv.last >= sg.first) return fail(RG_ERR_GRAPH, "path steps must follow the topological id order");
+                    if (pv.last >= sg.first) return no_path_view("path steps must follow the topological id order");
                     ed[sg.first][pv.last] |= 1ull << k;
                     if (s + 1 == st.size()) ed[L - 1][sg.last] |= 1ull << k;   // pathwise_graph.rs:225-232
                 }
@@ -320,7 +336,7 @@ int build_from_gfa(const char* text, int64_t len, HostGraph& g) {
             g.eoff[i + 1] = (int32_t)g.epred.size();
         }
         int rc = finish_path_view(g);
-        if (rc != RG_OK) return rc;
+        if (rc != RG_OK) return no_path_view(g_last_error);
     }
     return RG_OK;
 }
@@ -343,13 +359,21 @@ int build_from_lnz(const char* lnz, int64_t L, const int64_t* pred_off, const in
     if (!pred_off || !pred_rows) return fail(RG_ERR_ARG, "null pred arrays");
     int rc = fill_rows_from(lnz, L, node_id, g);
     if (rc) return rc;
+    if (pred_off[0] != 0) return fail(RG_ERR_ARG, "pred_off[0] must be 0");
+    for (int64_t i = 0; i < L; ++i)
+        if (pred_off[i + 1] < pred_off[i]) return fail(RG_ERR_ARG, "pred_off must be non-decreasing");
     g.pred_off.resize(L + 1);
     for (int64_t i = 0; i <= L; ++i) g.pred_off[i] = (int32_t)pred_off[i];
     g.pred_rows.resize(pred_off[L]);
-    for (int64_t e = 0; e < pred_off[L]; ++e) {
-        if (pred_rows[e] < 0 || pred_rows[e] >= L) return fail(RG_ERR_ARG, "pred row out of range");
-        g.pred_rows[e] = (int32_t)pred_rows[e];
-    }
+    if (pred_off[1] != 0) return fail(RG_ERR_GRAPH, "row 0 has no predecessors");
+    for (int64_t i = 1; i < L; ++i)
+        for (int64_t e = pred_off[i]; e < pred_off[i + 1]; ++e) {
+            // a DP row reads rows above it only (a later, equal or F predecessor row is never written when it is read)
+            if (pred_rows[e] < 0 || pred_rows[e] >= std::min(i, L - 1))
+                return fail(RG_ERR_GRAPH, "predecessor " + std::to_string(pred_rows[e]) + " of row " + std::to_string(i) +
+                                              " is not an earlier row (graph not topological)");
+            g.pred_rows[e] = (int32_t)pred_rows[e];
+        }
     if (g.pred_off[L] == g.pred_off[L - 1]) return fail(RG_ERR_GRAPH, "row F has no predecessor");
     if (!node_id) {
         // no ids given: number segments by their start rows, as utils.rs:144-165 would count them
@@ -362,6 +386,7 @@ int build_from_lnz(const char* lnz, int64_t L, const int64_t* pred_off, const in
     }
     compute_r_values(g);
     g.has_lnz = true;
+    build_rev_ids(g);
     return RG_OK;
 }
 

@@ -41,6 +41,7 @@ struct HostGraph {
 
     // ---- PathGraph view (m4/m8) ----
     bool has_path = false;
+    std::string path_error;                     // why a GFA with P lines has no PathGraph view (reported for modes 4+)
     int32_t P = 0;
     std::vector<uint64_t> row_mask;             // paths through each row (all ones for rows 0, L-1)
     std::vector<int32_t> alphas;

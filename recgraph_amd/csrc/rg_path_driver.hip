@@ -126,23 +126,14 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
     if (C > 32) return fail(RG_ERR_ARG, "reads longer than 2047 bases are not supported by the pathwise kernels");
     const int wpad = C * WAVE;
     const int dir_words = WAVE * (C <= 16 ? 1 : 2);
-    // Rolling rows: in HBM (L2 / Infinity-Cache resident, many waves per CU) by default; the LDS variant
-    // (one wave per CU at P = 32, n = 1000) measured 3.3x slower on MI355X (profiles/r01_notes.md).
-    bool lds = false;
-    if (getenv("RG_ROWS_IN_LDS")) lds = (size_t)P * wpad * sizeof(int) + 64 * sizeof(int) <= 160 * 1024;
-    // experimental second-generation sweep (RG_SWEEP_REG=1): rolling rows in registers, paths split over the
-    // waves of a workgroup.  Parity-green but measured slower than k_sweep on MI355X (profiles/r01_notes.md),
-    // so it is not the default.
-    const bool use_reg = C <= 16 && getenv("RG_SWEEP_REG") != nullptr;
-    if (use_reg) lds = true;   // no HBM rolling-row buffer needed
-    // packed 16-bit rows (rg_sweep16.hip) whenever the scores of this batch provably fit; RG_SWEEP_I32=1 forces k_sweep
+    // packed 16-bit rows (rg_sweep16.hip) whenever the scores of this batch provably fit; RG_SWEEP_I32=1 forces the i32
+    // kernel (test hook: the two must agree byte for byte)
     DevScores dsc;
     for (int i = 0; i < 36; ++i) dsc.t[i] = p.scores[i];
-    const bool use16 = !lds && !use_reg && !getenv("RG_SWEEP_I32") && sweep16_admissible(dsc, h.max_path_rows, max_n, C);
+    const bool use16 = !getenv("RG_SWEEP_I32") && sweep16_admissible(dsc, h.max_path_rows, max_n, C);
     auto sweep = [&](const SweepArgs& sa_, int nr) {
-        if (use_reg) launch_sweep_reg(sa_, nr, C, stream);
-        else if (use16) launch_sweep16(sa_, nr, C, stream);
-        else launch_sweep(sa_, nr, C, lds, stream);
+        if (use16) launch_sweep16(sa_, nr, C, stream);
+        else launch_sweep(sa_, nr, C, stream);
     };
     int rc;
     if (!w.tables) {
@@ -206,7 +197,7 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
     // reads per chunk: bounded by a memory budget for the per-read work buffers
     const size_t per_read = (size_t)(fdirs_stride + (mode == RG_MODE_RECOMBINATION ? rdirs_stride : 0)) * 4 +
                             (size_t)layer_stride * 4 * (mode == RG_MODE_RECOMBINATION ? 2 : 1) +
-                            (lds ? 0 : (size_t)P * wpad * 4) + (size_t)wpad * 20 + sizeof(ReadState);
+                            (size_t)P * wpad * 4 + (size_t)wpad * 20 + sizeof(ReadState);
     size_t budget = (size_t)96 << 30;
     {
         size_t fr = 0, tot = 0;
@@ -220,7 +211,7 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
         gaps_nonpos = gaps_nonpos && p.scores[x * 6 + 5] <= 0 && p.scores[5 * 6 + x] <= 0;
         for (int y = 0; y < 5; ++y) maxmatch = std::max(maxmatch, p.scores[x * 6 + y]);
     }
-    const bool two_sweep = mode == RG_MODE_RECOMBINATION && gaps_nonpos && !use_reg && !getenv("RG_THREE_SWEEPS");
+    const bool two_sweep = mode == RG_MODE_RECOMBINATION && gaps_nonpos && !getenv("RG_THREE_SWEEPS");
     // forward emissions of the two-sweep pipeline are loose (threshold from the path-0 score): k_sweep16 writes them as
     // (row, lane) records that k_expand filters with the final bound; k_sweep writes plain Cand entries
     const bool use_rec = two_sweep && use16 && !getenv("RG_NO_FREC");
@@ -241,7 +232,7 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
         if ((rc = w.state.alloc(chunk)) || (rc = w.fdirs.alloc((size_t)chunk * fdirs_stride)) ||
             (rc = w.flayer.alloc((size_t)chunk * layer_stride)))
             return rc;
-        if (!lds && (rc = w.roll.alloc((size_t)chunk * P * wpad))) return rc;
+        if ((rc = w.roll.alloc((size_t)chunk * P * wpad))) return rc;
         if (mode == RG_MODE_RECOMBINATION) {
             if ((rc = w.rdirs.alloc((size_t)chunk * rdirs_stride)) || (rc = w.rlayer.alloc((size_t)chunk * layer_stride)) ||
                 (rc = w.mf.alloc((size_t)chunk * wpad)) || (rc = w.wr.alloc((size_t)chunk * wpad)) ||

@@ -31,7 +31,7 @@ struct SweepArgs {
     const long long* read_off;
     const uint8_t* bad;
     ReadState* state;
-    int* roll;                 // [reads][P][wpad] rolling rows when they do not fit LDS
+    int* roll;                 // [reads][P][wpad] rolling rows (packed pairs for k_sweep16: half the words)
     int rev;                   // 0 forward sweep, 1 reverse sweep
     int track_best;            // maintain the best member per (row, col) (m8)
     const int* thr;            // [reads][wpad] emission thresholds by real column, or null
@@ -173,8 +173,7 @@ struct TraceArgs {
     int semi;
 };
 
-void launch_sweep(const SweepArgs& a, int nreads, int C, bool lds, hipStream_t s);
-void launch_sweep_reg(const SweepArgs& a, int nreads, int C, hipStream_t s);
+void launch_sweep(const SweepArgs& a, int nreads, int C, hipStream_t s);
 void launch_sweep16(const SweepArgs& a, int nreads, int C, hipStream_t s);   // packed 16-bit rows (rg_sweep16.hip)
 bool sweep16_admissible(const DevScores& sc, int max_path_rows, int max_n, int C);
 void launch_expand(const ExpandArgs& a, int nreads, int C, hipStream_t s);

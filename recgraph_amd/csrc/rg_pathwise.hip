@@ -6,7 +6,7 @@
 //   * lane t owns the C consecutive DP columns t*C .. t*C+C-1 (C = ceil(columns/64));
 //   * every path keeps ONE rolling row of absolute scores, stored as [q][lane] (q = column inside the
 //     lane's chunk) so that the 64 lanes of a load/store touch 64 consecutive words: conflict-free in
-//     LDS, fully coalesced in HBM.  Rows live in LDS when P*64*C*4 bytes fit (kLds), else in HBM;
+//     LDS, fully coalesced in HBM.  Rows live in HBM (L2 / Infinity-Cache resident: LDS-resident rows allow one wave per CU and measured 3.4x slower);
 //   * per (row, edge group): the group's alpha path runs the max-plus recurrence as a lane-local
 //     serial scan + one wave-level prefix-max (the "left" dependency), giving a 2-bit direction per
 //     column; every member path then follows those directions with its own values.  Runs of L are
@@ -24,25 +24,14 @@ constexpr int NEG = INT32_MIN / 4;
 #ifndef RG_SWEEP_WAVES
 #define RG_SWEEP_WAVES 2
 #endif
-#ifndef RG_SWEEP_KMAX
-#define RG_SWEEP_KMAX 0
-#endif
 
-template <bool kLds>
+// rolling rows of one read in HBM (L2 / Infinity-Cache resident), [path][q][lane]
 struct Rows {
-    int* base;  // HBM rows of this read (kLds == false)
-    __device__ __forceinline__ int ld(int k, int idx, int wpad) const;
-    __device__ __forceinline__ void st(int k, int idx, int wpad, int v) const;
+    int* base;
+    __device__ __forceinline__ int ld(int k, int idx, int wpad) const { return base[(long long)k * wpad + idx]; }
+    __device__ __forceinline__ void st(int k, int idx, int wpad, int v) const { base[(long long)k * wpad + idx] = v; }
 };
 extern __shared__ __attribute__((aligned(16))) int g_lds[];
-template <>
-__device__ __forceinline__ int Rows<true>::ld(int k, int idx, int wpad) const { return g_lds[k * wpad + idx]; }
-template <>
-__device__ __forceinline__ void Rows<true>::st(int k, int idx, int wpad, int v) const { g_lds[k * wpad + idx] = v; }
-template <>
-__device__ __forceinline__ int Rows<false>::ld(int k, int idx, int wpad) const { return base[(long long)k * wpad + idx]; }
-template <>
-__device__ __forceinline__ void Rows<false>::st(int k, int idx, int wpad, int v) const { base[(long long)k * wpad + idx] = v; }
 
 __device__ __forceinline__ int wave_excl_max(int v, int lane) {
     (void)lane;
@@ -119,12 +108,12 @@ struct RowOps {
 };
 
 // One DP sweep over the whole graph for one read.
-template <int C, bool kLds, bool kUni>
+template <int C, bool kUni>
 __global__ __launch_bounds__(64, RG_SWEEP_WAVES) void k_sweep(SweepArgs a) {
     const int rd = blockIdx.x;
     const int lane = threadIdx.x;
     const PathGraphDev& g = a.g;
-    const int P = g.P, L = g.L;
+    const int P = g.P;
     const int wpad = C * WAVE;
     ReadState* rs = a.state + rd;
     const long long ro = a.read_off[rd];
@@ -137,12 +126,12 @@ __global__ __launch_bounds__(64, RG_SWEEP_WAVES) void k_sweep(SweepArgs a) {
     const bool rev = a.rev;
     const int ncols = rev ? n : n + 1;  // mirrored columns of the reverse sweep: c' = n - j, j = n..1
     const int GAP = 5;
-    // score table in LDS (after the rolling rows when they live there)
-    int* sct = g_lds + (kLds ? P * wpad : 0);
+    // score table in LDS
+    int* sct = g_lds;
     if (lane < 36) sct[lane] = a.sc.t[lane];
     __syncthreads();
 
-    Rows<kLds> rows{kLds ? nullptr : a.roll + (long long)rd * P * wpad};
+    Rows rows{a.roll + (long long)rd * P * wpad};
     // per-column constants of this lane
     unsigned long long erp[(C + 15) / 16] = {};   // 4 bits per column: read base facing column c (forward read[c]; reverse read[n-c+1])
     int GP[kUni ? 1 : C];         // prefix sums of the read-gap cost up to column c (general matrices only)
@@ -260,7 +249,6 @@ __global__ __launch_bounds__(64, RG_SWEEP_WAVES) void k_sweep(SweepArgs a) {
     // one coalesced load (next batch in flight) and broadcasts record t with v_readlane.
     //   x: row (20 bits) | base code (3) << 20 | flags (3) << 23 | group alpha (6) << 26
     //   y: direction-word slot (24 bits) | (knm + 1) (7) << 24        z, w: member mask
-    constexpr int KMAX = RG_SWEEP_KMAX;   // rows kept in registers across the inner rows of a segment (0 = off)
     const int4* steps = rev ? a.rsteps : a.fsteps;
     const int nsteps = rev ? a.nrsteps : a.nfsteps;
     int4 recs = make_int4(0, 0, 0, 0), recs_next = make_int4(0, 0, 0, 0);
@@ -280,12 +268,7 @@ __global__ __launch_bounds__(64, RG_SWEEP_WAVES) void k_sweep(SweepArgs a) {
         gmask = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(recs.w, idx) << 32) |
                 (unsigned)__builtin_amdgcn_readlane(recs.z, idx);
     };
-    // peek at the flags of record tt without consuming it (same or next batch)
-    auto peek_w0 = [&](int tt) -> int {
-        const int idx = tt & (WAVE - 1);
-        return idx == 0 && tt > 0 ? __builtin_amdgcn_readlane(recs_next.x, 0) : __builtin_amdgcn_readlane(recs.x, idx);
-    };
-    constexpr int F_FIRST = 1, F_LAST = 2, F_INNER = 4;
+    constexpr int F_FIRST = 1, F_LAST = 2;
 
     // semiglobal end-row selection (forward sweep): the lane that owns column n folds every member value
     //   * per path: first row (>= 1) with the largest last-column value  (ending_node, recombination.rs:885-897)
@@ -327,67 +310,6 @@ __global__ __launch_bounds__(64, RG_SWEEP_WAVES) void k_sweep(SweepArgs a) {
         int ga = (w0 >> 26) & 63;
         int slot = w1 & 0xffffff;
         const int nm = __popcll(gmask);
-        if (KMAX > 0 && (flags & F_INNER) && nm <= KMAX) {
-            // ---- inner rows of a segment with a small group: rows stay in registers for the whole run ----
-            int mk[KMAX > 0 ? KMAX : 1];
-            {
-                unsigned long long tm = gmask;
-#pragma unroll
-                for (int kk = 0; kk < KMAX; ++kk) { mk[kk] = tm ? __builtin_ctzll(tm) : 0; tm = tm ? (tm & (tm - 1)) : 0; }
-            }
-            int r[KMAX > 0 ? KMAX : 1][C];
-#pragma unroll
-            for (int kk = 0; kk < KMAX; ++kk)
-                if (kk < nm) {
-#pragma unroll
-                    for (int q = 0; q < C; ++q) r[kk][q] = rows.ld(mk[kk], q * WAVE + lane, wpad);
-                }
-            while (true) {
-                const int g_i = __builtin_amdgcn_readfirstlane(sct[li * 6 + GAP]);
-                const int g0 = a.semi ? 0 : g_i;
-#pragma unroll
-                for (int q = 0; q < C; ++q) s[q] = sct[li * 6 + (int)((erp[q / 16] >> (4 * (q % 16))) & 7)];
-                unsigned dmask = 0, lmask = 0;
-                int src = 0;
-#pragma unroll
-                for (int kk = 0; kk < KMAX; ++kk)
-                    if (kk < nm && mk[kk] == ga) RowOps<C, kUni>::alpha(r[kk], s, GP, gcost, g_i, g0, lane, ncols, dmask, lmask, src);
-                if (dirs) store_dirs(slot, dmask, lmask);
-#pragma unroll
-                for (int kk = 0; kk < KMAX; ++kk)
-                    if (kk < nm && mk[kk] != ga) RowOps<C, kUni>::member(r[kk], s, GP, gcost, g_i, g0, lane, ncols, dmask, lmask, src);
-                cells += (unsigned long long)nm;
-                if (semi_end) {
-#pragma unroll
-                    for (int kk = 0; kk < KMAX; ++kk) if (kk < nm) end_fold(mk[kk], i, r[kk]);
-                    end_row_done(i);
-                }
-                if (track) {
-#pragma unroll
-                    for (int q = 0; q < C; ++q) bkey[q] = INT32_MIN;
-#pragma unroll
-                    for (int kk = 0; kk < KMAX; ++kk)
-                        if (kk < nm) {
-#pragma unroll
-                            for (int q = 0; q < C; ++q)
-                                if ((lane * C + q) < ncols) bkey[q] = max(bkey[q], r[kk][q] * 64 + mk[kk]);
-                        }
-                    row_end(i, ((w1 >> 24) & 127) - 1, bkey);
-                }
-                ++t;
-                if (t >= nsteps) break;
-                if (!((peek_w0(t) >> 23) & F_INNER)) break;     // next record starts another segment
-                fetch(t, w0, w1, gmask);
-                i = w0 & 0xfffff; li = (w0 >> 20) & 7; ga = (w0 >> 26) & 63; slot = w1 & 0xffffff;
-            }
-#pragma unroll
-            for (int kk = 0; kk < KMAX; ++kk)
-                if (kk < nm) {
-#pragma unroll
-                    for (int q = 0; q < C; ++q) rows.st(mk[kk], q * WAVE + lane, wpad, r[kk][q]);
-                }
-            continue;
-        }
         // ---- general (row, group) step ----
         const int g_i = __builtin_amdgcn_readfirstlane(sct[li * 6 + GAP]);
         const int g0 = a.semi ? 0 : g_i;
@@ -1007,31 +929,21 @@ __global__ __launch_bounds__(64) void k_trace(TraceArgs a) {
 
 // ---------------------------------------------------------------------------------
 // launchers
-template <int C, bool kUni>
-static void launch_sweep_cu(const SweepArgs& a, int nreads, bool lds, hipStream_t s) {
-    const size_t sct_bytes = 192 * sizeof(int);
-    if (lds) {
-        const size_t bytes = (size_t)a.g.P * C * WAVE * sizeof(int) + sct_bytes;
-        (void)hipFuncSetAttribute((const void*)k_sweep<C, true, kUni>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-        hipLaunchKernelGGL((k_sweep<C, true, kUni>), dim3(nreads), dim3(64), bytes, s, a);
-    } else {
-        hipLaunchKernelGGL((k_sweep<C, false, kUni>), dim3(nreads), dim3(64), sct_bytes, s, a);
-    }
-}
 template <int C>
-static void launch_sweep_c(const SweepArgs& a, int nreads, bool lds, hipStream_t s) {
+static void launch_sweep_c(const SweepArgs& a, int nreads, hipStream_t s) {
     // uniform read-gap cost: every (base, '-') entry equal (reads hold ACGTN only)
     bool uni = true;
     for (int b = 1; b < 5; ++b) uni = uni && a.sc.t[b * 6 + 5] == a.sc.t[5];
-    if (uni) launch_sweep_cu<C, true>(a, nreads, lds, s);
-    else launch_sweep_cu<C, false>(a, nreads, lds, s);
+    const size_t sct_bytes = 192 * sizeof(int);
+    if (uni) hipLaunchKernelGGL((k_sweep<C, true>), dim3(nreads), dim3(64), sct_bytes, s, a);
+    else hipLaunchKernelGGL((k_sweep<C, false>), dim3(nreads), dim3(64), sct_bytes, s, a);
 }
-void launch_sweep(const SweepArgs& a, int nreads, int C, bool lds, hipStream_t s) {
+void launch_sweep(const SweepArgs& a, int nreads, int C, hipStream_t s) {
     switch (C) {
-        case 4: launch_sweep_c<4>(a, nreads, lds, s); break;
-        case 8: launch_sweep_c<8>(a, nreads, lds, s); break;
-        case 16: launch_sweep_c<16>(a, nreads, lds, s); break;
-        default: launch_sweep_c<32>(a, nreads, lds, s); break;
+        case 4: launch_sweep_c<4>(a, nreads, s); break;
+        case 8: launch_sweep_c<8>(a, nreads, s); break;
+        case 16: launch_sweep_c<16>(a, nreads, s); break;
+        default: launch_sweep_c<32>(a, nreads, s); break;
     }
 }
 void launch_seed(const SeedArgs& a, hipStream_t s) {

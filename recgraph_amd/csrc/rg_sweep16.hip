@@ -537,8 +537,12 @@ __global__ __launch_bounds__(64, 2) void k_sweep16(SweepArgs a) {
 // Host-side admission test: uniform read-gap cost and every absolute score provably inside the 16-bit budget.
 // A cell of path k at (row i, column j) is the score of an alignment of j read bases against at most `max_path_rows`
 // graph rows: |value| <= (max_path_rows + n) * max|entry|.  NEG16 plus a few steps of drift must not wrap either.
+// Gap entries must be <= 0: the border column then holds values <= 0, so that `d - max(d, u)` of lane 0's column 0
+// (d = NEG16 + s, u = the border value) stays above -32768 and the U mask keeps its sign (a positive border value of a
+// few thousand would wrap the 16-bit difference and flip the mask).
 bool sweep16_admissible(const DevScores& sc, int max_path_rows, int max_n, int C) {
     for (int b = 1; b < 5; ++b) if (sc.t[b * 6 + 5] != sc.t[5]) return false;
+    for (int b = 0; b < 5; ++b) if (sc.t[b * 6 + 5] > 0 || sc.t[5 * 6 + b] > 0) return false;
     long long maxabs = 0;
     for (int x = 0; x < 6; ++x)
         for (int y = 0; y < 6; ++y) {

@@ -87,8 +87,50 @@ def test_bad_inputs_are_status_codes_not_aborts(rg):
         api.Graph.from_gfa_text("S\tx\tACGT\n")                       # non-numeric segment name
     with pytest.raises(_lib.RecGraphError):
         api.Graph.from_gfa_text("S\t1\tA\nS\t2\tC\nL\t1\t-\t2\t+\t0M\n")  # reverse orientation
-    with pytest.raises(_lib.RecGraphError):
-        api.Graph.from_gfa_text("S\t1\tA\nS\t2\tC\nS\t3\tG\nL\t1\t+\t3\t+\t0M\nP\tp\t1+,3+\t*\n" )  # segment 2 on no path
+
+
+def test_graphs_that_are_not_topological_are_rejected(rg):
+    """The DP kernels read rows above the current one only; a back-link would make them read rows never written
+    (ADVICE r1).  RG_ERR_GRAPH (-4) on the host instead."""
+    from recgraph_amd import _lib, api
+    for gfa in ("S\t1\tA\nS\t2\tC\nL\t2\t+\t1\t+\t0M\n",                 # back-link
+                "S\t1\tA\nS\t2\tC\nL\t1\t+\t2\t+\t0M\nL\t2\t+\t2\t+\t0M\n"):  # self-link
+        with pytest.raises(_lib.RecGraphError) as e:
+            api.Graph.from_gfa_text(gfa)
+        assert e.value.code == -4
+    ok = api.Graph.from_lnz("$AACAAAF", {1: [0], 3: [2], 4: [2], 5: [3, 4], 7: [6]})
+    assert ok.rows == 8
+    for preds in ({1: [0], 3: [4], 4: [2], 5: [3, 4], 7: [6]},     # later row
+                  {1: [0], 3: [3], 7: [6]},                         # itself
+                  {1: [0], 3: [7], 7: [6]},                         # the F row
+                  {1: [0], 7: [7]},                                 # F from F
+                  {1: [0], 3: [-1], 7: [6]}):
+        with pytest.raises(_lib.RecGraphError) as e:
+            api.Graph.from_lnz("$AACAAAF", preds)
+        assert e.value.code == -4, preds
+
+
+def test_gfa_without_a_usable_path_view_keeps_the_lnz_view(rg):
+    """Modes 0-3 only need graph::read_graph (main.rs:29): a GFA whose P lines the pathwise kernels cannot take is
+    still a graph; the reason comes back when a pathwise mode is requested."""
+    from recgraph_amd import _lib, api
+    base = "S\t1\tA\nS\t2\tC\nS\t3\tG\nL\t1\t+\t2\t+\t0M\nL\t1\t+\t3\t+\t0M\nL\t2\t+\t3\t+\t0M\n"
+    cases = {
+        "segment of row": base + "P\tp\t1+,3+\t*\n",                                   # segment 2 on no path
+        "64 paths": base + "".join("P\tp%d\t1+,2+,3+\t*\n" % k for k in range(65)),
+        "'+' path steps": base + "P\tp\t1+,2-,3+\t*\n",
+        "unknown segment": base + "P\tp\t1+,9+\t*\n",
+        "topological id order": base + "P\tp\t1+,3+,2+\t*\n",
+    }
+    for why, gfa in cases.items():
+        g = api.Graph.from_gfa_text(gfa)
+        assert g.rows == 5 and g.paths_number == 0 and why in g.path_error, (why, g.path_error)
+        assert g.dump(0) == "$ACGF" and g.dump(2) == "1:0;2:1;3:1,2;4:3;"
+        with pytest.raises(_lib.RecGraphError) as e:
+            api.Batch(g, ["ACG"], api.make_params(api.MODE_PATHWISE))
+        assert e.value.code == -4 and why in str(e.value)
+    g = api.Graph.from_gfa_text(base + "P\tp\t1+,2+,3+\t*\nP\tq\t1+,3+\t*\n")
+    assert g.paths_number == 2 and g.path_error == ""
 
 
 def test_no_cpu_fallback(rg, example_gfa):
