@@ -1,6 +1,8 @@
 """GPU, BASELINE.json's full configuration sizes: size-independent properties (determinism, shard
-invariance, CIGAR/score consistency recomputed independently of both implementations) plus oracle spot
-checks.  The oracle takes ~0.7 s per read at config 5, so only a few reads are compared byte-for-byte there."""
+invariance, CIGAR/score consistency recomputed independently of both implementations) plus a byte-for-byte
+comparison of EVERY read of the sample with the oracle (its threaded runner: ~0.8 s per read per host thread at
+config 5)."""
+import os
 import re
 
 import numpy as np
@@ -75,10 +77,11 @@ def test_c5_m8_properties(oracle, c5):
             assert _cigar_score(ops, m.group(3), rd) >= int(m.group(2))
             assert m.group(3) == sg.path_sequence(int(m.group(1)))      # global alignment spells the whole path
     assert 0 < nrec < len(reads)                  # both GAF shapes occur at config 5
-    # oracle spot checks (second restatement; ~0.7 s per read)
+    # all 384 reads byte for byte against the oracle (second restatement, sharded over the host threads)
     og = oracle.Graph.from_gfa_text(sg.gfa())
-    for i in (0, 1, 2, 3, 17, 101):
-        assert texts[i] == og.align(oracle.M8_ABS, reads[i], name=names[i])[0]
+    _, _, exp = og.bench_text(oracle.M8_ABS, reads, nthreads=min(os.cpu_count() or 1, 96), name_prefix="r", idx_base=1)
+    bad = [i for i in range(len(reads)) if texts[i].encode() != exp[i]]
+    assert not bad, (len(bad), bad[:5], texts[bad[0]][-200:], exp[bad[0]][-200:])
 
 
 def test_c5_huge_recombination_cost_equals_best_single_path(c5):
@@ -109,8 +112,9 @@ def test_c4_m4_properties(oracle):
         if int(m.group(1)) == 0:
             assert sc == int(m.group(2))     # path 0 is always its group's alpha: a plain NW optimum
     og = oracle.Graph.from_gfa_text(sg.gfa())
-    for i in (0, 5, 9):
-        assert texts[i] == og.align(oracle.M4_ABS, reads[i], name=names[i])[0]
+    _, _, exp = og.bench_text(oracle.M4_ABS, reads, nthreads=min(os.cpu_count() or 1, 96), name_prefix="r", idx_base=1)
+    bad = [i for i in range(len(reads)) if texts[i].encode() != exp[i]]
+    assert not bad, (len(bad), bad[:5])
 
 
 def test_c2_m0_full_config_vs_oracle(oracle):

@@ -147,3 +147,42 @@ def test_sweep_kernel_variants_agree(oracle, monkeypatch):
     texts, _ = api.align_batch(gg, rd[:8], None, mode=api.MODE_RECOMBINATION, score_matrix=sm)
     for i, r in enumerate(rd[:8]):
         assert texts[i] == og.align(oracle.M8_ABS, r, name="read%d" % i, scores=table)[0]
+
+
+def test_three_sweep_pipeline(oracle, monkeypatch):
+    """The -m 8 / -m 9 pipeline the driver takes when a gap entry is positive (no path-0 lower bound for the forward
+    thresholds: forward column maxima first, reverse sweep, forward again) or on request (RG_THREE_SWEEPS), with the
+    packed 16-bit sweep and with the i32 sweep.  Same records as the two-sweep pipeline, all equal to the oracle."""
+    from recgraph_amd import api, synth
+    g = synth.haplotype_graph(2500, 12, path_len=400, seed=41)
+    rd = synth.haplotype_reads(g, 30, length=400, seed=42, mosaic_frac=0.6) + [g.path_sequence(7)[:390], "ACGTTGCA" * 11]
+    gg = api.Graph.from_gfa_text(g.gfa())
+    names = ["r%d" % i for i in range(len(rd))]
+    for mode, om, reads in ((api.MODE_RECOMBINATION, oracle.M8_ABS, rd), (api.MODE_RECOMBINATION_SEMI, oracle.M9_ABS, [r[:170] for r in rd[:14]])):
+        base = _check(oracle, g.gfa(), reads, mode, om)
+        monkeypatch.setenv("RG_THREE_SWEEPS", "1")
+        t16, _ = api.align_batch(gg, reads, names[:len(reads)], mode=mode)
+        monkeypatch.setenv("RG_SWEEP_I32", "1")
+        t32, _ = api.align_batch(gg, reads, names[:len(reads)], mode=mode)
+        monkeypatch.delenv("RG_SWEEP_I32")
+        monkeypatch.delenv("RG_THREE_SWEEPS")
+        assert t16 == base and t32 == base
+    # matrices with positive gap entries (reachable through api.rs-style custom matrices only): the driver must pick
+    # the three-sweep pipeline and the i32 sweep by itself.  Uniform (+1 everywhere) and non-uniform gap costs.
+    og = oracle.Graph.from_gfa_text(g.gfa())
+    for tweak in ({"ACGTN": 1}, {"A": 2, "C": -3, "G": 1, "T": -6, "N": -2}):
+        sm = api.create_score_matrix_i32(3, -5)
+        for bases, v in tweak.items():
+            for b in bases:
+                sm[(b, "-")] = v
+                sm[("-", b)] = v
+        table = api._table_from_dict(sm)
+        for mode, om in ((api.MODE_RECOMBINATION, oracle.M8_ABS), (api.MODE_PATHWISE, oracle.M4_ABS), (api.MODE_RECOMBINATION_SEMI, oracle.M9_ABS)):
+            reads = rd[:12] if mode != api.MODE_RECOMBINATION_SEMI else [r[:170] for r in rd[:8]]
+            texts, _ = api.align_batch(gg, reads, None, mode=mode, score_matrix=sm)
+            for i, r in enumerate(reads):
+                assert texts[i] == og.align(om, r, name="read%d" % i, scores=table)[0], (tweak, mode, i)
+        # and against the LITERAL restatement (delta-encoded matrices, pruned scan) on two reads
+        texts, _ = api.align_batch(gg, rd[:2], None, mode=api.MODE_RECOMBINATION, score_matrix=sm)
+        for i in range(2):
+            assert texts[i] == og.align(oracle.M8_PRUNED, rd[i], name="read%d" % i, scores=table)[0]

@@ -54,3 +54,44 @@ def test_two_rank_gather_preserves_read_order():
         assert p.exitcode == 0
     assert text == "".join("read%04d\tGAF\n" % i for i in range(11))
     assert empty == [b"x", b""]
+
+
+def _run_bench(extra, env_extra):
+    import json
+    import subprocess
+    env = dict(os.environ, RG_BENCH_STUB="1", **env_extra)
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "C2", "--batch", "64", "--steps", "3",
+                          "--warmup", "1", "--no-cpu"] + extra, env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout          # ONE JSON line, from rank 0
+    return json.loads(lines[0])
+
+
+def test_bench_launcher_runs_the_world_2_path():
+    """`python bench.py --gpus 2` with no launcher in the environment starts two rank processes itself and runs the
+    real world > 1 code path of bench.py (process group, per-rank read shards, barrier + max-over-ranks timing, gather
+    of every step's text to rank 0) — over gloo with the device work stubbed out (RG_BENCH_STUB=1: there is no GPU
+    here), same code otherwise."""
+    weak = _run_bench(["--gpus", "2"], {})
+    assert weak["n_gpus"] == 2 and weak["scaling"] == "weak" and weak["steps"] == 3 and "STUB" in weak["data"]
+    assert "128 reads/step over all GPUs" in weak["config"]["workload"]
+    # the stub formats 'read<i>\t<16 bases>\n' per read: all 3 steps of both ranks must arrive on rank 0
+    per_rank = 3 * sum(len("read%d\t" % i) + 16 + 1 for i in range(64))
+    assert weak["gaf_bytes_gathered"] == 2 * per_rank
+    strong = _run_bench(["--gpus", "2", "--scaling", "strong"], {})
+    assert strong["n_gpus"] == 2 and strong["scaling"] == "strong"
+    assert "64 reads/step over all GPUs" in strong["config"]["workload"]
+    assert strong["gaf_bytes_gathered"] == 3 * 2 * sum(len("read%d\t" % i) + 16 + 1 for i in range(32))
+    one = _run_bench([], {})
+    assert one["n_gpus"] == 1 and one["gaf_bytes_gathered"] == per_rank
+
+
+def test_bench_refuses_a_world_size_it_was_not_asked_for():
+    import subprocess
+    env = dict(os.environ, RG_BENCH_STUB="1", WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--no-cpu"], env=env, capture_output=True,
+                         text=True, timeout=120)
+    assert out.returncode == 2 and "WORLD_SIZE" in out.stderr
