@@ -138,6 +138,25 @@ int32_t rg_result_score(const rg_batch* b, int64_t i);   /* exec(..).0 of the re
 /* seq_index is seq_name.1 of the reference (0 = score only: empty text). Returns bytes needed (excl. NUL). */
 int64_t rg_result_gaf(const rg_batch* b, int64_t i, const char* name, int64_t seq_index, char* buf, int64_t cap);
 
+/* Structured form of the same record: the fields of the reference's GAFStruct (gaf_output.rs:6-20) so that a caller
+ * (the Rust shim under shim/) builds its GAFStruct without parsing text.  query_name is the caller's.  Strings are not
+ * owned by the library: the node ids of `path` go to path_ids[0 .. n_path_ids) and `comments` (NUL-terminated) to
+ * comments[] when the capacities suffice; call once with null buffers to learn the sizes.  alignment_block_length and
+ * mapping_quality are "*" unless `empty` is set (GAFStruct::new(), gaf_output.rs:22-38: both "", strand ' ', path [0]). */
+typedef struct rg_gaf_fields {
+    int32_t has_record;          /* 0: the reference returns no GAFStruct for this read (it panics: see rg_result_status) */
+    int32_t empty;               /* 1: GAFStruct::new() ("band not enough for correct output", gaf_output.rs:861-864) */
+    uint32_t warning;            /* RG_READ_BAND_WARNING / RG_READ_BAND_NOT_ENOUGH: the stdout line printed before the record */
+    char strand;
+    uint64_t query_length, query_start, query_end;
+    uint64_t path_length, path_start, path_end;
+    uint64_t residue_matches_number;
+    int64_t n_path_ids;
+    int64_t comments_len;        /* bytes, excluding the NUL */
+} rg_gaf_fields;
+int32_t rg_result_fields(const rg_batch* b, int64_t i, rg_gaf_fields* out, uint64_t* path_ids, int64_t path_cap, char* comments,
+                         int64_t comments_cap);
+
 /* Formats every read of the batch (as rg_result_gaf would, name i = names[i] or "read<i>" when names is
  * NULL, seq_index = seq_index_base + i) into one buffer using `nthreads` host threads; returns bytes needed. */
 int64_t rg_batch_format_all(const rg_batch* b, const char* const* names, int64_t seq_index_base, char* buf,
@@ -154,6 +173,25 @@ int64_t rg_batch_kernel_launches(const rg_batch* b, int32_t k);
 /* one-shot convenience: create + run + fetch */
 int32_t rg_align_batch(const rg_graph* g, const rg_params* p, const char* reads, const int64_t* read_off,
                        int64_t nreads, rg_batch** out);
+
+/*
+ * The same read loop over several GPUs behind ONE call (the reference loop main.rs:56,174,257,297 has no order
+ * dependence between reads): the reads are cut into contiguous shards, one per entry of device_ids (NULL: every visible
+ * device), each shard runs create + run + fetch on its device from its own host thread and stream; the graph tables are
+ * uploaded once per device; nothing is exchanged between devices.  Shard k holds reads [begin_k, begin_{k+1}) and is an
+ * ordinary rg_batch, owned by the rg_multi, for the rg_result_* accessors; rg_multi_format_all concatenates the text of
+ * all shards in input order (names[i], seq_index_base + i index the whole read set).  With names == NULL the default
+ * name of read i is "read<j>", j = its index inside its shard (as rg_batch_format_all): pass names for global numbering.
+ */
+typedef struct rg_multi rg_multi;
+int32_t rg_align_batch_multi(const rg_graph* g, const rg_params* p, const char* reads, const int64_t* read_off,
+                             int64_t nreads, const int32_t* device_ids, int32_t ndev, rg_multi** out);
+int32_t rg_multi_shards(const rg_multi* m);
+rg_batch* rg_multi_batch(const rg_multi* m, int32_t k);
+int64_t rg_multi_shard_begin(const rg_multi* m, int32_t k);      /* k == shards: nreads */
+int64_t rg_multi_format_all(const rg_multi* m, const char* const* names, int64_t seq_index_base, char* buf, int64_t cap,
+                            int32_t nthreads);
+void rg_multi_destroy(rg_multi* m);
 
 const char* rg_last_error(void);
 int32_t rg_device_count(void);

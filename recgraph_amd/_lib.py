@@ -13,6 +13,13 @@ class RecGraphError(RuntimeError):
         self.code = code
 
 
+class GafFields(C.Structure):
+    _fields_ = [("has_record", C.c_int32), ("empty", C.c_int32), ("warning", C.c_uint32), ("strand", C.c_char),
+                ("query_length", C.c_uint64), ("query_start", C.c_uint64), ("query_end", C.c_uint64),
+                ("path_length", C.c_uint64), ("path_start", C.c_uint64), ("path_end", C.c_uint64),
+                ("residue_matches_number", C.c_uint64), ("n_path_ids", C.c_int64), ("comments_len", C.c_int64)]
+
+
 class Params(C.Structure):
     _fields_ = [("mode", C.c_int32), ("scores", C.c_int32 * 36), ("gap_open", C.c_int32), ("gap_ext", C.c_int32),
                 ("band_b", C.c_float), ("band_f", C.c_float), ("bta_override", C.c_int64),
@@ -37,8 +44,9 @@ def build_library(force=False):
 SYMBOLS = ["rg_params_default", "rg_scores_match_mis", "rg_graph_from_gfa", "rg_graph_create_lnz",
            "rg_graph_create_path", "rg_graph_destroy", "rg_graph_path_error", "rg_graph_rows", "rg_graph_paths", "rg_graph_dump",
            "rg_batch_create", "rg_batch_set_reads", "rg_batch_run", "rg_batch_fetch", "rg_batch_destroy", "rg_batch_size",
-           "rg_result_status", "rg_result_score", "rg_result_gaf", "rg_batch_format_all", "rg_batch_cell_updates", "rg_batch_kernel_count",
-           "rg_batch_kernel_name", "rg_batch_kernel_ms", "rg_batch_kernel_launches", "rg_align_batch", "rg_last_error",
+           "rg_result_status", "rg_result_score", "rg_result_gaf", "rg_result_fields", "rg_batch_format_all", "rg_batch_cell_updates", "rg_batch_kernel_count",
+           "rg_batch_kernel_name", "rg_batch_kernel_ms", "rg_batch_kernel_launches", "rg_align_batch", "rg_align_batch_multi", "rg_multi_shards", "rg_multi_batch", "rg_multi_shard_begin",
+           "rg_multi_format_all", "rg_multi_destroy", "rg_last_error",
            "rg_device_count", "rg_set_device"]
 
 _lib = None
@@ -81,6 +89,16 @@ def load():
     l.rg_result_score.argtypes = [vp, i64]
     l.rg_result_gaf.argtypes = [vp, i64, C.c_char_p, i64, C.c_char_p, i64]
     l.rg_result_gaf.restype = i64
+    l.rg_result_fields.argtypes = [vp, i64, P(GafFields), P(u64), i64, C.c_char_p, i64]
+    l.rg_align_batch_multi.argtypes = [vp, P(Params), C.c_char_p, P(i64), i64, P(i32), i32, P(vp)]
+    l.rg_multi_shards.argtypes = [vp]
+    l.rg_multi_batch.argtypes = [vp, i32]
+    l.rg_multi_batch.restype = vp
+    l.rg_multi_shard_begin.argtypes = [vp, i32]
+    l.rg_multi_shard_begin.restype = i64
+    l.rg_multi_format_all.argtypes = [vp, P(C.c_char_p), i64, C.c_char_p, i64, i32]
+    l.rg_multi_format_all.restype = i64
+    l.rg_multi_destroy.argtypes = [vp]
     l.rg_batch_format_all.argtypes = [vp, P(C.c_char_p), i64, C.c_char_p, i64, i32]
     l.rg_batch_format_all.restype = i64
     l.rg_batch_cell_updates.argtypes = [vp]

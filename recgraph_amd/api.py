@@ -41,25 +41,28 @@ READ_BAND_WARNING, READ_BAND_NOT_ENOUGH, READ_WOULD_PANIC, READ_BAD_BASE = 1, 2,
 # score matrices (HashMap<(char,char), i32|f32> of the reference as a dict)
 # ----------------------------------------------------------------------------------------------
 def create_score_matrix_i32(match_score=None, mismatch_score=None, matrix_file_path=None):
-    """api.rs:131-152: match/mismatch default 2/-4; any pairing with '-' scores 2*mismatch;
-    a .mtx file (score_matrix.rs:67-105) sets every gap entry to -200."""
+    """api.rs:131-152: a .mtx file (score_matrix.rs:67-105, every gap entry -200) or match/mismatch scores, where any
+    pairing with '-' scores 2*mismatch (score_matrix.rs:35-51).  Without a file both scores are required: the reference
+    unwraps them (api.rs:143-146)."""
     if matrix_file_path is not None:
         return _matrix_from_mtx(matrix_file_path)
-    m = 2 if match_score is None else match_score
-    x = -4 if mismatch_score is None else mismatch_score
+    if match_score is None or mismatch_score is None:
+        raise _lib.RecGraphError(-1, "called `Option::unwrap()` on a `None` value (api.rs:143-146)")
     out = (C.c_int32 * 36)()
-    _lib.load().rg_scores_match_mis(m, x, 0, out)
+    _lib.load().rg_scores_match_mis(match_score, mismatch_score, 0, out)
     return _dict_from_table(out)
 
 
-def create_score_matrix_f32(match_score=None, mismatch_score=None, matrix_file_path=None):
-    """api.rs:153-164: as above but the gap entries equal the mismatch score (score_matrix.rs:52-66)."""
-    if matrix_file_path is not None:
-        return {k: float(v) for k, v in _matrix_from_mtx(matrix_file_path).items()}
-    m = 2 if match_score is None else int(match_score)
-    x = -4 if mismatch_score is None else int(mismatch_score)
+def create_score_matrix_f32(match_score=None, mismatch_score=None, matrix_type=None):
+    """api.rs:153-164: the i32 matrix above with every value as f32 — so its gap entries are 2*mismatch, unlike the
+    DEFAULT matrix of align_global_no_gap / align_local_no_gap (score_matrix.rs:52-66, gap = mismatch)."""
+    return {k: float(v) for k, v in create_score_matrix_i32(match_score, mismatch_score, matrix_type).items()}
+
+
+def _score_matrix_match_mis_f32(m, x):
+    """score_matrix::create_score_matrix_match_mis_f32 (score_matrix.rs:52-66): gap entries equal the mismatch score."""
     out = (C.c_int32 * 36)()
-    _lib.load().rg_scores_match_mis(m, x, 1, out)
+    _lib.load().rg_scores_match_mis(int(m), int(x), 1, out)
     return {k: float(v) for k, v in _dict_from_table(out).items()}
 
 
@@ -264,6 +267,22 @@ class Batch:
         lib.rg_result_gaf(self._h, i, nb, seq_index, buf, n + 1)
         return buf.value.decode()
 
+    def fields(self, i, name=""):
+        """The record of read i as a GAFStruct built from rg_result_fields (no text parsing); None when the
+        reference produces no GAFStruct for it (it panics on this read)."""
+        lib = _lib.load()
+        f = _lib.GafFields()
+        check(lib.rg_result_fields(self._h, i, C.byref(f), None, 0, None, 0))
+        if not f.has_record:
+            return None
+        ids = (C.c_uint64 * max(1, f.n_path_ids))()
+        com = C.create_string_buffer(f.comments_len + 1)
+        check(lib.rg_result_fields(self._h, i, C.byref(f), ids, f.n_path_ids, com, f.comments_len + 1))
+        star = "" if f.empty else "*"
+        return GAFStruct("" if f.empty else name, f.query_length, f.query_start, f.query_end, f.strand.decode(),
+                         [int(ids[k]) for k in range(f.n_path_ids)], f.path_length, f.path_start, f.path_end,
+                         f.residue_matches_number, star, star, com.value.decode())
+
     def format_all(self, names=None, seq_index_base=1, nthreads=8):
         """All GAF text of the batch in one buffer (C++ host threads)."""
         lib = _lib.load()
@@ -292,6 +311,61 @@ class Batch:
         return {lib.rg_batch_kernel_name(self._h, k).decode(): (lib.rg_batch_kernel_ms(self._h, k),
                                                                  lib.rg_batch_kernel_launches(self._h, k))
                 for k in range(lib.rg_batch_kernel_count(self._h))}
+
+
+class _ShardView(Batch):
+    """A shard of an rg_multi: borrowed rg_batch handle (owned by the rg_multi)."""
+
+    def __init__(self, handle, n, owner):
+        self._h, self.n, self._owner = handle, n, owner
+
+    def __del__(self):
+        pass
+
+
+class MultiBatch:
+    """rg_align_batch_multi: the read loop over several GPUs behind one call (contiguous read shards, one host thread
+    and one stream per device, results in input order)."""
+
+    def __init__(self, graph, reads, params, device_ids=None):
+        lib = _lib.load()
+        self.graph = graph
+        self.n = len(reads)
+        blob = "".join(reads).encode()
+        offs = np.zeros(self.n + 1, dtype=np.int64)
+        np.cumsum([len(x) for x in reads], out=offs[1:])
+        self._h = C.c_void_p()
+        devs = (C.c_int32 * len(device_ids))(*device_ids) if device_ids is not None else None
+        check(lib.rg_align_batch_multi(graph._h, C.byref(params), blob, offs.ctypes.data_as(C.POINTER(C.c_int64)), self.n,
+                                       devs, len(device_ids) if device_ids is not None else 0, C.byref(self._h)))
+        k = lib.rg_multi_shards(self._h)
+        self.begin = [lib.rg_multi_shard_begin(self._h, i) for i in range(k + 1)]
+        self.shards = [_ShardView(C.c_void_p(lib.rg_multi_batch(self._h, i)), self.begin[i + 1] - self.begin[i], self) for i in range(k)]
+
+    def __del__(self):
+        try:
+            _lib.load().rg_multi_destroy(self._h)
+        except Exception:
+            pass
+
+    def locate(self, i):
+        """(shard, index inside the shard) of read i."""
+        import bisect
+        k = bisect.bisect_right(self.begin, i) - 1
+        return self.shards[k], i - self.begin[k]
+
+    def format_all(self, names, seq_index_base=1, nthreads=8):
+        lib = _lib.load()
+        arr = (C.c_char_p * self.n)(*[x.encode() for x in names])
+        cap = 4096 + 2048 * self.n
+        while True:
+            buf = C.create_string_buffer(cap)
+            need = lib.rg_multi_format_all(self._h, arr, seq_index_base, buf, cap, nthreads)
+            if need < 0:
+                raise _lib.RecGraphError(need, lib.rg_last_error().decode())
+            if need + 1 <= cap:
+                return buf.raw[:need]
+            cap = need + 4096
 
 
 _COMPLEMENT = {"A": "T", "C": "G", "G": "C", "T": "A", "N": "N"}
@@ -366,7 +440,7 @@ def _f32_usize(x):
 
 def align_global_no_gap(read, graph, sequence_name=None, score_matrix=None, bases_to_add=None):
     """api.rs:11-40.  Defaults: f32 matrix (2, -4, gaps -4), bases_to_add = len * 0.1, name ("no_name", 1)."""
-    sm = score_matrix if score_matrix is not None else create_score_matrix_f32(2, -4)
+    sm = score_matrix if score_matrix is not None else _score_matrix_match_mis_f32(2, -4)
     bta = _f32_usize(np.float32(len(read)) * np.float32(0.1 if bases_to_add is None else bases_to_add))
     name, idx = sequence_name if sequence_name is not None else ("no_name", 1)
     if idx == 0:
@@ -390,7 +464,7 @@ def align_global_gap(read, graph, sequence_name=None, score_matrix=None, bases_t
 
 def align_local_no_gap(read, graph, sequence_name=None, score_matrix=None):
     """api.rs:76-99.  Defaults: f32 matrix (2, -4, gaps -4), name ("no_name", 1)."""
-    sm = score_matrix if score_matrix is not None else create_score_matrix_f32(2, -4)
+    sm = score_matrix if score_matrix is not None else _score_matrix_match_mis_f32(2, -4)
     name, idx = sequence_name if sequence_name is not None else ("no_name", 1)
     if idx == 0:
         raise _lib.RecGraphError(-1, "alignment.1.unwrap() on None (api.rs:97)")

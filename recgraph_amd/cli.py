@@ -1,6 +1,6 @@
 """Command line front-end mirroring the mode dispatch of the reference's ``src/main.rs`` for the modes on
 the accelerated path (``-m 0, 1, 2, 3, 4, 5, 8, 9``): same positional arguments, flag names and defaults
-(``src/args_parser.rs:3-147``), GAF on stdout (or appended to ``-o``), ``Done in N.`` on stderr.
+(``src/args_parser.rs:3-147``), GAF on stdout (or written to ``-o`` with the reference's create/append rule, ``utils.rs:200-219``), ``Done in N.`` on stderr.
 
     python -m recgraph_amd.cli reads.fa graph.gfa -m 8 -R 4 -r 0.1 -B 1
 """
@@ -28,6 +28,26 @@ def get_sequences(path):
     if len(seqs) != len(names):
         raise SystemExit("wrong fasta file format")      # sequences.rs:41-43
     return seqs, names
+
+
+def write_gaf_records(out_file, records, numbers):
+    """utils::write_gaf (utils.rs:200-219) applied to every record in turn, with the file opened once: the reference
+    appends when the file exists and ``number != 1`` and otherwise re-creates (truncates) it.  With the 0-based numbers
+    of modes 4/5/8/9 the SECOND read has number 1: the file is truncated there and the first record is lost; the first
+    read (number 0) is appended to a file that already exists.  Same final bytes as the per-read open/append loop."""
+    import os
+    exists = os.path.exists(out_file)
+    mode, buf = None, []
+    for rec, num in zip(records, numbers):
+        if exists and num != 1:
+            mode = mode or "a"
+            buf.append(rec)
+        else:
+            mode, buf = "w", [rec]
+        exists = True
+    if mode:
+        with open(out_file, mode) as f:
+            f.write("".join(r + "\n" for r in buf))
 
 
 def build_parser():
@@ -74,12 +94,19 @@ def main(argv=None):
     for i, st in enumerate(status):
         if st & (api.READ_WOULD_PANIC | api.READ_BAD_BASE):
             raise SystemExit("read %d (%s): the reference panics on this input" % (i, names[i]))
-    out = "".join(texts)
     if a.out_file == "standard output":
-        sys.stdout.write(out)
+        sys.stdout.write("".join(texts))
     else:
-        with open(a.out_file, "w") as f:      # one write of all records (the reference re-opens per read, utils.rs:200-219)
-            f.write(out)
+        # warning lines are println!'d by the exec functions whatever -o says; only the record goes through write_gaf
+        records, numbers = [], []
+        for i, t in enumerate(texts):
+            lines = t.split("\n")[:-1]
+            sys.stdout.write("".join(ln + "\n" for ln in lines[:-1]))
+            records.append(lines[-1])
+            # main.rs passes i + 1 in modes 0-3 (:98-103, :161-166, :206-211, :246-251) and the 0-based i in modes
+            # 4, 5, 8, 9 (:260, :268, :311)
+            numbers.append(i + 1 if a.alignment_mode in (0, 1, 2, 3) else i)
+        write_gaf_records(a.out_file, records, numbers)
     sys.stderr.write("Done in %d.\n" % int(time.time() - t0))    # main.rs:319-323
 
 

@@ -180,6 +180,15 @@ struct rg_batch {
     }
 };
 
+static void rg_batch_destroy_impl(rg_batch* b) {
+    if (!b) return;
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    (void)hipSetDevice(b->dev);     // buffers and stream are freed on the device that owns them
+    delete b;
+    (void)hipSetDevice(cur);
+}
+
 namespace {
 
 struct Timed {
@@ -328,6 +337,12 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
 }
 
 extern "C" {
+
+struct rg_multi {
+    std::vector<rg_batch*> shards;
+    std::vector<int64_t> begin;    // shards.size() + 1
+    ~rg_multi() { for (rg_batch* b : shards) rg_batch_destroy_impl(b); }
+};
 
 const char* rg_last_error(void) { return g_last_error.c_str(); }
 
@@ -533,7 +548,7 @@ int32_t rg_batch_fetch(rg_batch* b) {
     return RG_OK;
 }
 
-void rg_batch_destroy(rg_batch* b) { delete b; }
+void rg_batch_destroy(rg_batch* b) { rg_batch_destroy_impl(b); }
 int64_t rg_batch_size(const rg_batch* b) { return b ? b->nreads : 0; }
 
 static uint32_t public_status(uint32_t s) { return s & 0xffu; }
@@ -547,33 +562,60 @@ int32_t rg_result_score(const rg_batch* b, int64_t i) {
     return b->rec[i].score;
 }
 
+// GAFStruct of read i (false: the reference produces none — score-only call, or it panics on this read)
+static bool build_fields(const rg_batch* b, int64_t i, const char* name, GafFields& out) {
+    const DevRecord& d = b->rec[i];
+    if (d.status & (ST_BAD_BASE | ST_WOULD_PANIC)) return false;
+    ReadRecord r;
+    r.status = public_status(d.status); r.score = d.score; r.fscore = d.fscore; r.end_row = d.end_row; r.end_col = d.end_col;
+    r.stop_row = d.stop_row; r.stop_col = d.stop_col; r.best_path = d.best_path; r.rev_path = d.rev_path; r.fen = d.fen;
+    r.rsn = d.rsn; r.rec_col = d.rec_col; r.displacement = d.displacement; r.n_ops = d.n_ops; r.n_fwd_ops = d.n_fwd_ops;
+    r.ops = b->ops.data() + (size_t)i * b->ops_stride;
+    r.rows = is_poa(b->p.mode) ? b->oprows.data() + (size_t)i * b->ops_stride : nullptr;
+    std::string read = b->reads.substr((size_t)b->off[i], (size_t)(b->off[i + 1] - b->off[i]));
+    std::string nm = name ? name : "";
+    switch (b->p.mode) {
+        case RG_MODE_GLOBAL_POA: out = fields_m0_simd(b->g->h, read, nm, r, b->p.amb_mode); break;
+        case RG_MODE_GLOBAL_POA_SCALAR:
+        case RG_MODE_GAP_POA:
+        case RG_MODE_LOCAL_POA:
+        case RG_MODE_LOCAL_POA_SCALAR:
+        case RG_MODE_GAP_LOCAL_POA: out = fields_poa_banded(b->g->h, read, nm, r, b->p.amb_mode); break;
+        default: out = fields_pathwise(b->g->h, read, nm, r, b->p.mode); break;
+    }
+    return true;
+}
+
 int64_t rg_result_gaf(const rg_batch* b, int64_t i, const char* name, int64_t seq_index, char* buf, int64_t cap) {
     if (!b || !b->fetched || i < 0 || i >= b->nreads) return fail(RG_ERR_ARG, "result not available");
     const DevRecord& d = b->rec[i];
     std::string out;
-    if ((d.status & (ST_BAD_BASE | ST_WOULD_PANIC)) == 0 && seq_index != 0) {
-        ReadRecord r;
-        r.status = public_status(d.status); r.score = d.score; r.fscore = d.fscore; r.end_row = d.end_row; r.end_col = d.end_col;
-        r.stop_row = d.stop_row; r.stop_col = d.stop_col; r.best_path = d.best_path; r.rev_path = d.rev_path; r.fen = d.fen;
-        r.rsn = d.rsn; r.rec_col = d.rec_col; r.displacement = d.displacement; r.n_ops = d.n_ops; r.n_fwd_ops = d.n_fwd_ops;
-        r.ops = b->ops.data() + (size_t)i * b->ops_stride;
-        r.rows = is_poa(b->p.mode) ? b->oprows.data() + (size_t)i * b->ops_stride : nullptr;
-        std::string read = b->reads.substr((size_t)b->off[i], (size_t)(b->off[i + 1] - b->off[i]));
-        std::string nm = name ? name : "";
-        switch (b->p.mode) {
-            case RG_MODE_GLOBAL_POA: out = format_m0_simd(b->g->h, read, nm, r, b->p.amb_mode); break;
-            case RG_MODE_GLOBAL_POA_SCALAR:
-            case RG_MODE_GAP_POA:
-            case RG_MODE_LOCAL_POA:
-            case RG_MODE_LOCAL_POA_SCALAR:
-            case RG_MODE_GAP_LOCAL_POA: out = format_poa_banded(b->g->h, read, nm, r, b->p.amb_mode); break;
-            default: out = format_pathwise(b->g->h, read, nm, r, b->p.mode); break;
-        }
-    } else if ((d.status & (ST_BAD_BASE | ST_WOULD_PANIC)) == 0 && (d.status & ST_BAND_WARNING)) {
+    GafFields f;
+    if (seq_index != 0 && build_fields(b, i, name, f)) out = f.text();
+    else if ((d.status & (ST_BAD_BASE | ST_WOULD_PANIC)) == 0 && (d.status & ST_BAND_WARNING))
         out = "Band length probably too short, maybe try with larger b and f\n";
-    }
     if (buf && (int64_t)out.size() + 1 <= cap) memcpy(buf, out.c_str(), out.size() + 1);
     return (int64_t)out.size();
+}
+
+int32_t rg_result_fields(const rg_batch* b, int64_t i, rg_gaf_fields* out, uint64_t* path_ids, int64_t path_cap, char* comments,
+                         int64_t comments_cap) {
+    if (!b || !b->fetched || i < 0 || i >= b->nreads || !out) return fail(RG_ERR_ARG, "result not available");
+    memset(out, 0, sizeof *out);
+    GafFields f;
+    if (!build_fields(b, i, "", f)) { out->strand = ' '; return RG_OK; }
+    out->has_record = 1;
+    out->empty = f.empty ? 1 : 0;
+    out->query_length = f.qlen; out->query_start = f.qstart; out->query_end = f.qend;
+    out->strand = f.strand;
+    out->path_length = f.plen; out->path_start = f.pstart; out->path_end = f.pend;
+    out->residue_matches_number = f.residues;
+    out->n_path_ids = (int64_t)f.path.size();
+    out->comments_len = (int64_t)f.comments.size();
+    out->warning = f.pre.empty() ? 0 : (f.empty ? RG_READ_BAND_NOT_ENOUGH : RG_READ_BAND_WARNING);
+    if (path_ids && path_cap >= (int64_t)f.path.size()) for (size_t k = 0; k < f.path.size(); ++k) path_ids[k] = f.path[k];
+    if (comments && comments_cap >= (int64_t)f.comments.size() + 1) memcpy(comments, f.comments.c_str(), f.comments.size() + 1);
+    return RG_OK;
 }
 
 int64_t rg_batch_format_all(const rg_batch* b, const char* const* names, int64_t seq_index_base, char* buf, int64_t cap,
@@ -623,6 +665,63 @@ int32_t rg_align_batch(const rg_graph* g, const rg_params* p, const char* reads,
     *out = b;
     return RG_OK;
 }
+
+// ---- all visible GPUs behind one call ("one call may use all visible GPUs") ----
+int32_t rg_align_batch_multi(const rg_graph* g, const rg_params* p, const char* reads, const int64_t* read_off, int64_t nreads,
+                             const int32_t* device_ids, int32_t ndev, rg_multi** out) {
+    if (!g || !p || !reads || !read_off || !out || nreads < 1) return fail(RG_ERR_ARG, "null/empty argument");
+    std::vector<int> devs;
+    if (device_ids) {
+        if (ndev < 1) return fail(RG_ERR_ARG, "empty device list");
+        devs.assign(device_ids, device_ids + ndev);
+    } else {
+        const int n = rg_device_count();
+        if (n < 1) return fail(RG_ERR_NO_DEVICE, "no HIP device");
+        for (int d = 0; d < n; ++d) devs.push_back(d);
+    }
+    if ((int64_t)devs.size() > nreads) devs.resize((size_t)nreads);
+    const int S = (int)devs.size();
+    auto m = std::make_unique<rg_multi>();
+    m->shards.assign(S, nullptr);
+    m->begin.resize(S + 1);
+    for (int k = 0; k <= S; ++k) m->begin[k] = nreads / S * k + std::min<int64_t>(k, nreads % S);   // contiguous, sizes differ by <= 1
+    std::vector<int> rcs(S, RG_OK);
+    std::vector<std::string> errs(S);
+    auto work = [&](int k) {
+        // the reference's read loop (main.rs:56,174,257,297) on this shard: one host thread, one device, one stream
+        if (hipSetDevice(devs[k]) != hipSuccess) { (void)hipGetLastError(); rcs[k] = RG_ERR_NO_DEVICE; errs[k] = "hipSetDevice(" + std::to_string(devs[k]) + ") failed"; return; }
+        rcs[k] = rg_align_batch(g, p, reads, read_off + m->begin[k], m->begin[k + 1] - m->begin[k], &m->shards[k]);
+        if (rcs[k]) errs[k] = g_last_error;     // thread-local: carry it to the caller's thread
+    };
+    std::vector<std::thread> th;
+    for (int k = 1; k < S; ++k) th.emplace_back(work, k);
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    work(0);
+    (void)hipSetDevice(cur);
+    for (auto& t : th) t.join();
+    for (int k = 0; k < S; ++k)
+        if (rcs[k]) return fail(rcs[k], "device " + std::to_string(devs[k]) + ": " + errs[k]);
+    *out = m.release();
+    return RG_OK;
+}
+int32_t rg_multi_shards(const rg_multi* m) { return m ? (int32_t)m->shards.size() : 0; }
+rg_batch* rg_multi_batch(const rg_multi* m, int32_t k) { return m && k >= 0 && k < (int32_t)m->shards.size() ? m->shards[k] : nullptr; }
+int64_t rg_multi_shard_begin(const rg_multi* m, int32_t k) { return m && k >= 0 && k <= (int32_t)m->shards.size() ? m->begin[k] : -1; }
+int64_t rg_multi_format_all(const rg_multi* m, const char* const* names, int64_t seq_index_base, char* buf, int64_t cap,
+                            int32_t nthreads) {
+    if (!m) return fail(RG_ERR_ARG, "null handle");
+    int64_t total = 0;
+    for (size_t k = 0; k < m->shards.size(); ++k) {
+        const int64_t left = buf && cap > total ? cap - total : 0;
+        const int64_t need = rg_batch_format_all(m->shards[k], names ? names + m->begin[k] : nullptr, seq_index_base + m->begin[k],
+                                                 left ? buf + total : nullptr, left, nthreads);
+        if (need < 0) return need;
+        total += need;
+    }
+    return total;
+}
+void rg_multi_destroy(rg_multi* m) { delete m; }
 
 }  // extern "C"
 

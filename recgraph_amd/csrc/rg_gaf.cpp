@@ -20,34 +20,33 @@ std::string f32_display(float v) {  // Rust `{}` for f32: shortest round-trip, f
     return std::string(b, r.ptr);
 }
 
+std::string GafFields::line() const {
+    std::string s = name;
+    s += '\t'; s += std::to_string(qlen);
+    s += '\t'; s += std::to_string(qstart);
+    s += '\t'; s += std::to_string(qend);
+    s += '\t'; s += strand;
+    s += "\t>";
+    for (size_t i = 0; i < path.size(); ++i) { if (i) s += '>'; s += std::to_string(path[i]); }
+    s += '\t'; s += std::to_string(plen);
+    s += '\t'; s += std::to_string(pstart);
+    s += '\t'; s += std::to_string(pend);
+    s += '\t'; s += std::to_string(residues);
+    s += empty ? "\t\t\t" : "\t*\t*\t";
+    s += comments;
+    return s;
+}
+
 namespace {
 
-const char* kEmptyGaf = "\t0\t0\t0\t \t>0\t0\t0\t0\t0\t\t\t";  // GAFStruct::new() (gaf_output.rs:22-38)
-
-struct Fields {
-    std::string name;
-    size_t qlen = 0, qstart = 0, qend = 0;
-    char strand = '+';
-    std::vector<uint64_t> path;
-    size_t plen = 0, pstart = 0, pend = 0, residues = 0;
-    std::string comments;
-    std::string str() const {
-        std::string s = name;
-        s += '\t'; s += std::to_string(qlen);
-        s += '\t'; s += std::to_string(qstart);
-        s += '\t'; s += std::to_string(qend);
-        s += '\t'; s += strand;
-        s += "\t>";
-        for (size_t i = 0; i < path.size(); ++i) { if (i) s += '>'; s += std::to_string(path[i]); }
-        s += '\t'; s += std::to_string(plen);
-        s += '\t'; s += std::to_string(pstart);
-        s += '\t'; s += std::to_string(pend);
-        s += '\t'; s += std::to_string(residues);
-        s += "\t*\t*\t";
-        s += comments;
-        return s;
-    }
-};
+// GAFStruct::new() (gaf_output.rs:22-38): what gaf_of_global_abpoa_simd returns when the band was not enough
+GafFields empty_gaf() {
+    GafFields f;
+    f.empty = true;
+    f.strand = ' ';
+    f.path.assign(1, 0);
+    return f;
+}
 
 // run-length text of a D/d/U/L op string: D->M, d->X, U->I, L->D
 std::string rle_cigar(const std::string& ops) {
@@ -119,10 +118,14 @@ void build_rev_ids(HostGraph& g) {
     }
 }
 
-std::string format_m0_simd(const HostGraph& g, const std::string& read, const std::string& name,
-                           const ReadRecord& r, int amb) {
+GafFields fields_m0_simd(const HostGraph& g, const std::string& read, const std::string& name,
+                         const ReadRecord& r, int amb) {
     const std::vector<uint64_t>& nid = (amb & 1) ? g.node_id_rev : g.node_id;
-    if (r.status & RG_READ_BAND_NOT_ENOUGH) return std::string("band not enough for correct output\n") + kEmptyGaf + "\n";
+    if (r.status & RG_READ_BAND_NOT_ENOUGH) {
+        GafFields e = empty_gaf();
+        e.pre = "band not enough for correct output\n";
+        return e;
+    }
     int row = r.end_row, col = r.end_col;
     std::string ops, pseq;
     std::vector<uint64_t> ids;
@@ -144,7 +147,7 @@ std::string format_m0_simd(const HostGraph& g, const std::string& read, const st
     std::reverse(pseq.begin(), pseq.end());
     dedup(ids);
     std::reverse(ids.begin(), ids.end());
-    Fields f;
+    GafFields f;
     f.name = name; f.qlen = read.size(); f.qstart = (size_t)col; f.qend = (size_t)r.end_col;
     f.strand = (amb & 2) ? '-' : '+';
     f.path = ids; f.plen = plen;
@@ -152,17 +155,17 @@ std::string format_m0_simd(const HostGraph& g, const std::string& read, const st
     f.pend = (size_t)g.seg_off[r.end_row];
     f.residues = residues;
     f.comments = rle_cigar(ops) + ", score: " + f32_display(r.fscore) + "\t" + pseq;
-    return f.str() + "\n";
+    return f;
 }
 
 // ---------------------------------------------------------------------------------
 // m0 scalar and m2: per-segment cigar strings (gaf_output.rs:96-381).  Ops flagged OP_CONT were
 // produced inside an X/Y run of the m2 walker, which does not re-check segment/direction changes.
-std::string format_poa_banded(const HostGraph& g, const std::string& read, const std::string& name,
-                              const ReadRecord& r, int amb) {
+GafFields fields_poa_banded(const HostGraph& g, const std::string& read, const std::string& name,
+                            const ReadRecord& r, int amb) {
     const std::vector<uint64_t>& nid = (amb & 1) ? g.node_id_rev : g.node_id;
-    std::string out;
-    if (r.status & RG_READ_BAND_WARNING) out += "Band length probably too short, maybe try with larger b and f\n";
+    GafFields f;
+    if (r.status & RG_READ_BAND_WARNING) f.pre = "Band length probably too short, maybe try with larger b and f\n";
     int row = r.end_row;
     std::vector<std::string> cigars;   // front insertion order reproduced by reversing at the end
     std::string cigar;
@@ -208,7 +211,6 @@ std::string format_poa_banded(const HostGraph& g, const std::string& read, const
     cigars.push_back(cigar);
     dedup(ids);
     std::reverse(ids.begin(), ids.end());
-    Fields f;
     f.name = name; f.qlen = read.size(); f.qstart = (size_t)r.stop_col; f.qend = (size_t)r.end_col;
     f.strand = (amb & 2) ? '-' : '+';
     f.path = ids; f.plen = plen;
@@ -219,16 +221,15 @@ std::string format_poa_banded(const HostGraph& g, const std::string& read, const
     std::string comments;
     for (size_t k = cigars.size(); k-- > 1;) { comments += cigars[k]; if (k > 1) comments += ","; }
     f.comments = comments;
-    out += f.str() + "\n";
-    return out;
+    return f;
 }
 
 // ---------------------------------------------------------------------------------
 // m4 / m8: the device returns D/U/L ops only; rows are re-derived by walking the chosen path.
-std::string format_pathwise(const HostGraph& g, const std::string& read, const std::string& name,
-                            const ReadRecord& r, int mode) {
+GafFields fields_pathwise(const HostGraph& g, const std::string& read, const std::string& name,
+                          const ReadRecord& r, int mode) {
     const int n = (int)read.size();
-    Fields f;
+    GafFields f;
     f.name = name; f.qlen = (size_t)n; f.qstart = 0; f.qend = (size_t)(n - 1);
     const bool rec = (mode == RG_MODE_RECOMBINATION || mode == RG_MODE_RECOMBINATION_SEMI) && r.best_path != r.rev_path;
     // semiglobal walkers stop where the read is consumed: the path may start inside the graph, and the coordinate
@@ -262,7 +263,7 @@ std::string format_pathwise(const HostGraph& g, const std::string& read, const s
         f.plen = f.pend + tail_in_segment(g, r.end_row) + 1;
         f.comments = rle_cigar(ops) + ", best path: " + std::to_string(bp) + ", score: " + std::to_string(r.score) +
                      "\t" + pseq;
-        return f.str() + "\n";
+        return f;
     }
     // recombination (recombination_output.rs:363-631)
     const int fp = r.best_path, rp = r.rev_path;
@@ -329,7 +330,7 @@ std::string format_pathwise(const HostGraph& g, const std::string& read, const s
                  std::to_string(g.node_id[r.rsn]) + "[" + std::to_string(node_off(r.rsn)) + "], score: " +
                  f32_display(r.fscore) + ", displacement: " + std::to_string(r.displacement) + "\t" + pseq + "\t" +
                  std::to_string(rec_edge);
-    return f.str() + "\n";
+    return f;
 }
 
 }  // namespace rg

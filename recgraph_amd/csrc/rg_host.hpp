@@ -84,15 +84,25 @@ struct ReadRecord {
     int32_t n_fwd_ops = 0;       // m8 rec: ops of the forward half (walk order), the rest is the reverse half
 };
 
-// GAF text exactly as the reference prints it
+// One GAFStruct (gaf_output.rs:6-20) as the host builds it from a device record, plus the warning lines the reference
+// prints on stdout before it.  text() is exactly what the reference prints for the read.
+struct GafFields {
+    std::string pre;             // "Band length probably too short..." / "band not enough for correct output" lines
+    bool empty = false;          // GAFStruct::new() (gaf_output.rs:22-38): alignment_block_length / mapping_quality are ""
+    std::string name;
+    size_t qlen = 0, qstart = 0, qend = 0;
+    char strand = '+';
+    std::vector<uint64_t> path;
+    size_t plen = 0, pstart = 0, pend = 0, residues = 0;
+    std::string comments;
+    std::string line() const;    // GAFStruct::to_string (gaf_output.rs:70-94)
+    std::string text() const { return pre + line() + "\n"; }
+};
 // amb: rg_params.amb_mode (bit 0 reversed handle ids, bit 1 strand '-')
-std::string format_m0_simd(const HostGraph& g, const std::string& read, const std::string& name, const ReadRecord& r,
-                           int amb = 0);
-std::string format_poa_banded(const HostGraph& g, const std::string& read, const std::string& name,
-                              const ReadRecord& r, int amb = 0);
+GafFields fields_m0_simd(const HostGraph& g, const std::string& read, const std::string& name, const ReadRecord& r, int amb = 0);
+GafFields fields_poa_banded(const HostGraph& g, const std::string& read, const std::string& name, const ReadRecord& r, int amb = 0);
+GafFields fields_pathwise(const HostGraph& g, const std::string& read, const std::string& name, const ReadRecord& r, int mode);
 void build_rev_ids(HostGraph& g);
-std::string format_pathwise(const HostGraph& g, const std::string& read, const std::string& name,
-                            const ReadRecord& r, int mode);
 std::string f32_display(float v);
 
 }  // namespace rg

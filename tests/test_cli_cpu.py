@@ -21,3 +21,42 @@ def test_fasta_reader(tmp_path):
     here = os.path.dirname(os.path.abspath(__file__))
     seqs, names = cli.get_sequences(os.path.join(here, "golden", "example_reads.fa"))
     assert len(seqs) == len(names) == 52 and all(len(s) == 150 for s in seqs)
+
+
+def test_out_file_semantics_follow_write_gaf(tmp_path):
+    """utils.rs:200-219 + the numbers main.rs passes: modes 0-3 create the file at the first read and append after;
+    modes 4/5/8/9 pass the 0-based index, so the file is re-created at the SECOND read (main.rs:260,268,311)."""
+    from recgraph_amd import cli
+    recs = ["rec%d" % i for i in range(4)]
+    p = tmp_path / "o.gaf"
+    cli.write_gaf_records(str(p), recs, [1, 2, 3, 4])                 # modes 0-3
+    assert p.read_text() == "rec0\nrec1\nrec2\nrec3\n"
+    cli.write_gaf_records(str(p), recs[:2], [1, 2])                    # an existing file is truncated by number 1
+    assert p.read_text() == "rec0\nrec1\n"
+    p.unlink()
+    cli.write_gaf_records(str(p), recs, [0, 1, 2, 3])                 # modes 4/5/8/9: record 0 is lost
+    assert p.read_text() == "rec1\nrec2\nrec3\n"
+    cli.write_gaf_records(str(p), recs[:1], [0])                       # one read, file exists: appended
+    assert p.read_text() == "rec1\nrec2\nrec3\nrec0\n"
+    p.unlink()
+    cli.write_gaf_records(str(p), recs[:1], [0])                       # one read, no file: created
+    assert p.read_text() == "rec0\n"
+    # literal per-read restatement of write_gaf for comparison on random cases
+    import os
+    import random
+
+    def literal(path, records, numbers):
+        for r, n in zip(records, numbers):
+            with open(path, "a" if os.path.exists(path) and n != 1 else "w") as f:
+                f.write(r + "\n")
+    rnd = random.Random(5)
+    for case in range(50):
+        k = rnd.randint(1, 5)
+        base = rnd.choice([0, 1])
+        a, b = tmp_path / ("a%d" % case), tmp_path / ("b%d" % case)
+        if rnd.random() < 0.5:
+            a.write_text("old\n")
+            b.write_text("old\n")
+        cli.write_gaf_records(str(a), recs[:k], list(range(base, base + k)))
+        literal(str(b), recs[:k], list(range(base, base + k)))
+        assert a.read_text() == b.read_text()

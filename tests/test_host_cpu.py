@@ -65,7 +65,11 @@ def test_score_matrices_and_defaults(rg):
     assert m[("A", "A")] == 10 and m[("A", "C")] == -10 and m[("N", "N")] == -10 and ("-", "-") not in m
     assert m[("A", "-")] == -20                     # any pairing with '-' = 2x (score_matrix.rs:43)
     f = api.create_score_matrix_f32(2, -4)
-    assert f[("A", "-")] == -4.0                    # f32 variant: gap = x (score_matrix.rs:52-66)
+    assert f[("A", "-")] == -8.0 and f[("A", "A")] == 2.0          # api.rs:153-164: the i32 matrix as f32 (gap = 2x)
+    d = api._score_matrix_match_mis_f32(2, -4)                     # default of align_*_no_gap (score_matrix.rs:52-66)
+    assert d[("A", "-")] == -4.0 and d[("N", "N")] == -4.0 and ("-", "-") not in d
+    with pytest.raises(Exception):
+        api.create_score_matrix_i32(2, None)                       # api.rs:143-146 unwraps both
     h = api.create_score_matrix_i32(matrix_file_path=os.path.join(HERE, "golden", "HOXD70.mtx"))
     assert h[("A", "A")] == 91 and h[("T", "G")] == -144 and h[("G", "T")] == -114 and h[("A", "-")] == -200
     p = api.make_params(8)
