@@ -102,14 +102,21 @@ class HipEngine:
         except _lib.RecGraphError:
             del self.handles[1:]
         self.rows, self.paths = self.graph.rows, self.graph.paths_number
+        self.host_s = {}
 
     def thread_init(self):
         self._lib.check(self._lib.load().rg_set_device(self.dev))     # hipSetDevice is per thread
 
     def device_part(self, h, reads):
+        t0 = time.perf_counter()
         h.set_reads(reads)      # upload inside the step
+        t1 = time.perf_counter()
         h.run()
+        t2 = time.perf_counter()
         h.fetch()
+        t3 = time.perf_counter()
+        for k, v in (("set_reads", t1 - t0), ("run", t2 - t1), ("fetch", t3 - t2)):
+            self.host_s[k] = self.host_s.get(k, 0.0) + v
         return h
 
     def format(self, h, nthreads):
@@ -131,6 +138,7 @@ class StubEngine:
             return {}
 
     def __init__(self, dev, gfa, mode, first_reads):
+        self.host_s = {}
         self.handles = [self.H(), self.H()]
         self.rows, self.paths = gfa.count("\n"), 0
 
@@ -275,7 +283,9 @@ def main():
         last = None
         fut = pool.submit(eng.device_part, hs[0], read_sets[0])
         for i in range(k):
+            tw = time.perf_counter()
             cur = fut.result()
+            eng.host_s["wait_for_device"] = eng.host_s.get("wait_for_device", 0.0) + time.perf_counter() - tw
             if i + 1 < k and len(hs) > 1:
                 fut = pool.submit(eng.device_part, hs[(i + 1) % len(hs)], read_sets[(i + 1) % len(read_sets)])
             if record:
@@ -284,7 +294,9 @@ def main():
                     acc[0] += ms
                     acc[1] += nl
                 cells_total += cur.cell_updates
+            tf = time.perf_counter()
             texts.append(eng.format(cur, nthreads))
+            eng.host_s["format"] = eng.host_s.get("format", 0.0) + time.perf_counter() - tf
             last = (cur, i % len(read_sets))
             if i + 1 < k and len(hs) == 1:
                 fut = pool.submit(eng.device_part, hs[0], read_sets[(i + 1) % len(read_sets)])
@@ -300,6 +312,7 @@ def main():
             eng.sync()
 
     sync()
+    eng.host_s.clear()
     t0 = time.perf_counter()
     texts, (last_h, last_set) = run_steps(args.steps, batches, True)
     # final gather of ALL the GAF records of the timed steps to rank 0 (RCCL over xGMI when N > 1)
@@ -381,6 +394,9 @@ def main():
                        "parallelism": "read-shard x%d" % world},
             "cell_updates_per_s": round(cells_all / dt, 1),
             "kernel_ms_per_step": {k: round(v[0] / args.steps, 3) for k, v in kstats.items()},
+            # host wall time per step: device thread = set_reads (canonicalise + upload) + run + fetch, main thread =
+            # format (+ wait_for_device when the device thread is the longer leg); the two threads overlap
+            "host_ms_per_step": {k: round(v / args.steps * 1e3, 3) for k, v in eng.host_s.items()},
             "gaf_bytes_gathered": gathered_bytes,
             "roofline": roof,
         }

@@ -429,23 +429,39 @@ static int load_reads(rg_batch* b, const char* reads, const int64_t* read_off, i
     b->off.resize(nreads + 1);
     const long long base = read_off[0];
     for (int64_t i = 0; i <= nreads; ++i) b->off[i] = read_off[i] - base;
-    b->reads.assign(reads + base, reads + read_off[nreads]);
-    b->codes.resize(b->reads.size());
+    // sequences.rs:13-22 as two 256-entry tables: canonical character ('-' -> 'N', upper case) and base code (0xff = none)
+    static const struct Canon {
+        char ch[256];
+        uint8_t code[256];
+        Canon() {
+            for (int c = 0; c < 256; ++c) {
+                const char u = c == '-' ? 'N' : (char)toupper(c);
+                ch[c] = u;
+                const int k = base_code(u);
+                code[c] = k < 0 ? 0xff : (uint8_t)k;
+            }
+        }
+    } canon;
+    const size_t total = (size_t)(read_off[nreads] - base);
+    b->reads.resize(total);
+    b->codes.resize(total);
     b->bad.assign(nreads, 0);
     b->bta.resize(nreads);
     b->max_n = 0;
+    const unsigned char* src = reinterpret_cast<const unsigned char*>(reads) + base;
     for (int64_t r = 0; r < nreads; ++r) {
         const long long n = b->off[r + 1] - b->off[r];
         if (n < 1) return fail(RG_ERR_ARG, "empty read");
         b->max_n = std::max<int>(b->max_n, (int)n);
+        unsigned any_bad = 0;
         for (long long k = b->off[r]; k < b->off[r + 1]; ++k) {
-            char c = b->reads[k];
-            c = c == '-' ? 'N' : (char)toupper((unsigned char)c);  // sequences.rs:13-22
-            b->reads[k] = c;
-            int code = base_code(c);
-            if (code < 0) { b->bad[r] = 1; code = 4; }
-            b->codes[k] = (uint8_t)code;
+            const unsigned char c = src[k];
+            const uint8_t code = canon.code[c];
+            b->reads[k] = canon.ch[c];
+            any_bad |= code == 0xff;
+            b->codes[k] = code == 0xff ? 4 : code;
         }
+        b->bad[r] = any_bad ? 1 : 0;
         // main.rs:57: (b + f * seq.len() as f32) as usize, seq.len() = n + 1
         float v = p->band_b + p->band_f * (float)(n + 1);
         long long bt = p->bta_override >= 0 ? p->bta_override : (v > 0 ? (long long)v : 0);

@@ -26,23 +26,77 @@
 constexpr int NREG = 16;     // independent chains per wave (latency of one VALU op is hidden 16 deep)
 constexpr int UNROLL = 8;    // NREG * UNROLL instructions per loop iteration
 
-enum Kind { PK_ADD, PK_MAX, PK_SUB, PK_ASHR, BITOP3, AND_OR, LSHL_OR, MAX_I32, ADD_U32, DPP_MOV, MIX, NKIND };
-static const char* kind_name[NKIND] = {"v_pk_add_u16", "v_pk_max_i16", "v_pk_sub_i16", "v_pk_ashrrev_i16", "v_bitop3_b32",
-                                       "v_and_or_b32", "v_lshl_or_b32", "v_max_i32", "v_add_u32", "v_mov_b32_dpp(row_shr:1)",
-                                       "sweep16 mix (pk_add, pk_max, pk_sub, pk_ashr, bitop3 x2, and_or, max_i32)"};
+// one entry per instruction form: asm text with %0 = the chain register (read-modify-write), %1 / %2 = two other VGPRs
+#define KINDS(X)                                                                     \
+    X(PK_ADD, "v_pk_add_u16", "v_pk_add_u16 %0, %0, %1")                            \
+    X(PK_MAX, "v_pk_max_i16", "v_pk_max_i16 %0, %0, %1")                            \
+    X(PK_MAXU, "v_pk_max_u16", "v_pk_max_u16 %0, %0, %1")                           \
+    X(PK_MIN, "v_pk_min_i16", "v_pk_min_i16 %0, %0, %1")                            \
+    X(PK_SUB, "v_pk_sub_i16", "v_pk_sub_i16 %0, %0, %1")                            \
+    X(PK_ASHR, "v_pk_ashrrev_i16", "v_pk_ashrrev_i16 %0, 1, %0")                    \
+    X(PK_LSHL, "v_pk_lshlrev_b16", "v_pk_lshlrev_b16 %0, 1, %0")                    \
+    X(PK_MAD, "v_pk_mad_i16", "v_pk_mad_i16 %0, %0, %1, %2")                        \
+    X(BITOP3, "v_bitop3_b32", "v_bitop3_b32 %0, %0, %1, %2 bitop3:0xca")            \
+    X(BFI, "v_bfi_b32", "v_bfi_b32 %0, %0, %1, %2")                                 \
+    X(AND_OR, "v_and_or_b32", "v_and_or_b32 %0, %0, %1, %2")                        \
+    X(LSHL_OR, "v_lshl_or_b32", "v_lshl_or_b32 %0, %0, 16, %1")                     \
+    X(LSHL_ADD, "v_lshl_add_u32", "v_lshl_add_u32 %0, %0, 1, %1")                   \
+    X(ADD3, "v_add3_u32", "v_add3_u32 %0, %0, %1, %2")                              \
+    X(MAX3, "v_max3_i32", "v_max3_i32 %0, %0, %1, %2")                              \
+    X(MAX_I32, "v_max_i32", "v_max_i32 %0, %0, %1")                                 \
+    X(MAX_U32, "v_max_u32", "v_max_u32 %0, %0, %1")                                 \
+    X(MIN_I32, "v_min_i32", "v_min_i32 %0, %0, %1")                                 \
+    X(MAX_I16, "v_max_i16", "v_max_i16 %0, %0, %1")                                 \
+    X(ADD_U32, "v_add_u32", "v_add_u32 %0, %0, %1")                                 \
+    X(SUB_U32, "v_sub_u32", "v_sub_u32 %0, %0, %1")                                 \
+    X(ADD_U16, "v_add_u16", "v_add_u16 %0, %0, %1")                                 \
+    X(AND_B32, "v_and_b32", "v_and_b32 %0, %0, %1")                                 \
+    X(OR_B32, "v_or_b32", "v_or_b32 %0, %0, %1")                                    \
+    X(XOR_B32, "v_xor_b32", "v_xor_b32 %0, %0, %1")                                 \
+    X(OR3, "v_or3_b32", "v_or3_b32 %0, %0, %1, %2")                                 \
+    X(LSHLREV, "v_lshlrev_b32", "v_lshlrev_b32 %0, 1, %0")                          \
+    X(ASHRREV, "v_ashrrev_i32", "v_ashrrev_i32 %0, 1, %0")                          \
+    X(BFE_I32, "v_bfe_i32", "v_bfe_i32 %0, %0, 3, 5")                               \
+    X(PERM, "v_perm_b32", "v_perm_b32 %0, %0, %1, %2")                              \
+    X(ALIGNBIT, "v_alignbit_b32", "v_alignbit_b32 %0, %0, %1, 16")                 \
+    X(MOV, "v_mov_b32", "v_mov_b32 %0, %1")                                         \
+    X(CNDMASK, "v_cndmask_b32", "v_cndmask_b32 %0, %0, %1, vcc")                    \
+    X(CMP_CND, "v_cmp_gt_i32 + v_cndmask_b32 (counted as 2)", "v_cmp_gt_i32 vcc, %0, %1\n v_cndmask_b32 %0, %0, %2, vcc") \
+    X(MAD_U24, "v_mad_u32_u24", "v_mad_u32_u24 %0, %0, %1, %2")                     \
+    X(MUL_LO, "v_mul_lo_u32", "v_mul_lo_u32 %0, %0, %1")                            \
+    X(ADD_F32, "v_add_f32", "v_add_f32 %0, %0, %1")                                 \
+    X(MAX_F32, "v_max_f32", "v_max_f32 %0, %0, %1")                                 \
+    X(FMA_F32, "v_fma_f32", "v_fma_f32 %0, %0, %1, %2")                             \
+    X(PK_ADD_F16, "v_pk_add_f16", "v_pk_add_f16 %0, %0, %1")                        \
+    X(PK_MAX_F16, "v_pk_max_f16", "v_pk_max_f16 %0, %0, %1")                        \
+    X(DPP_MOV, "v_mov_b32_dpp(row_shr:1)", "v_mov_b32_dpp %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf") \
+    X(DPP_MAX, "v_max_i32_dpp(row_shr:1)", "v_max_i32_dpp %0, %1, %0 row_shr:1 row_mask:0xf bank_mask:0xf") \
+    X(READLANE, "v_readlane_b32 (to SGPR) + v_add_u32 with it (counted as 2)", "v_readlane_b32 s20, %1, 3\n v_add_u32 %0, s20, %0")
+
+enum Kind {
+#define X(id, name, text) id,
+    KINDS(X)
+#undef X
+    MIX, MIX_ADD, NKIND
+};
+static const char* kind_name[NKIND] = {
+#define X(id, name, text) name,
+    KINDS(X)
+#undef X
+    "sweep16 mix (pk_add, pk_max, pk_sub, pk_ashr, bitop3 x2, and_or, max_i32)",
+    "alternating v_pk_max_i16 / v_add_u32"};
+static const int kind_count[NKIND] = {
+#define X(id, name, text) (id == CMP_CND || id == READLANE) ? 2 : 1,
+    KINDS(X)
+#undef X
+    1, 1};
 
 template <int K>
 __device__ __forceinline__ void op(int& r, int a, int b) {
-    if (K == PK_ADD) asm volatile("v_pk_add_u16 %0, %0, %1" : "+v"(r) : "v"(a));
-    else if (K == PK_MAX) asm volatile("v_pk_max_i16 %0, %0, %1" : "+v"(r) : "v"(a));
-    else if (K == PK_SUB) asm volatile("v_pk_sub_i16 %0, %0, %1" : "+v"(r) : "v"(a));
-    else if (K == PK_ASHR) asm volatile("v_pk_ashrrev_i16 %0, 1, %0" : "+v"(r));
-    else if (K == BITOP3) asm volatile("v_bitop3_b32 %0, %0, %1, %2 bitop3:0xca" : "+v"(r) : "v"(a), "v"(b));
-    else if (K == AND_OR) asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(r) : "s"(0xffff0000), "v"(b));
-    else if (K == LSHL_OR) asm volatile("v_lshl_or_b32 %0, %0, 16, %1" : "+v"(r) : "v"(b));
-    else if (K == MAX_I32) asm volatile("v_max_i32 %0, %0, %1" : "+v"(r) : "v"(a));
-    else if (K == ADD_U32) asm volatile("v_add_u32 %0, %0, %1" : "+v"(r) : "v"(a));
-    else if (K == DPP_MOV) asm volatile("v_mov_b32_dpp %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(r) : "v"(a));
+#define X(id, name, text) \
+    if (K == id) asm volatile(text : "+v"(r) : "v"(a), "v"(b) : "vcc", "s20");
+    KINDS(X)
+#undef X
 }
 
 template <int K>
@@ -55,8 +109,10 @@ __global__ __launch_bounds__(256) void k_valu(int iters, int a, int b, int* out)
         for (int u = 0; u < UNROLL; ++u) {
 #pragma unroll
             for (int k = 0; k < NREG; ++k) {
-                if (K == MIX) {
-                    switch ((u * NREG + k) & 7) {
+                if (K == MIX || K == MIX_ADD) {
+                    if (K == MIX_ADD) {
+                        if ((u * NREG + k) & 1) op<ADD_U32>(r[k], a, b); else op<PK_MAX>(r[k], a, b);
+                    } else switch ((u * NREG + k) & 7) {
                         case 0: op<PK_ADD>(r[k], a, b); break;
                         case 1: op<PK_MAX>(r[k], a, b); break;
                         case 2: op<PK_SUB>(r[k], a, b); break;
@@ -92,13 +148,13 @@ static double run_valu(int waves_per_simd, int ncu, int iters, int* d_out) {
     CHK(hipEventSynchronize(e1));
     float ms = 0;
     CHK(hipEventElapsedTime(&ms, e0, e1));
-    const double winstr = (double)blocks * 4.0 * (double)iters * NREG * UNROLL;
+    const double winstr = (double)blocks * 4.0 * (double)iters * NREG * UNROLL * kind_count[K];
     return winstr / (ms * 1e-3);
 }
 
 template <int K>
 static void valu_kind(int ncu, int iters, int* d_out, std::string& json) {
-    char buf[512];
+    char buf[1024];
     double v[3];
     const int w[3] = {1, 2, 4};
     for (int i = 0; i < 3; ++i) v[i] = run_valu<K>(w[i], ncu, iters, d_out);
@@ -148,19 +204,13 @@ int main(int argc, char** argv) {
     int* d_out;
     CHK(hipMalloc((void**)&d_out, 64));
     if (what == "valu") {
-        const int iters = argc > 2 ? atoi(argv[2]) : 20000;
+        const int iters = argc > 2 ? atoi(argv[2]) : 8000;
         std::string json = "{";
-        valu_kind<PK_ADD>(ncu, iters, d_out, json);
-        valu_kind<PK_MAX>(ncu, iters, d_out, json);
-        valu_kind<PK_SUB>(ncu, iters, d_out, json);
-        valu_kind<PK_ASHR>(ncu, iters, d_out, json);
-        valu_kind<BITOP3>(ncu, iters, d_out, json);
-        valu_kind<AND_OR>(ncu, iters, d_out, json);
-        valu_kind<LSHL_OR>(ncu, iters, d_out, json);
-        valu_kind<MAX_I32>(ncu, iters, d_out, json);
-        valu_kind<ADD_U32>(ncu, iters, d_out, json);
-        valu_kind<DPP_MOV>(ncu, iters, d_out, json);
+#define X(id, name, text) valu_kind<id>(ncu, iters, d_out, json);
+        KINDS(X)
+#undef X
         valu_kind<MIX>(ncu, iters, d_out, json);
+        valu_kind<MIX_ADD>(ncu, iters, d_out, json);
         char buf[256];
         snprintf(buf, sizeof buf, ", \"compute_units\": %d, \"clock_mhz\": %d, \"unit\": \"wave64 instructions per second, whole chip\"}", ncu,
                  prop.clockRate / 1000);
