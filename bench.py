@@ -5,7 +5,7 @@ Workload (BASELINE.json configs[4], the configuration the north-star target is q
 alignment (R=4 r=0.1 B=1) of synthetic 1 kbp reads against a fixed synthetic ~10 k-row / 32-path graph.  The read set is
 25 distinct batches of 4096 reads (102 400 distinct reads per GPU, seeded); a "step" is one pass of the hot path over ONE
 batch: upload of the batch's reads (rg_batch_set_reads: the timed region starts with the graph resident and the reads in
-host memory as the caller hands them over — 4 MB per step, PCIe-inclusive), two DP sweeps, candidate expansion, search,
+host memory in the C ABI's input form, bases + offsets — 4 MB per step, PCIe-inclusive), two DP sweeps, candidate expansion, search,
 layer rebuild and traceback on the device, record fetch and GAF formatting on the host.  Consecutive steps alternate
 between two batch handles so that the device part of step i+1 overlaps the host formatting of step i.  The GAF text of
 EVERY timed step is kept and gathered to rank 0 at the end (inside the timed region), over RCCL when N > 1.
@@ -107,15 +107,21 @@ class HipEngine:
     def thread_init(self):
         self._lib.check(self._lib.load().rg_set_device(self.dev))     # hipSetDevice is per thread
 
-    def device_part(self, h, reads):
+    def pack(self, reads):
+        return self._api.Batch.pack_reads(reads)        # the C ABI's input form: bases blob + offsets
+
+    def set_reads(self, h, packed):
         t0 = time.perf_counter()
-        h.set_reads(reads)      # upload inside the step
+        h.set_reads(packed)     # canonicalise + upload, inside the step (main thread: overlaps the other handle's kernels)
+        self.host_s["set_reads"] = self.host_s.get("set_reads", 0.0) + time.perf_counter() - t0
+
+    def device_part(self, h):
         t1 = time.perf_counter()
         h.run()
         t2 = time.perf_counter()
         h.fetch()
         t3 = time.perf_counter()
-        for k, v in (("set_reads", t1 - t0), ("run", t2 - t1), ("fetch", t3 - t2)):
+        for k, v in (("run", t2 - t1), ("fetch", t3 - t2)):
             self.host_s[k] = self.host_s.get(k, 0.0) + v
         return h
 
@@ -145,8 +151,13 @@ class StubEngine:
     def thread_init(self):
         pass
 
-    def device_part(self, h, reads):
-        h.reads = reads
+    def pack(self, reads):
+        return reads
+
+    def set_reads(self, h, packed):
+        h.reads = packed
+
+    def device_part(self, h):
         return h
 
     def format(self, h, nthreads):
@@ -266,10 +277,14 @@ def main():
         lo, hi = shard_bounds(batch, rank, world)
         batches = [make_reads(batch, 5678 + num + 100000 * (i + 1))[lo:hi] for i in range(nb)]
     warm = make_reads(len(batches[0]), 5678 + num + 1000 * rank)
+    nreads_step = len(batches[0])
 
     dev = local_rank
     eng = (StubEngine if stub else HipEngine)(dev, gfa, mode, warm)
     hs = eng.handles
+    batch_reads = batches                       # strings: the parity gate and the CPU legs align these
+    batches = [eng.pack(b) for b in batches]    # the C ABI's input form, built once (not part of the hot path)
+    warm_packed = eng.pack(warm)
     from concurrent.futures import ThreadPoolExecutor
     pool = ThreadPoolExecutor(1, initializer=eng.thread_init)
     cores = os.cpu_count() or 1
@@ -278,16 +293,22 @@ def main():
     cells_total = 0
 
     def run_steps(k, read_sets, record):
+        """k steps over `read_sets` (cycled).  Per step and handle: set_reads (host canonicalisation + H2D) -> device part
+        (kernels + record fetch, device thread) -> format (host threads).  With two handles the device part of step i+1
+        overlaps the formatting of step i and the set_reads of step i+2 (both on the main thread)."""
         nonlocal cells_total
         texts = []
         last = None
-        fut = pool.submit(eng.device_part, hs[0], read_sets[0])
+        nh = len(hs)
+        for j in range(min(nh, k)):
+            eng.set_reads(hs[j], read_sets[j % len(read_sets)])
+        fut = pool.submit(eng.device_part, hs[0])
         for i in range(k):
             tw = time.perf_counter()
             cur = fut.result()
             eng.host_s["wait_for_device"] = eng.host_s.get("wait_for_device", 0.0) + time.perf_counter() - tw
-            if i + 1 < k and len(hs) > 1:
-                fut = pool.submit(eng.device_part, hs[(i + 1) % len(hs)], read_sets[(i + 1) % len(read_sets)])
+            if i + 1 < k and nh > 1:
+                fut = pool.submit(eng.device_part, hs[(i + 1) % nh])
             if record:
                 for kk, (ms, nl) in cur.kernel_stats().items():      # before the handle is reused
                     acc = kstats.setdefault(kk, [0.0, 0])
@@ -298,12 +319,14 @@ def main():
             texts.append(eng.format(cur, nthreads))
             eng.host_s["format"] = eng.host_s.get("format", 0.0) + time.perf_counter() - tf
             last = (cur, i % len(read_sets))
-            if i + 1 < k and len(hs) == 1:
-                fut = pool.submit(eng.device_part, hs[0], read_sets[(i + 1) % len(read_sets)])
+            if i + nh < k:
+                eng.set_reads(cur, read_sets[(i + nh) % len(read_sets)])
+            if i + 1 < k and nh == 1:
+                fut = pool.submit(eng.device_part, hs[0])
         return texts, last
 
     if args.warmup:
-        run_steps(args.warmup, [warm], False)
+        run_steps(args.warmup, [warm_packed], False)
 
     def sync():
         eng.sync()
@@ -324,12 +347,12 @@ def main():
         tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if stub else "cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-        ct = torch.tensor([float(cells_total), float(sum(len(b) for b in batches[:1]))], dtype=torch.float64,
+        ct = torch.tensor([float(cells_total), float(nreads_step)], dtype=torch.float64,
                           device="cpu" if stub else "cuda")
         dist.all_reduce(ct, op=dist.ReduceOp.SUM)
         cells_all, reads_step_all = float(ct[0].item()), int(ct[1].item())
     else:
-        cells_all, reads_step_all = float(cells_total), len(batches[0])
+        cells_all, reads_step_all = float(cells_total), nreads_step
     rc = 0
     if rank == 0:
         total_reads = reads_step_all * args.steps
@@ -341,7 +364,7 @@ def main():
             ms = sum(v[0] for v in sweeps.values())
             launches = sum(v[1] for v in sweeps.values())
             counting = sum(v[1] for k, v in sweeps.items() if not k.endswith("_colmax")) or launches
-            reads_per_launch = len(batches[0]) * args.steps * (2 if mode == 8 else 1) / counting if mode in (4, 8) else len(batches[0])
+            reads_per_launch = nreads_step * args.steps * (2 if mode == 8 else 1) / counting if mode in (4, 8) else nreads_step
             per_launch_units = cells_total / counting            # cell-updates one sweep launch processes (this rank)
             avg_s = ms / launches / 1e3
             algo = per_launch_units * BYTES_PER_CELL_UPDATE[mode] / avg_s / 1e9
@@ -394,15 +417,15 @@ def main():
                        "parallelism": "read-shard x%d" % world},
             "cell_updates_per_s": round(cells_all / dt, 1),
             "kernel_ms_per_step": {k: round(v[0] / args.steps, 3) for k, v in kstats.items()},
-            # host wall time per step: device thread = set_reads (canonicalise + upload) + run + fetch, main thread =
-            # format (+ wait_for_device when the device thread is the longer leg); the two threads overlap
+            # host wall time per step: device thread = run + fetch, main thread = format + set_reads (canonicalise + upload
+            # of the batch two steps ahead) + wait_for_device; the two threads overlap
             "host_ms_per_step": {k: round(v / args.steps * 1e3, 3) for k, v in eng.host_s.items()},
             "gaf_bytes_gathered": gathered_bytes,
             "roofline": roof,
         }
         cpu = None
         if not args.no_cpu and not stub:
-            reads_last = batches[last_set]
+            reads_last = batch_reads[last_set]
             gpu_cores = cores if world == 1 else max(1, cores // world)
             if world == 1 and args.cpu_reads != 0:
                 cpu, checked, bad = cpu_legs(args, mode, gfa, reads_last, lambda i, nm, idx: last_h.gaf_text(i, nm, idx).encode(), gpu_cores)

@@ -233,12 +233,18 @@ class Batch:
         check(lib.rg_batch_create(graph._h, C.byref(params), blob, offs.ctypes.data_as(C.POINTER(C.c_int64)), self.n,
                                   C.byref(self._h)))
 
-    def set_reads(self, reads):
-        """Replace the reads of this handle (work buffers in HBM are kept): rg_batch_set_reads."""
-        self.n = len(reads)
-        blob = "".join(reads).encode()
-        offs = np.zeros(self.n + 1, dtype=np.int64)
+    @staticmethod
+    def pack_reads(reads):
+        """The C ABI's read-set form: (concatenated bases as bytes, int64 offsets[n + 1])."""
+        offs = np.zeros(len(reads) + 1, dtype=np.int64)
         np.cumsum([len(x) for x in reads], out=offs[1:])
+        return "".join(reads).encode(), offs
+
+    def set_reads(self, reads):
+        """Replace the reads of this handle (work buffers in HBM are kept): rg_batch_set_reads.  ``reads`` is a list of
+        strings or an already packed ``(bytes, offsets)`` pair (``pack_reads``)."""
+        blob, offs = reads if isinstance(reads, tuple) else self.pack_reads(reads)
+        self.n = len(offs) - 1
         check(_lib.load().rg_batch_set_reads(self._h, blob, offs.ctypes.data_as(C.POINTER(C.c_int64)), self.n))
 
     def __del__(self):

@@ -77,30 +77,34 @@ enum Kind {
 #define X(id, name, text) id,
     KINDS(X)
 #undef X
-    MIX, MIX_ADD, NKIND
+    MIX, MIX_ADD, MIX_BLOCK, NKIND
 };
 static const char* kind_name[NKIND] = {
 #define X(id, name, text) name,
     KINDS(X)
 #undef X
     "sweep16 mix (pk_add, pk_max, pk_sub, pk_ashr, bitop3 x2, and_or, max_i32)",
-    "alternating v_pk_max_i16 / v_add_u32"};
+    "alternating v_pk_max_i16 / v_add_u32",
+    "blocks of 64 v_add_u32 then 64 v_pk_max_i16"};
 static const int kind_count[NKIND] = {
 #define X(id, name, text) (id == CMP_CND || id == READLANE) ? 2 : 1,
     KINDS(X)
 #undef X
-    1, 1};
+    1, 1, 1};
 
 template <int K>
 __device__ __forceinline__ void op(int& r, int a, int b) {
 #define X(id, name, text) \
-    if (K == id) asm volatile(text : "+v"(r) : "v"(a), "v"(b) : "vcc", "s20");
+    if (K == id) { if (id == CNDMASK || id == CMP_CND || id == READLANE) asm volatile(text : "+v"(r) : "v"(a), "v"(b) : "vcc", "s20"); \
+                   else asm volatile(text : "+v"(r) : "v"(a), "v"(b)); }
     KINDS(X)
 #undef X
 }
 
 template <int K>
-__global__ __launch_bounds__(256) void k_valu(int iters, int a, int b, int* out) {
+__global__ __launch_bounds__(1024) void k_valu(int iters, int a, int b, int* out) {
+    extern __shared__ int lds_pad[];
+    if (iters < 0) lds_pad[threadIdx.x] = a;   // never: keeps the LDS allocation
     int r[NREG];
 #pragma unroll
     for (int k = 0; k < NREG; ++k) r[k] = threadIdx.x + k;
@@ -109,8 +113,10 @@ __global__ __launch_bounds__(256) void k_valu(int iters, int a, int b, int* out)
         for (int u = 0; u < UNROLL; ++u) {
 #pragma unroll
             for (int k = 0; k < NREG; ++k) {
-                if (K == MIX || K == MIX_ADD) {
-                    if (K == MIX_ADD) {
+                if (K == MIX || K == MIX_ADD || K == MIX_BLOCK) {
+                    if (K == MIX_BLOCK) {
+                        if (u < UNROLL / 2) op<ADD_U32>(r[k], a, b); else op<PK_MAX>(r[k], a, b);
+                    } else if (K == MIX_ADD) {
                         if ((u * NREG + k) & 1) op<ADD_U32>(r[k], a, b); else op<PK_MAX>(r[k], a, b);
                     } else switch ((u * NREG + k) & 7) {
                         case 0: op<PK_ADD>(r[k], a, b); break;
@@ -136,19 +142,22 @@ __global__ __launch_bounds__(256) void k_valu(int iters, int a, int b, int* out)
 
 template <int K>
 static double run_valu(int waves_per_simd, int ncu, int iters, int* d_out) {
-    const int blocks = ncu * waves_per_simd;   // 256 threads = 4 waves = one per SIMD
+    // one workgroup per CU (96 KB of LDS each: two cannot share a CU) of 4 * w waves = w waves on each of the 4 SIMDs
+    const int blocks = ncu;
+    const int threads = 256 * waves_per_simd;
     hipEvent_t e0, e1;
     CHK(hipEventCreate(&e0));
     CHK(hipEventCreate(&e1));
-    hipLaunchKernelGGL((k_valu<K>), dim3(blocks), dim3(256), 0, 0, iters / 8, 3, 5, d_out);   // warm-up
+    (void)hipFuncSetAttribute((const void*)k_valu<K>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    hipLaunchKernelGGL((k_valu<K>), dim3(blocks), dim3(threads), 96 * 1024, 0, iters / 8, 3, 5, d_out);   // warm-up
     CHK(hipDeviceSynchronize());
     CHK(hipEventRecord(e0, 0));
-    hipLaunchKernelGGL((k_valu<K>), dim3(blocks), dim3(256), 0, 0, iters, 3, 5, d_out);
+    hipLaunchKernelGGL((k_valu<K>), dim3(blocks), dim3(threads), 96 * 1024, 0, iters, 3, 5, d_out);
     CHK(hipEventRecord(e1, 0));
     CHK(hipEventSynchronize(e1));
     float ms = 0;
     CHK(hipEventElapsedTime(&ms, e0, e1));
-    const double winstr = (double)blocks * 4.0 * (double)iters * NREG * UNROLL * kind_count[K];
+    const double winstr = (double)blocks * 4.0 * waves_per_simd * (double)iters * NREG * UNROLL * kind_count[K];
     return winstr / (ms * 1e-3);
 }
 
@@ -211,6 +220,7 @@ int main(int argc, char** argv) {
 #undef X
         valu_kind<MIX>(ncu, iters, d_out, json);
         valu_kind<MIX_ADD>(ncu, iters, d_out, json);
+        valu_kind<MIX_BLOCK>(ncu, iters, d_out, json);
         char buf[256];
         snprintf(buf, sizeof buf, ", \"compute_units\": %d, \"clock_mhz\": %d, \"unit\": \"wave64 instructions per second, whole chip\"}", ncu,
                  prop.clockRate / 1000);
