@@ -293,7 +293,7 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
             TIMED(T, use16 ? "k_sweep16_rev" : "k_sweep_rev", sweep(r, chunk));
             if (use_rec) {
                 ExpandArgs ec{w.state.p, w.rrec.p, w.rrec_cap, w.nrrec.p, nullptr, 0, nullptr, nullptr, wpad, p.base_rec_cost, gd.knm, 1, off,
-                              p.rec_band_width};
+                              p.rec_band_width, p.scores[5]};
                 TIMED(T, "k_colmax_rec", launch_colmax_rec(ec, w.wr.p, w.wrarg.p, chunk, C, stream));
             }
             BoundArgs ba{gd, w.state.p, off, w.mf.p, w.mfarg.p, w.wr.p, w.wrarg.p, wpad, p.base_rec_cost, p.multi_rec_cost,
@@ -310,9 +310,9 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
             if (use_rec) {
                 HIPCHK(hipMemsetAsync(w.nf.p, 0, sizeof(unsigned) * chunk, stream));
                 HIPCHK(hipMemsetAsync(w.nr.p, 0, sizeof(unsigned) * chunk, stream));
-                ExpandArgs ea{w.state.p, w.frec.p, w.frec_cap, w.nrec.p, w.fcand.p, w.fcap, w.nf.p, w.wr.p, wpad, p.base_rec_cost, gd.knm, 0, off, p.rec_band_width};
+                ExpandArgs ea{w.state.p, w.frec.p, w.frec_cap, w.nrec.p, w.fcand.p, w.fcap, w.nf.p, w.wr.p, wpad, p.base_rec_cost, gd.knm, 0, off, p.rec_band_width, p.scores[5]};
                 TIMED(T, "k_expand", launch_expand(ea, chunk, C, stream));
-                ExpandArgs er{w.state.p, w.rrec.p, w.rrec_cap, w.nrrec.p, w.rcand.p, w.rcap, w.nr.p, w.mf.p, wpad, p.base_rec_cost, gd.knm, 1, off, p.rec_band_width};
+                ExpandArgs er{w.state.p, w.rrec.p, w.rrec_cap, w.nrrec.p, w.rcand.p, w.rcap, w.nr.p, w.mf.p, wpad, p.base_rec_cost, gd.knm, 1, off, p.rec_band_width, p.scores[5]};
                 TIMED(T, "k_expand", launch_expand(er, chunk, C, stream));
             }
             SearchArgs sr{gd, w.state.p, w.fcand.p, w.rcand.p, w.nf.p, w.nr.p, w.ridx.p, w.fcap, w.rcap, w.wr.p, wpad, p.base_rec_cost,

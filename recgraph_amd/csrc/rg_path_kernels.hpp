@@ -76,6 +76,7 @@ struct ExpandArgs {
     int rev;                   // records of the reverse sweep: lane columns are mirrored (real column = n - c)
     const long long* read_off;
     float rbw;                 // -B
+    int gcost;                 // uniform read-gap cost: the records hold z-space keys (z = A - c * gcost, rg_sweep16.hip)
 };
 
 struct SeedArgs {

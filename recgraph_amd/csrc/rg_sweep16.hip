@@ -13,6 +13,11 @@
 // stitched with 32-bit per-lane arithmetic (a dozen instructions per row update) and one wave-level DPP prefix max
 // exactly like the i32 kernel.  Rows in HBM are [path][r][lane] packed words.
 //
+// Rows are kept in "z-space": the word of column c holds z = A - c * g (g = the uniform read-gap cost, what an L move
+// adds per column).  An L run then copies z unchanged (no add in the left scan and in the members' fill-forward), the
+// diagonal adds s - g, and the cross-lane stitching needs no column arithmetic.  z >= A (g <= 0): the admission test
+// bounds it; every output converts back (A = z + c * g).
+//
 // Outputs (direction words, column maxima, candidates, sink values, semiglobal end rows) are identical to k_sweep's;
 // the argument recorded for a column maximum may be a different cell with the same value (k_bound only needs a real
 // cell: any candidate pair gives a valid lower bound).  Everything downstream is shared.
@@ -56,16 +61,16 @@ __device__ __forceinline__ int bfi(int mask, int a, int b) {
     return __builtin_amdgcn_bitop3_b32(mask, a, b, 0xCA);   // (mask & a) | (~mask & b) in ONE v_bitop3_b32
 }
 
-// Row operators on packed rows.  MU / ML: per register, 0xffff in the halves whose column took U (not D) / L.
+// Row operators on packed z-space rows.  MU / ML: per register, 0xffff in the halves whose column took U (not D) / L.
+// s[] holds the packed pairs (s - g): z_d = z_prev + (s - g), z_u = z_old + g_i, z_l = z_left.
 template <int C>
 struct RowOps16 {
     static constexpr int H = C / 2;
     // bit r = column r of the lane (low half), bit 16 + r = column H + r (high half)
     static constexpr unsigned FULL = H >= 16 ? 0xffffffffu : ((((1u << H) - 1u) << 16) | ((1u << H) - 1u));
 
-    static __device__ __forceinline__ void alpha(int (&row)[H], const int (&s)[H], int g, int g_i, int g0, int lane,
+    static __device__ __forceinline__ void alpha(int (&row)[H], const int (&s)[H], int g_i, int g0, int lane,
                                                  int (&MU)[H], int (&ML)[H], unsigned& umask, unsigned& lmask, int& src) {
-        const int G2 = pack16(g, g);
         const int GI = pack16(g_i, g_i);
         const int GI0 = lane == 0 ? pack16(g0, g_i) : GI;          // border column 0 adds g0
         int prev = __builtin_amdgcn_alignbit(row[H - 1], dpp_shr1(row[H - 1], NEGPAIR), 16);
@@ -78,23 +83,22 @@ struct RowOps16 {
             const int du = pk_max(d, u);                            // D on ties (d >= u); lane 0 column 0: d = -inf -> U
             MU[r] = pk_sign(pk_sub(d, du));                         // d - max(d, u) < 0 where U (|d - u| is a few scores: no wrap)
             um |= (unsigned)MU[r] & ((unsigned)ONE2 << r);
-            run = pk_max(du, pk_add(run, G2));                      // chain without carry-in, for the totals
+            run = pk_max(du, run);                                  // prefix maxima of the two half chains (no carry-in)
             row[r] = du;
             prev = old;
         }
-        // stitch: value at the lane's last column reachable from sources inside the lane, in z-space (v - c*g)
+        // stitch: best source inside the lane = max of both chains; left scan over the lanes in z-space is a plain
+        // prefix maximum
         const int TL = lo16(run), TH = hi16(run);
-        const int E = max(TH, TL + H * g);
-        const int z = E - (lane * C + C - 1) * g;
-        const int ze = dpp_shr1(dpp_incl_max(z, NEG32), NEG32);     // best source of the lanes to the left
-        const int bl = max(ze + (lane * C - 1) * g, NEG16);         // value "at column lane*C - 1"
-        const int bh = max(max(TL, bl + H * g), NEG16);             // value at column lane*C + H - 1
+        const int ze = dpp_shr1(dpp_incl_max(max(TH, TL), NEG32), NEG32);   // best source of the lanes to the left
+        const int bl = max(ze, NEG16);                              // carry into the lane's first column
+        const int bh = max(TL, bl);                                 // carry into column H of the lane
         int vprev = pack16(bl, bh);
         unsigned lm = 0;
 #pragma unroll
         for (int r = 0; r < H; ++r) {
             const int du = row[r];
-            const int v = pk_max(du, pk_add(vprev, G2));
+            const int v = pk_max(du, vprev);
             ML[r] = pk_sign(pk_sub(du, v));                         // du - max(du, left) < 0 where L (left strictly better)
             lm |= (unsigned)ML[r] & ((unsigned)ONE2 << r);
             row[r] = v;
@@ -106,13 +110,12 @@ struct RowOps16 {
         umask = um; lmask = lm;
     }
 
-    static __device__ __forceinline__ void member(int (&row)[H], const int (&s)[H], int g, int g_i, int g0, int lane,
+    static __device__ __forceinline__ void member(int (&row)[H], const int (&s)[H], int g_i, int g0, int lane,
                                                   const int (&MU)[H], const int (&ML)[H], unsigned lmask, int src) {
-        const int G2 = pack16(g, g);
         const int GI = pack16(g_i, g_i);
         const int GI0 = lane == 0 ? pack16(g0, g_i) : GI;
         int prev = __builtin_amdgcn_alignbit(row[H - 1], dpp_shr1(row[H - 1], NEGPAIR), 16);
-        int lastv = NEGPAIR;                                        // base of the last non-L column of each half
+        int lastv = NEGPAIR;                                        // z of the last non-L column of each half
 #pragma unroll
         for (int r = 0; r < H; ++r) {
             const int old = row[r];
@@ -121,21 +124,18 @@ struct RowOps16 {
             lastv = bfi(ML[r], lastv, base);
             prev = old;
         }
-        // z-value of the lane's last non-L column, fetched by the lanes to the right that start with L columns
+        // z of the lane's last non-L column, fetched by the lanes to the right that start with L columns
         const unsigned nl = ~lmask & FULL;
         const unsigned nl_lo = nl & 0xffffu, nl_hi = nl >> 16;
-        const int p_lo = 31 - __clz((int)(nl_lo | 1u)), p_hi = 31 - __clz((int)(nl_hi | 1u));
         const int v_lo = lo16(lastv), v_hi = hi16(lastv);
-        int zl = NEG32;
-        if (nl_lo) zl = v_lo - (lane * C + p_lo) * g;
-        if (nl_hi) zl = v_hi - (lane * C + H + p_hi) * g;
+        const int zl = nl_hi ? v_hi : (nl_lo ? v_lo : NEG32);
         const int cur = __shfl(zl, src, WAVE);
-        const int bl = max(cur + (lane * C - 1) * g, NEG16);
-        const int bh = max(nl_lo ? v_lo + (H - 1 - p_lo) * g : bl + H * g, NEG16);
+        const int bl = max(cur, NEG16);
+        const int bh = nl_lo ? max(v_lo, NEG16) : bl;
         int vprev = pack16(bl, bh);
 #pragma unroll
         for (int r = 0; r < H; ++r) {
-            const int v = bfi(ML[r], pk_add(vprev, G2), row[r]);
+            const int v = bfi(ML[r], vprev, row[r]);
             row[r] = v;
             vprev = v;
         }
@@ -150,7 +150,8 @@ struct RowOps16 {
 
 // kColmax = false: no per-column maxima (the reverse sweep of the record pipeline: its maxima and their cells are
 // taken from its own records by k_colmax_rec)
-template <int C, bool kColmax>
+// kRec = true: emissions leave as (row, lane) records (a.frec); false: as Cand entries (a.cand) or not at all
+template <int C, bool kColmax, bool kRec>
 __global__ __launch_bounds__(64, 2) void k_sweep16(SweepArgs a) {
     constexpr int H = C / 2;
     constexpr int KRUN = C <= 16 ? RG_SWEEP16_KRUN : 0;   // rows kept in registers across the inner rows of a segment
@@ -178,18 +179,38 @@ __global__ __launch_bounds__(64, 2) void k_sweep16(SweepArgs a) {
     int* s2 = lds16 + 192;               // [5][64] packed score pairs: s2[li*64 + (code_lo | code_hi << 3)]
     if (lane < 36) sct[lane] = a.sc.t[lane];
     __syncthreads();
+    const int gcost = sct[GAP];          // uniform read-gap cost (checked by the launcher): the z-space slope
     for (int e = lane; e < 5 * 64; e += WAVE) {
         const int li = e >> 6, cl = e & 7, ch = (e >> 3) & 7;
-        s2[e] = (cl < 6 && ch < 6) ? pack16(sct[li * 6 + cl], sct[li * 6 + ch]) : 0;
+        s2[e] = (cl < 6 && ch < 6) ? pack16(sct[li * 6 + cl] - gcost, sct[li * 6 + ch] - gcost) : 0;   // diagonal step in z-space
     }
     int* rows = a.roll + (long long)rd * P * wrow;
-    const int gcost = sct[GAP];          // uniform read-gap cost (checked by the launcher)
     // per-column constants of this lane
     unsigned long long pcode[(H + 7) / 8] = {};   // 8 bits per register: code_lo | code_hi << 3
     int thrk[C];                         // emission threshold << 16 per column (INT32_MAX = never; columns that do not exist)
     int minthrk = INT32_MAX;             // lowest threshold of the lane
+    int minplain = INT32_MAX;            // lowest threshold of the lane without the member rule (rows every path visits)
     const bool tight = a.thr != nullptr; // thresholds from the other sweep's column maxima
     const int oob = max((int)((float)(n + 1) * (1.0f - a.rbw) / 2.0f), 1);
+    // Emission threshold of lane column q as a z-space key (z << 16): keys are z << 16 | path with |z| < 2^15, so a
+    // threshold outside that range means always / never.  `member_rule`: additionally require a true value >= 0 with
+    // key >= 1, which every cell whose winner is a member path satisfies when some path is NOT through the row (the
+    // reference's non-member entries are 0: knm >= 0); rows that every path visits (knm < 0) use the plain threshold.
+    auto thr_key = [&](int q, bool member_rule) -> int {
+        const int c = lane * C + q;
+        const int j = rev ? n - c : c;
+        int th = INT32_MAX;
+        if (c < ncols && j >= oob && j < n + 1 - oob) {
+            if (a.thr) th = a.thr[(long long)rd * wpad + j];
+            else if (a.lb) th = a.lb[rd] + a.brc - (n - j) * a.maxmatch;
+        }
+        if (th == INT32_MAX) return INT32_MAX;
+        long long tz = (long long)th - (long long)c * gcost;       // threshold on z
+        if (tz > 32767) return INT32_MAX;
+        int key = tz < -32768 ? INT32_MIN : (int)tz * 65536;
+        if (member_rule) key = max(key, (-c * gcost) * 65536 + 1);  // true key >= 1  <=>  z key >= (-c g) << 16 | 1
+        return key;
+    };
     {
 #pragma unroll
         for (int q = 0; q < C; ++q) {
@@ -198,23 +219,16 @@ __global__ __launch_bounds__(64, 2) void k_sweep16(SweepArgs a) {
             if (c >= 1 && c < ncols) code = rev ? read[n - c + 1] : read[c];
             const int r = q % H, hi = q / H;
             pcode[r / 8] |= (unsigned long long)code << (8 * (r % 8) + 3 * hi);
-            const int j = rev ? n - c : c;
-            int th = INT32_MAX;
-            if (c < ncols && j >= oob && j < n + 1 - oob) {
-                if (a.thr) th = a.thr[(long long)rd * wpad + j];
-                else if (a.lb) th = a.lb[rd] + a.brc - (n - j) * a.maxmatch;
-            }
-            // keys are value << 16 | path with |value| < 2^15: thresholds outside that range mean always / never
-            thrk[q] = th > 32767 ? INT32_MAX : (th < -32768 ? INT32_MIN : th * 65536);
+            thrk[q] = thr_key(q, true);
         }
-        // start rows: the gap-only row, identical for every path (uniform gap cost: c * gcost)
+        // start rows: the gap-only row, identical for every path (uniform gap cost: A = c * gcost, z = 0)
 #pragma unroll
-        for (int q = 0; q < C; ++q) minthrk = min(minthrk, thrk[q]);
+        for (int q = 0; q < C; ++q) { minthrk = min(minthrk, thrk[q]); minplain = min(minplain, thr_key(q, false)); }
         for (int k = 0; k < P; ++k) {
 #pragma unroll
             for (int r = 0; r < H; ++r) {
                 const int c0 = lane * C + r, c1 = c0 + H;
-                rows[(long long)k * wrow + r * WAVE + lane] = pack16(c0 < ncols ? c0 * gcost : NEG16, c1 < ncols ? c1 * gcost : NEG16);
+                rows[(long long)k * wrow + r * WAVE + lane] = pack16(c0 < ncols ? 0 : NEG16, c1 < ncols ? 0 : NEG16);
             }
         }
     }
@@ -225,7 +239,7 @@ __global__ __launch_bounds__(64, 2) void k_sweep16(SweepArgs a) {
     for (int q = 0; q < (kColmax ? C : 1); ++q) { ckey[q] = INT32_MIN; crow[q] = 0; }
     unsigned ncand = 0;
     unsigned long long cells = 0;
-    Cand* cand = a.cand ? a.cand + (long long)rd * a.cand_cap : nullptr;
+    Cand* cand = !kRec && a.cand ? a.cand + (long long)rd * a.cand_cap : nullptr;
     uint32_t* dirs = a.dirs ? a.dirs + (long long)rd * a.dirs_stride : nullptr;
     const bool track = a.track_best;
 
@@ -237,7 +251,6 @@ __global__ __launch_bounds__(64, 2) void k_sweep16(SweepArgs a) {
         // The column maxima ignore that rule (k_bound re-checks the recorded cell; an unusable cell has value <= 0 and
         // can only raise a non-positive maximum, which loosens thresholds, never tightens them); emissions apply it
         // (it removes most of the negative-valued cells the loose forward thresholds would let through).
-        const int kthr = knm >= 0 ? knm : INT32_MIN;
         unsigned emask = 0;
         if (kColmax) {
 #pragma unroll
@@ -254,17 +267,23 @@ __global__ __launch_bounds__(64, 2) void k_sweep16(SweepArgs a) {
             int mx = bkey[0];
 #pragma unroll
             for (int q = 1; q < C; ++q) mx = max(mx, bkey[q]);
-            test = __any(mx >= minthrk);
+            test = __any(mx >= (knm >= 0 ? minthrk : minplain));
         }
-        if (a.frec) {
+        if (kRec) {
             // One fixed-size record per (row, lane) with any column above its threshold (1 + C/4 16-byte stores);
-            // k_expand re-tests every key with the final bound, which implies the threshold, so no per-lane column
-            // mask is needed: the compares only feed a ballot (VALU compare + scalar OR per column).
+            // k_expand re-tests every key with the final bound and the exact member-winner rule, so no per-lane column
+            // mask is needed: the compares only feed a ballot (VALU compare + scalar OR per column).  thrk already
+            // holds the member rule's necessary condition (true key >= 1); the few rows every path visits (knm < 0:
+            // the rule is void there) test against the lane's lowest plain threshold instead (a superset).
             unsigned long long has = 0;
             if (test) {
-                // bkey >= thr and bkey > kthr in one compare (kthr + 1 does not overflow: kthr is INT32_MIN or < 64)
+                if (knm >= 0) {
 #pragma unroll
-                for (int q = 0; q < C; ++q) has |= __ballot(bkey[q] >= max(thrk[q], kthr + 1));
+                    for (int q = 0; q < C; ++q) has |= __ballot(bkey[q] >= thrk[q]);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < C; ++q) has |= __ballot(bkey[q] >= minplain);
+                }
             }
             if (has) {
                 const unsigned before = __builtin_amdgcn_mbcnt_hi((unsigned)(has >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)has, 0u));
@@ -280,8 +299,13 @@ __global__ __launch_bounds__(64, 2) void k_sweep16(SweepArgs a) {
             return;
         }
         if (test) {
+            // Cand entries go to k_search unfiltered: the exact member-winner rule (true key > knm) applies here
+            const int gz = gcost * 65536;
 #pragma unroll
-            for (int q = 0; q < C; ++q) emask |= bkey[q] >= max(thrk[q], kthr + 1) ? (1u << q) : 0u;
+            for (int q = 0; q < C; ++q) {
+                const int tkey = bkey[q] + (lane * C + q) * gz;    // true key: value << 16 | path
+                emask |= (knm >= 0 ? (bkey[q] >= thrk[q] && tkey > knm) : bkey[q] >= minplain) ? (1u << q) : 0u;
+            }
         }
         if (cand && __any(emask != 0)) {
             const int cnt = __popc(emask);
@@ -294,7 +318,7 @@ __global__ __launch_bounds__(64, 2) void k_sweep16(SweepArgs a) {
                     if (pos < a.cand_cap) {
                         const int c = lane * C + q;
                         Cand cd;
-                        cd.row = i; cd.col = rev ? n - c : c; cd.val = bkey[q] >> 16; cd.path = bkey[q] & 0xffff;
+                        cd.row = i; cd.col = rev ? n - c : c; cd.val = (bkey[q] >> 16) + c * gcost; cd.path = bkey[q] & 0xffff;
                         cand[pos] = cd;
                     }
                     ++pos;
@@ -351,7 +375,7 @@ __global__ __launch_bounds__(64, 2) void k_sweep16(SweepArgs a) {
         int pv = 0;
 #pragma unroll
         for (int r = 0; r < H; ++r) if (r == ql_end % H) pv = row[r];
-        const int v = ql_end >= H ? hi16(pv) : lo16(pv);
+        const int v = (ql_end >= H ? hi16(pv) : lo16(pv)) + n * gcost;      // column n: A = z + n * g
         if (lane == ln_end) {
             if (v > endv[k]) { endv[k] = v; endr[k] = i; }
             rowkey = max(rowkey, v * 64 + (63 - k));
@@ -424,11 +448,11 @@ __global__ __launch_bounds__(64, 2) void k_sweep16(SweepArgs a) {
                 for (int r = 0; r < H; ++r) s[r] = s2[rli * 64 + (int)((pcode[r / 8] >> (8 * (r % 8))) & 63)];
                 unsigned umask, lmask;
                 int src;
-                RowOps16<C>::alpha(rr[0], s, gcost, g_i, g0, lane, MU, ML, umask, lmask, src);
+                RowOps16<C>::alpha(rr[0], s, g_i, g0, lane, MU, ML, umask, lmask, src);
                 if (dirs) store_dirs(rslot, umask, lmask);
 #pragma unroll
                 for (int kk = 1; kk < KRUN; ++kk)
-                    if (kk < nm) RowOps16<C>::member(rr[kk], s, gcost, g_i, g0, lane, MU, ML, lmask, src);
+                    if (kk < nm) RowOps16<C>::member(rr[kk], s, g_i, g0, lane, MU, ML, lmask, src);
                 cells += (unsigned long long)nm;
                 if (track) {
                     set_keys(bkey, rr[0], mk[0]);
@@ -478,7 +502,7 @@ __global__ __launch_bounds__(64, 2) void k_sweep16(SweepArgs a) {
             }
             unsigned umask, lmask;
             int src;
-            RowOps16<C>::alpha(rowa, s, gcost, g_i, g0, lane, MU, ML, umask, lmask, src);
+            RowOps16<C>::alpha(rowa, s, g_i, g0, lane, MU, ML, umask, lmask, src);
 #pragma unroll
             for (int r = 0; r < H; ++r) rows[(long long)ga * wrow + r * WAVE + lane] = rowa[r];
             if (track) { if (flags & F_FIRST) set_keys(bkey, rowa, ga); else fold_keys(bkey, rowa, ga); }
@@ -495,7 +519,7 @@ __global__ __launch_bounds__(64, 2) void k_sweep16(SweepArgs a) {
 #pragma unroll
                     for (int r = 0; r < H; ++r) nxt[r] = rows[(long long)knext * wrow + r * WAVE + lane];
                 } else knext = -1;
-                RowOps16<C>::member(cur, s, gcost, g_i, g0, lane, MU, ML, lmask, src);
+                RowOps16<C>::member(cur, s, g_i, g0, lane, MU, ML, lmask, src);
 #pragma unroll
                 for (int r = 0; r < H; ++r) rows[(long long)k * wrow + r * WAVE + lane] = cur[r];
                 if (track) fold_keys(bkey, cur, k);
@@ -513,7 +537,7 @@ __global__ __launch_bounds__(64, 2) void k_sweep16(SweepArgs a) {
         for (int q = 0; q < C; ++q) {
             const int c = lane * C + q;
             if (c < ncols) {
-                a.colmax_out[(long long)rd * wpad + (rev ? n - c : c)] = ckey[kColmax ? q : 0] == INT32_MIN ? NEG32 : ckey[kColmax ? q : 0] >> 16;
+                a.colmax_out[(long long)rd * wpad + (rev ? n - c : c)] = ckey[kColmax ? q : 0] == INT32_MIN ? NEG32 : (ckey[kColmax ? q : 0] >> 16) + c * gcost;
                 if (a.colarg_out) a.colarg_out[(long long)rd * wpad + (rev ? n - c : c)] = (crow[kColmax ? q : 0] << 8) | (ckey[kColmax ? q : 0] & 63);
             }
         }
@@ -524,7 +548,7 @@ __global__ __launch_bounds__(64, 2) void k_sweep16(SweepArgs a) {
         const int ql = n % C, ln = n / C;
         for (int k = lane; k < P; k += WAVE) {
             const int pv = rows[(long long)k * wrow + (ql % H) * WAVE + ln];
-            rs->sink_val[k] = ql >= H ? hi16(pv) : lo16(pv);
+            rs->sink_val[k] = (ql >= H ? hi16(pv) : lo16(pv)) + n * gcost;
         }
     }
     if (semi_end) {
@@ -551,7 +575,9 @@ bool sweep16_admissible(const DevScores& sc, int max_path_rows, int max_n, int C
             maxabs = std::max(maxabs, v < 0 ? -v : v);
         }
     if (maxabs > 1000) return false;
-    if ((long long)(max_path_rows + max_n + 2) * maxabs > 24000) return false;
+    if ((long long)(max_path_rows + max_n + 2) * maxabs > 24000) return false;      // |A| of every cell
+    // z = A - c * g <= max A + n * |g|: stay clear of the 16-bit top as well (thresholds and keys use z << 16)
+    if ((long long)(max_path_rows + max_n + 2) * maxabs + (long long)(max_n + 2) * maxabs > 30000) return false;
     if ((long long)(C / 2 + 2) * maxabs > 2000) return false;
     return true;
 }
@@ -584,9 +610,10 @@ __global__ __launch_bounds__(256) void k_expand(ExpandArgs a) {
         const int knm = a.knm[rl >> 6];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const int key = keys[e];
-            const int val = key >> 16, cc = (rl & 63) * C + 4 * part + e;
+            const int cc = (rl & 63) * C + 4 * part + e;
             if (cc >= (a.rev ? nread : nread + 1)) continue;               // column does not exist: the key is garbage
+            const int key = keys[e] + cc * a.gcost * 65536;                // records hold z-space keys: A = z + c * g
+            const int val = key >> 16;
             const int col = a.rev ? nread - cc : cc;
             if (col < oob || col >= nread + 1 - oob) continue;             // outside the recombination band (-B)
             if (val + wr[col] - a.brc < bound) continue;                   // implies the sweep's emission threshold
@@ -624,9 +651,9 @@ __global__ __launch_bounds__(256) void k_colmax_rec(ExpandArgs a, int* colmax_ou
         for (unsigned t = threadIdx.x / C; t < nrec; t += blockDim.x / C) {
             const int* rp = base + (long long)t * (4 + C);
             const int rl = rp[0], q = threadIdx.x % C;
-            const int key = rp[4 + q];
             const int cc = (rl & 63) * C + q;
             if (cc >= (a.rev ? nread : nread + 1)) continue;
+            const int key = rp[4 + q] + cc * a.gcost * 65536;              // z-space key -> value << 16 | path
             const int col = a.rev ? nread - cc : cc;
             if (col < oob || col >= nread + 1 - oob) continue;
             const int knm = a.knm[rl >> 6];
@@ -653,20 +680,21 @@ void launch_colmax_rec(const ExpandArgs& a, int* colmax_out, int* colarg_out, in
     }
 }
 
-template <bool kColmax>
+template <bool kColmax, bool kRec>
 static void launch_sweep16_c(const SweepArgs& a, int nreads, int C, hipStream_t s) {
     const size_t bytes = (size_t)(192 + 5 * 64) * sizeof(int);
     switch (C) {
-        case 4: hipLaunchKernelGGL((k_sweep16<4, kColmax>), dim3(nreads), dim3(64), bytes, s, a); break;
-        case 8: hipLaunchKernelGGL((k_sweep16<8, kColmax>), dim3(nreads), dim3(64), bytes, s, a); break;
-        case 16: hipLaunchKernelGGL((k_sweep16<16, kColmax>), dim3(nreads), dim3(64), bytes, s, a); break;
-        default: hipLaunchKernelGGL((k_sweep16<32, kColmax>), dim3(nreads), dim3(64), bytes, s, a); break;
+        case 4: hipLaunchKernelGGL((k_sweep16<4, kColmax, kRec>), dim3(nreads), dim3(64), bytes, s, a); break;
+        case 8: hipLaunchKernelGGL((k_sweep16<8, kColmax, kRec>), dim3(nreads), dim3(64), bytes, s, a); break;
+        case 16: hipLaunchKernelGGL((k_sweep16<16, kColmax, kRec>), dim3(nreads), dim3(64), bytes, s, a); break;
+        default: hipLaunchKernelGGL((k_sweep16<32, kColmax, kRec>), dim3(nreads), dim3(64), bytes, s, a); break;
     }
 }
 void launch_sweep16(const SweepArgs& a, int nreads, int C, hipStream_t s) {
     // a sweep that writes records and is not asked for column maxima skips their tracking
-    if (a.frec && !a.colmax_out) launch_sweep16_c<false>(a, nreads, C, s);
-    else launch_sweep16_c<true>(a, nreads, C, s);
+    if (a.frec && !a.colmax_out) launch_sweep16_c<false, true>(a, nreads, C, s);
+    else if (a.frec) launch_sweep16_c<true, true>(a, nreads, C, s);
+    else launch_sweep16_c<true, false>(a, nreads, C, s);
 }
 
 }  // namespace rg
