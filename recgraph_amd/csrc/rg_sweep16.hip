@@ -110,16 +110,23 @@ struct RowOps16 {
         umask = um; lmask = lm;
     }
 
-    static __device__ __forceinline__ void member(int (&row)[H], const int (&s)[H], int g_i, int g0, int lane,
-                                                  const int (&MU)[H], const int (&ML)[H], unsigned lmask, int src) {
+    // SEL[r]: per half what a member adds to the source the alpha chose there (g_i under the U cells, s - g under the D
+    // cells); computed once per group that has members besides its alpha
+    static __device__ __forceinline__ void select_steps(int (&SEL)[H], const int (&s)[H], const int (&MU)[H], int g_i, int g0, int lane) {
         const int GI = pack16(g_i, g_i);
         const int GI0 = lane == 0 ? pack16(g0, g_i) : GI;
+#pragma unroll
+        for (int r = 0; r < H; ++r) SEL[r] = bfi(MU[r], r == 0 ? GI0 : GI, s[r]);
+    }
+
+    static __device__ __forceinline__ void member(int (&row)[H], const int (&SEL)[H], int lane,
+                                                  const int (&MU)[H], const int (&ML)[H], unsigned lmask, int src) {
         int prev = __builtin_amdgcn_alignbit(row[H - 1], dpp_shr1(row[H - 1], NEGPAIR), 16);
         int lastv = NEGPAIR;                                        // z of the last non-L column of each half
 #pragma unroll
         for (int r = 0; r < H; ++r) {
             const int old = row[r];
-            const int base = bfi(MU[r], pk_add(old, r == 0 ? GI0 : GI), pk_add(prev, s[r]));
+            const int base = pk_add(bfi(MU[r], old, prev), SEL[r]);  // U: old + g_i, D: prev + (s - g)
             row[r] = base;
             lastv = bfi(ML[r], lastv, base);
             prev = old;
@@ -412,7 +419,7 @@ __global__ __launch_bounds__(64, 2) void k_sweep16(SweepArgs a) {
 
     int s[H];
     int bkey[C];
-    int MU[H], ML[H];
+    int MU[H], ML[H], SEL[H];
     while (t < nsteps) {
         int w0, w1;
         unsigned long long gmask;
@@ -449,10 +456,11 @@ __global__ __launch_bounds__(64, 2) void k_sweep16(SweepArgs a) {
                 unsigned umask, lmask;
                 int src;
                 RowOps16<C>::alpha(rr[0], s, g_i, g0, lane, MU, ML, umask, lmask, src);
+                if (nm > 1) RowOps16<C>::select_steps(SEL, s, MU, g_i, g0, lane);
                 if (dirs) store_dirs(rslot, umask, lmask);
 #pragma unroll
                 for (int kk = 1; kk < KRUN; ++kk)
-                    if (kk < nm) RowOps16<C>::member(rr[kk], s, g_i, g0, lane, MU, ML, lmask, src);
+                    if (kk < nm) RowOps16<C>::member(rr[kk], SEL, lane, MU, ML, lmask, src);
                 cells += (unsigned long long)nm;
                 if (track) {
                     set_keys(bkey, rr[0], mk[0]);
@@ -503,6 +511,7 @@ __global__ __launch_bounds__(64, 2) void k_sweep16(SweepArgs a) {
             unsigned umask, lmask;
             int src;
             RowOps16<C>::alpha(rowa, s, g_i, g0, lane, MU, ML, umask, lmask, src);
+            if (nm > 1) RowOps16<C>::select_steps(SEL, s, MU, g_i, g0, lane);
 #pragma unroll
             for (int r = 0; r < H; ++r) rows[(long long)ga * wrow + r * WAVE + lane] = rowa[r];
             if (track) { if (flags & F_FIRST) set_keys(bkey, rowa, ga); else fold_keys(bkey, rowa, ga); }
@@ -519,7 +528,7 @@ __global__ __launch_bounds__(64, 2) void k_sweep16(SweepArgs a) {
 #pragma unroll
                     for (int r = 0; r < H; ++r) nxt[r] = rows[(long long)knext * wrow + r * WAVE + lane];
                 } else knext = -1;
-                RowOps16<C>::member(cur, s, g_i, g0, lane, MU, ML, lmask, src);
+                RowOps16<C>::member(cur, SEL, lane, MU, ML, lmask, src);
 #pragma unroll
                 for (int r = 0; r < H; ++r) rows[(long long)k * wrow + r * WAVE + lane] = cur[r];
                 if (track) fold_keys(bkey, cur, k);
