@@ -134,6 +134,23 @@ static int upload_graph(rg_graph* gr, GraphTables** out) {
     return RG_OK;
 }
 
+// page-locked host staging buffer (H2D / D2H by DMA, no pageable bounce copy)
+template <typename T>
+struct PinBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    ~PinBuf() { if (p) (void)hipHostFree(p); }
+    int alloc(size_t count) {
+        if (count <= n && p) return RG_OK;
+        if (p) { (void)hipHostFree(p); p = nullptr; n = 0; }
+        if (count == 0) count = 1;
+        count += count / 4;           // head-room: read sets of a stream differ a little in size
+        HIPCHK(hipHostMalloc((void**)&p, count * sizeof(T), hipHostMallocDefault));
+        n = count;
+        return RG_OK;
+    }
+};
+
 struct KernelStat {
     std::string name;
     double ms = 0;
@@ -145,17 +162,20 @@ struct rg_batch {
     GraphTables* gt = nullptr;         // the graph's tables on this batch's device
     rg_params p;
     int64_t nreads = 0;
-    std::string reads;                 // upper-cased bases, '-' -> 'N'
+    const uint8_t* codes = nullptr;    // base codes 0..4 per base (inside `stage`); the canonical text of a read (upper
+                                       // case, '-' -> 'N': sequences.rs:13-22) is "ACGTN"[code]
     std::vector<long long> off;
-    std::vector<uint8_t> codes, bad;
+    std::vector<uint8_t> bad;
     std::vector<int> bta;
     int max_n = 0;
     hipStream_t stream = nullptr;
     int dev = 0;                       // device the handle was created on (graph tables are bound to it too)
     // device inputs
-    DevBuf<uint8_t> d_reads, d_bad;
-    DevBuf<long long> d_off;
-    DevBuf<int> d_bta, d_col0;
+    // one device block [off | bta | codes | bad] filled by ONE DMA from the pinned block `stage` (same layout)
+    DevBuf<uint8_t> d_in;
+    PinBuf<uint8_t> stage;
+    struct InView { const uint8_t* reads; const long long* off; const uint8_t* bad; const int* bta; } in{};
+    DevBuf<int> d_col0;
     // work + outputs
     DevBuf<int> d_arena_m;
     DevBuf<uint32_t> d_arena_pw;
@@ -263,7 +283,7 @@ int run_local(rg_batch* b) {
     PoaArgs a;
     a.g = DevLnz{h.L, g->d_lnz.p, g->d_pred_off.p, g->d_pred_rows.p, g->d_r_values.p, g->d_min_pred.p};
     for (int i = 0; i < 36; ++i) a.sc.t[i] = b->p.scores[i];
-    a.reads = b->d_reads.p; a.read_off = b->d_off.p; a.bad = b->d_bad.p; a.bta = b->d_bta.p; a.col0 = b->d_col0.p;
+    a.reads = b->in.reads; a.read_off = b->in.off; a.bad = b->in.bad; a.bta = b->in.bta; a.col0 = b->d_col0.p;
     a.gap_open = b->p.gap_open; a.gap_ext = b->p.gap_ext; a.max_n = b->max_n; a.lds_read = b->max_n <= 16000 ? 1 : 0;
     a.cap_cells = b->cap_cells; a.arena_m = b->d_arena_m.p; a.arena_pw = b->d_arena_pw.p; a.rinfo = b->d_rinfo.p;
     a.rec = b->d_rec.p; a.ops = b->d_ops.p; a.oprows = b->d_oprows.p; a.ops_stride = b->ops_stride;
@@ -298,7 +318,7 @@ int run_poa(rg_batch* b) {
         PoaArgs a;
         a.g = DevLnz{h.L, g->d_lnz.p, g->d_pred_off.p, g->d_pred_rows.p, g->d_r_values.p, g->d_min_pred.p};
         for (int i = 0; i < 36; ++i) a.sc.t[i] = b->p.scores[i];
-        a.reads = b->d_reads.p; a.read_off = b->d_off.p; a.bad = b->d_bad.p; a.bta = b->d_bta.p; a.col0 = b->d_col0.p;
+        a.reads = b->in.reads; a.read_off = b->in.off; a.bad = b->in.bad; a.bta = b->in.bta; a.col0 = b->d_col0.p;
         a.nreads = (int)b->nreads; a.read_base = 0; a.max_n = b->max_n; a.lds_read = b->max_n <= 16000 ? 1 : 0; a.gap_open = b->p.gap_open; a.gap_ext = b->p.gap_ext;
         a.cap_cells = b->cap_cells; a.arena_m = b->d_arena_m.p; a.arena_pw = b->d_arena_pw.p; a.rinfo = b->d_rinfo.p;
         a.rec = b->d_rec.p; a.ops = b->d_ops.p; a.oprows = b->d_oprows.p; a.ops_stride = b->ops_stride;
@@ -443,34 +463,46 @@ static int load_reads(rg_batch* b, const char* reads, const int64_t* read_off, i
         }
     } canon;
     const size_t total = (size_t)(read_off[nreads] - base);
-    b->reads.resize(total);
-    b->codes.resize(total);
+    // staging layout (8-byte aligned pieces): offsets (int64), bta (int32), codes (u8), bad (u8)
+    const size_t o_off = 0, o_bta = o_off + sizeof(long long) * (size_t)(nreads + 1);
+    const size_t o_codes = (o_bta + sizeof(int) * (size_t)nreads + 7) & ~(size_t)7;
+    const size_t o_bad = (o_codes + total + 7) & ~(size_t)7;
+    const size_t in_bytes = o_bad + (size_t)nreads;
+    int rc;
+    if ((rc = b->stage.alloc(in_bytes))) return rc;
     b->bad.assign(nreads, 0);
     b->bta.resize(nreads);
     b->max_n = 0;
     const unsigned char* src = reinterpret_cast<const unsigned char*>(reads) + base;
+    uint8_t* codes = b->stage.p + o_codes;
+    b->codes = codes;
+    for (size_t k = 0; k < total; ++k) codes[k] = canon.code[src[k]];       // one table pass over the whole blob
     for (int64_t r = 0; r < nreads; ++r) {
         const long long n = b->off[r + 1] - b->off[r];
         if (n < 1) return fail(RG_ERR_ARG, "empty read");
         b->max_n = std::max<int>(b->max_n, (int)n);
-        unsigned any_bad = 0;
-        for (long long k = b->off[r]; k < b->off[r + 1]; ++k) {
-            const unsigned char c = src[k];
-            const uint8_t code = canon.code[c];
-            b->reads[k] = canon.ch[c];
-            any_bad |= code == 0xff;
-            b->codes[k] = code == 0xff ? 4 : code;
+        // a character outside ACGTN (after canonicalisation): the reference panics on the score lookup
+        if (memchr(codes + b->off[r], 0xff, (size_t)n)) {
+            b->bad[r] = 1;
+            for (long long k = b->off[r]; k < b->off[r + 1]; ++k) if (codes[k] == 0xff) codes[k] = 4;
         }
-        b->bad[r] = any_bad ? 1 : 0;
         // main.rs:57: (b + f * seq.len() as f32) as usize, seq.len() = n + 1
         float v = p->band_b + p->band_f * (float)(n + 1);
         long long bt = p->bta_override >= 0 ? p->bta_override : (v > 0 ? (long long)v : 0);
         b->bta[r] = (int)std::min<long long>(bt, 1 << 28);
     }
-    int rc;
-    if ((rc = b->d_reads.upload(b->codes)) || (rc = b->d_off.upload(b->off)) || (rc = b->d_bad.upload(b->bad)) ||
-        (rc = b->d_bta.upload(b->bta)))
-        return rc;
+    memcpy(b->stage.p + o_off, b->off.data(), sizeof(long long) * (size_t)(nreads + 1));
+    memcpy(b->stage.p + o_bta, b->bta.data(), sizeof(int) * (size_t)nreads);
+    memcpy(b->stage.p + o_bad, b->bad.data(), (size_t)nreads);
+    if ((rc = b->d_in.alloc(in_bytes + in_bytes / 4))) return rc;
+    // ONE DMA from the pinned block on the batch's stream (no blit kernel that would queue behind a running sweep of
+    // another handle), ordered before the kernels of the next run
+    HIPCHK(hipMemcpyAsync(b->d_in.p, b->stage.p, in_bytes, hipMemcpyHostToDevice, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    b->in.off = reinterpret_cast<const long long*>(b->d_in.p + o_off);
+    b->in.bta = reinterpret_cast<const int*>(b->d_in.p + o_bta);
+    b->in.reads = b->d_in.p + o_codes;
+    b->in.bad = b->d_in.p + o_bad;
     if ((rc = b->d_rec.alloc(nreads)) || (rc = b->d_cells.alloc(1))) return rc;
     const HostGraph& h = g->h;
     // traceback ops per read: POA walks at most L rows + n columns; a pathwise walk stays on the rows of one path per
@@ -588,7 +620,8 @@ static bool build_fields(const rg_batch* b, int64_t i, const char* name, GafFiel
     r.rsn = d.rsn; r.rec_col = d.rec_col; r.displacement = d.displacement; r.n_ops = d.n_ops; r.n_fwd_ops = d.n_fwd_ops;
     r.ops = b->ops.data() + (size_t)i * b->ops_stride;
     r.rows = is_poa(b->p.mode) ? b->oprows.data() + (size_t)i * b->ops_stride : nullptr;
-    std::string read = b->reads.substr((size_t)b->off[i], (size_t)(b->off[i + 1] - b->off[i]));
+    std::string read((size_t)(b->off[i + 1] - b->off[i]), 'N');
+    for (size_t k = 0; k < read.size(); ++k) read[k] = "ACGTN"[b->codes[(size_t)b->off[i] + k]];
     std::string nm = name ? name : "";
     switch (b->p.mode) {
         case RG_MODE_GLOBAL_POA: out = fields_m0_simd(b->g->h, read, nm, r, b->p.amb_mode); break;
@@ -753,7 +786,7 @@ int rg_run_pathwise(rg_batch* b) {
     gd.eoff = g->d_eoff.p; gd.epred = g->d_epred.p; gd.emask = g->d_emask.p; gd.roff = g->d_roff.p; gd.rsucc = g->d_rsucc.p;
     gd.rmask = g->d_rmask.p; gd.pnwp = g->d_pnwp.p; gd.rnwp = g->d_rnwp.p;
     std::vector<std::pair<std::string, std::pair<double, long long>>> st;
-    int rc = path_driver_run(h, gd, b->p, b->pw, b->d_reads.p, b->d_off.p, b->d_bad.p, (int)b->nreads, b->max_n, b->d_rec.p,
+    int rc = path_driver_run(h, gd, b->p, b->pw, b->in.reads, b->in.off, b->in.bad, (int)b->nreads, b->max_n, b->d_rec.p,
                              b->d_ops.p, b->ops_stride, b->d_cells.p, b->stream, st);
     b->stats.clear();
     for (auto& s : st) b->stats.push_back(KernelStat{s.first, s.second.first, s.second.second});
