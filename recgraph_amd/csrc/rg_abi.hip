@@ -306,26 +306,41 @@ int run_poa(rg_batch* b) {
     if (!h.has_lnz) return fail(RG_ERR_ARG, "graph has no LnzGraph view");
     const int mode = b->p.mode;
     if (is_local(mode)) return run_local(b);
-    const int planes = mode == RG_MODE_GAP_POA ? 3 : 1;   // m2: m | y | (spare) score planes, w0 | w1 path planes
+    const int planes = mode == RG_MODE_GAP_POA ? 2 : 1;   // m2: m | y score planes, w0 | w1 path planes
     Timed T(b);
     for (auto& s : b->stats) { s.ms = 0; s.launches = 0; }
-    for (int attempt = 0; attempt < 8; ++attempt) {
+    for (int attempt = 0; attempt < 12; ++attempt) {
         int rc;
-        if ((rc = b->d_arena_m.alloc((size_t)b->nreads * b->cap_cells * planes)) ||
-            (rc = b->d_arena_pw.alloc((size_t)b->nreads * b->cap_cells * planes)))
+        // Reads per launch: the band arenas of one launch take at most 45 % of the HBM that is free (plus what this
+        // handle already holds), so that a second handle of a streaming caller fits beside this one.
+        const size_t per_read = (size_t)b->cap_cells * planes * (sizeof(int) + sizeof(uint32_t)) + (size_t)h.L * sizeof(int4);
+        size_t free_b = 0, total_b = 0;
+        HIPCHK(hipMemGetInfo(&free_b, &total_b));
+        free_b += b->d_arena_m.bytes() + b->d_arena_pw.bytes() + b->d_rinfo.bytes();
+        const size_t budget = free_b / 100 * 45;
+        if (per_read > budget) return fail(RG_ERR_CAPACITY, "band arena of one read exceeds the free HBM");
+        const long long maxchunk = (long long)std::min<size_t>((size_t)b->nreads, budget / per_read);
+        const long long nchunks = (b->nreads + maxchunk - 1) / maxchunk;
+        const long long chunk = (b->nreads + nchunks - 1) / nchunks;      // even launches
+        if ((rc = b->d_arena_m.alloc((size_t)chunk * b->cap_cells * planes)) ||
+            (rc = b->d_arena_pw.alloc((size_t)chunk * b->cap_cells * planes)) || (rc = b->d_rinfo.alloc((size_t)chunk * h.L)))
             return rc;
         HIPCHK(hipMemsetAsync(b->d_cells.p, 0, sizeof(unsigned long long), b->stream));
         PoaArgs a;
         a.g = DevLnz{h.L, g->d_lnz.p, g->d_pred_off.p, g->d_pred_rows.p, g->d_r_values.p, g->d_min_pred.p};
         for (int i = 0; i < 36; ++i) a.sc.t[i] = b->p.scores[i];
         a.reads = b->in.reads; a.read_off = b->in.off; a.bad = b->in.bad; a.bta = b->in.bta; a.col0 = b->d_col0.p;
-        a.nreads = (int)b->nreads; a.read_base = 0; a.max_n = b->max_n; a.lds_read = b->max_n <= 16000 ? 1 : 0; a.gap_open = b->p.gap_open; a.gap_ext = b->p.gap_ext;
+        a.max_n = b->max_n; a.lds_read = b->max_n <= 16000 ? 1 : 0; a.gap_open = b->p.gap_open; a.gap_ext = b->p.gap_ext;
         a.cap_cells = b->cap_cells; a.arena_m = b->d_arena_m.p; a.arena_pw = b->d_arena_pw.p; a.rinfo = b->d_rinfo.p;
         a.rec = b->d_rec.p; a.ops = b->d_ops.p; a.oprows = b->d_oprows.p; a.ops_stride = b->ops_stride;
         a.cells = b->d_cells.p;
-        if (mode == RG_MODE_GLOBAL_POA) { if ((rc = T.run("k_m0_simd", [&] { launch_m0_simd(a, b->stream); }))) return rc; }
-        else if (mode == RG_MODE_GAP_POA) { if ((rc = T.run("k_m2_gap", [&] { launch_m2(a, b->stream); }))) return rc; }
-        else { if ((rc = T.run("k_m0_scalar", [&] { launch_m0_scalar(a, b->stream); }))) return rc; }
+        for (long long base = 0; base < b->nreads; base += chunk) {
+            a.read_base = (int)base;
+            a.nreads = (int)std::min<long long>(chunk, b->nreads - base);
+            if (mode == RG_MODE_GLOBAL_POA) { if ((rc = T.run("k_m0_simd", [&] { launch_m0_simd(a, b->stream); }))) return rc; }
+            else if (mode == RG_MODE_GAP_POA) { if ((rc = T.run("k_m2_gap", [&] { launch_m2(a, b->stream); }))) return rc; }
+            else { if ((rc = T.run("k_m0_scalar", [&] { launch_m0_scalar(a, b->stream); }))) return rc; }
+        }
         if ((rc = T.collect())) return rc;
         // overflow check: a read whose band cells did not fit asks for a bigger arena
         b->rec.resize(b->nreads);
@@ -340,7 +355,8 @@ int run_poa(rg_batch* b) {
         }
         const long long full = (long long)h.L * (b->max_n + 1);
         if (b->cap_cells >= full) return fail(RG_ERR_CAPACITY, "band arena overflow at full size");
-        b->cap_cells = std::min(full, b->cap_cells * 4);
+        b->cap_cells = std::min(full, b->cap_cells * 2);
+        for (auto& s : b->stats) { s.ms = 0; s.launches = 0; }
     }
     return fail(RG_ERR_CAPACITY, "band arena overflow");
 }
@@ -511,7 +527,7 @@ static int load_reads(rg_batch* b, const char* reads, const int64_t* read_off, i
                                  : std::min<long long>((long long)h.L + b->max_n + 8, 2ll * (h.max_path_rows + b->max_n) + 16);
     if ((rc = b->d_ops.alloc((size_t)nreads * b->ops_stride))) return rc;
     if (is_poa(mode)) {
-        if ((rc = b->d_oprows.alloc((size_t)nreads * b->ops_stride)) || (rc = b->d_rinfo.alloc((size_t)nreads * h.L))) return rc;
+        if ((rc = b->d_oprows.alloc((size_t)nreads * b->ops_stride))) return rc;
         long long maxbta = 0;
         for (int v : b->bta) maxbta = std::max<long long>(maxbta, v);
         const long long per_row = std::min<long long>(b->max_n + 1, 2 * maxbta + 40);

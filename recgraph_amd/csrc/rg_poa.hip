@@ -64,7 +64,8 @@ __device__ __forceinline__ int m_at(const M0Ctx& x, int p, int c) {
 
 template <bool kLdsRead>
 __global__ __launch_bounds__(64) void k_m0_simd(PoaArgs a) {
-    const int rd = blockIdx.x;
+    const int slot = blockIdx.x;              // arena slot of this launch
+    const int rd = a.read_base + slot;        // read of the batch
     const int lane = threadIdx.x;
     const DevLnz& g = a.g;
     const int L = g.L;
@@ -88,9 +89,9 @@ __global__ __launch_bounds__(64) void k_m0_simd(PoaArgs a) {
         if (lane == 0) { rec->status = ST_BAD_BASE; rec->n_ops = 0; rec->score = 0; }
         return;
     }
-    int* am = a.arena_m + (long long)rd * a.cap_cells;
-    uint32_t* apw = a.arena_pw + (long long)rd * a.cap_cells;
-    int4* rinfo = a.rinfo + (long long)rd * L;
+    int* am = a.arena_m + (long long)slot * a.cap_cells;
+    uint32_t* apw = a.arena_pw + (long long)slot * a.cap_cells;
+    int4* rinfo = a.rinfo + (long long)slot * L;
     const unsigned long long bta = (unsigned long long)a.bta[rd];
     const int GAP = 5;
     M0Ctx cx{am, rinfo, a.col0, 2 * W * sct[read_at(1) * 6 + GAP]};  // global_abpoa.rs:20

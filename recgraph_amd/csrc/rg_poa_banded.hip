@@ -48,7 +48,8 @@ enum : uint32_t { PD_O = 0, PD_D = 1, PD_d = 2, PD_L = 3, PD_U = 4 };
 // Arena planes per read (cap_cells each): m | y (m2) ; path words: w0 = pred<<3 | dir | X<<31, w1 = predY<<1 | Y.
 template <bool kGap, bool kLdsRead>
 __global__ __launch_bounds__(64) void k_poa_banded(PoaArgs a) {
-    const int rd = blockIdx.x;
+    const int slot = blockIdx.x;              // arena slot of this launch
+    const int rd = a.read_base + slot;        // read of the batch
     const int lane = threadIdx.x;
     const DevLnz& g = a.g;
     const int L = g.L;
@@ -71,13 +72,12 @@ __global__ __launch_bounds__(64) void k_poa_banded(PoaArgs a) {
         if (lane == 0) { rec->status = ST_BAD_BASE; rec->n_ops = 0; rec->score = 0; }
         return;
     }
-    const int planes = kGap ? 2 : 1;
-    int* am = a.arena_m + (long long)rd * a.cap_cells * (kGap ? 3 : 1);
+    constexpr int planes = kGap ? 2 : 1;
+    int* am = a.arena_m + (long long)slot * a.cap_cells * planes;
     int* ay = am + a.cap_cells;
-    uint32_t* pw0 = a.arena_pw + (long long)rd * a.cap_cells * (kGap ? 3 : 1);
+    uint32_t* pw0 = a.arena_pw + (long long)slot * a.cap_cells * planes;
     uint32_t* pw1 = pw0 + a.cap_cells;
-    (void)planes;
-    int4* rinfo = a.rinfo + (long long)rd * L;
+    int4* rinfo = a.rinfo + (long long)slot * L;
     const unsigned long long bta = (unsigned long long)a.bta[rd];
     const int GAP = 5;
     const int o = a.gap_open, e = a.gap_ext;
