@@ -25,7 +25,7 @@ typedef enum rg_status {
     RG_ERR_ARG = -1,         /* bad argument (null pointer, unsupported mode, empty read ...) */
     RG_ERR_GFA = -2,         /* GFA text not usable (non-numeric names, '-' orientations ...)  */
     RG_ERR_NO_DEVICE = -3,   /* no HIP device / HIP runtime error: the product never falls back to CPU */
-    RG_ERR_GRAPH = -4,       /* graph violates a precondition of the reference (not topological, >64 paths ...) */
+    RG_ERR_GRAPH = -4,       /* graph violates a precondition of the reference (not topological, >256 paths ...) */
     RG_ERR_CAPACITY = -5,    /* internal work buffer exhausted even after regrowth */
     RG_ERR_HIP = -6
 } rg_status;
@@ -92,18 +92,19 @@ int32_t rg_graph_from_gfa(const char* gfa_text, int64_t len, rg_graph** out);
  * node_id[i] = segment id of row i (0 for row 0 and the final 'F' row). */
 int32_t rg_graph_create_lnz(const char* lnz, int64_t L, const int64_t* pred_off, const int64_t* pred_rows,
                             const uint64_t* node_id, rg_graph** out);
-/* Same, from an already flattened PathGraph (pathwise_graph.rs:10-18): row_mask[i] bit k = paths_nodes[i][k];
- * edges of row i are (edge_pred[e], edge_mask[e]) for e in [edge_off[i], edge_off[i+1]) (PredHash,
- * pathwise_graph.rs:75-125; listed for segment-start rows and the 'F' row). */
+/* Same, from an already flattened PathGraph (pathwise_graph.rs:10-18).  Path sets are W = (P + 63) / 64 words each: bit
+ * (k & 63) of word (k >> 6) of row_mask[i * W ..] = paths_nodes[i][k]; edges of row i are (edge_pred[e],
+ * edge_mask[e * W ..]) for e in [edge_off[i], edge_off[i+1]) (PredHash, pathwise_graph.rs:75-125; listed for
+ * segment-start rows and the 'F' row).  P <= 256. */
 int32_t rg_graph_create_path(const char* lnz, int64_t L, int32_t P, const uint64_t* row_mask,
                              const int64_t* edge_off, const int64_t* edge_pred, const uint64_t* edge_mask,
                              const uint64_t* node_id, rg_graph** out);
 void rg_graph_destroy(rg_graph* g);
-/* A GFA whose P lines cannot be turned into a PathGraph (more than 64 paths, '-' path steps, a step on an unknown
+/* A GFA whose P lines cannot be turned into a PathGraph (more than 256 paths, '-' path steps, a step on an unknown
  * segment, steps against the id order, a segment on no path: pathwise_graph.rs:182) still yields the LnzGraph view, which
  * is all modes 0-3 need (main.rs:29); the reason is returned here ("" when the PathGraph view exists or the GFA has no
  * P lines) and by rg_batch_create (RG_ERR_GRAPH) when a pathwise mode is requested on such a graph.
- * Limits of the pathwise kernels: at most 64 paths; reads of at most 2047 bases. */
+ * Limits of the pathwise kernels: at most 256 paths; reads of at most 2047 bases. */
 const char* rg_graph_path_error(const rg_graph* g);
 int64_t rg_graph_rows(const rg_graph* g);   /* lnz.len() of the LnzGraph (or PathGraph if only that exists) */
 int32_t rg_graph_paths(const rg_graph* g);  /* paths_number, 0 without P lines */

@@ -120,13 +120,19 @@ static int upload_graph(rg_graph* gr, GraphTables** out) {
             segfirst[i] = i >= 1 && h.node_id[i] != h.node_id[i - 1];
             seglast[i] = (i + 1 == h.L) || h.node_id[i] != h.node_id[i + 1];
         }
-        if ((rc = g->d_row_mask.upload(h.row_mask)) || (rc = g->d_knm.upload(h.knm)) || (rc = g->d_dfs.upload(h.dfs)) ||
+        // path masks as RG_PW words per row / edge
+        auto flat = [](const std::vector<PMask>& v) {
+            std::vector<uint64_t> o(v.size() * RG_PW);
+            for (size_t i = 0; i < v.size(); ++i) for (int w = 0; w < RG_PW; ++w) o[i * RG_PW + w] = v[i].w[w];
+            return o;
+        };
+        if ((rc = g->d_row_mask.upload(flat(h.row_mask))) || (rc = g->d_knm.upload(h.knm)) || (rc = g->d_dfs.upload(h.dfs)) ||
             (rc = g->d_dfe.upload(h.dfe)) || (rc = g->d_fgoff.upload(h.fgoff)) || (rc = g->d_rgoff.upload(h.rgoff)) ||
             (rc = g->d_fgroups.upload(h.fgroups)) || (rc = g->d_rgroups.upload(h.rgroups)) ||
             (rc = g->d_node_id.upload(ids)) || (rc = g->d_segfirst.upload(segfirst)) ||
             (rc = g->d_seglast.upload(seglast)) || (rc = g->d_eoff.upload(h.eoff)) || (rc = g->d_epred.upload(h.epred)) ||
-            (rc = g->d_emask.upload(h.emask)) || (rc = g->d_roff.upload(h.roff)) || (rc = g->d_rsucc.upload(h.rsucc)) ||
-            (rc = g->d_rmask.upload(h.rmask)) || (rc = g->d_pnwp.upload(h.pnwp)) || (rc = g->d_rnwp.upload(h.rnwp)))
+            (rc = g->d_emask.upload(flat(h.emask))) || (rc = g->d_roff.upload(h.roff)) || (rc = g->d_rsucc.upload(h.rsucc)) ||
+            (rc = g->d_rmask.upload(flat(h.rmask))) || (rc = g->d_pnwp.upload(h.pnwp)) || (rc = g->d_rnwp.upload(h.rnwp)))
             return rc;
     }
     *out = g.get();

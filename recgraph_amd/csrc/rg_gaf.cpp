@@ -91,12 +91,12 @@ int step_on_path(const HostGraph& g, int row, int path, bool fwd) {
     if (fwd) {
         if (!g.pnwp[row]) return row - 1;
         int p = -1;
-        for (int e = g.eoff[row]; e < g.eoff[row + 1]; ++e) if ((g.emask[e] >> path) & 1) p = g.epred[e];
+        for (int e = g.eoff[row]; e < g.eoff[row + 1]; ++e) if (g.emask[e].test(path)) p = g.epred[e];
         return p < 0 ? row - 1 : p;
     }
     if (!g.rnwp[row]) return row + 1;
     int p = -1;
-    for (int e = g.roff[row]; e < g.roff[row + 1]; ++e) if ((g.rmask[e] >> path) & 1) p = g.rsucc[e];
+    for (int e = g.roff[row]; e < g.roff[row + 1]; ++e) if (g.rmask[e].test(path)) p = g.rsucc[e];
     return p < 0 ? row + 1 : p;
 }
 

@@ -94,17 +94,17 @@ int finish_path_view(HostGraph& g) {
     // alphas: lowest path id through the row (pathwise_graph.rs:200-205); rows 0 and L-1 -> 0
     g.alphas.assign(L, P + 1);
     for (int32_t i = 0; i < L; ++i)
-        if (g.row_mask[i]) g.alphas[i] = __builtin_ctzll(g.row_mask[i]);
+        if (g.row_mask[i].any()) g.alphas[i] = g.row_mask[i].lowest();
     g.alphas[0] = 0;
     g.alphas[L - 1] = 0;
     for (int32_t i = 1; i + 1 < L; ++i)
-        if (g.row_mask[i] == 0)
+        if (!g.row_mask[i].any())
             return fail(RG_ERR_GRAPH, "segment of row " + std::to_string(i) +
                                           " is on no path (the reference indexes out of bounds: pathwise_graph.rs:182)");
     g.pnwp.assign(L, 0);
     for (int32_t i = 0; i < L; ++i) g.pnwp[i] = g.eoff[i + 1] > g.eoff[i];
     // reverse PredHash: for every forward edge (node <- pred, mask): rev[pred] gets (node, mask)
-    std::vector<std::map<int32_t, uint64_t>> rev(L);
+    std::vector<std::map<int32_t, PMask>> rev(L);
     for (int32_t i = 0; i < L; ++i)
         for (int32_t e = g.eoff[i]; e < g.eoff[i + 1]; ++e) rev[g.epred[e]][i] |= g.emask[e];
     g.roff.assign(L + 1, 0);
@@ -147,11 +147,8 @@ int finish_path_view(HostGraph& g) {
         g.dfs.assign(r.begin(), r.end());
     }
     g.knm.assign(L, -1);
-    const uint64_t all = P == 64 ? ~0ull : ((1ull << P) - 1);
-    for (int32_t i = 0; i < L; ++i) {
-        uint64_t non = all & ~g.row_mask[i];
-        g.knm[i] = non ? 63 - __builtin_clzll(non) : -1;
-    }
+    const PMask all = PMask::first(P);
+    for (int32_t i = 0; i < L; ++i) g.knm[i] = all.andnot(g.row_mask[i]).highest();
     // DP programs: group alpha = alphas[pred] if member, else alphas[row] if member,
     // else lowest member
     auto build = [&](bool fwd, std::vector<int32_t>& goff, std::vector<GroupDesc>& groups, int32_t& nslots) {
@@ -160,19 +157,26 @@ int finish_path_view(HostGraph& g) {
         nslots = 0;
         for (int32_t i = 0; i < L; ++i) {
             if (i >= 1 && i + 1 < L) {
-                auto add = [&](int32_t p, uint64_t m) {
-                    m &= g.row_mask[i];
-                    if (!m) return;
+                auto add = [&](int32_t p, PMask m) {
+                    m = m & g.row_mask[i];
+                    if (!m.any()) return;
+                    const int ap = g.alphas[p], ai = g.alphas[i];
+                    const int ga = m.test(ap) ? ap : (m.test(ai) ? ai : m.lowest());
                     GroupDesc d;
                     d.pred = p;
-                    d.mask = m;
-                    uint32_t ap = (uint32_t)g.alphas[p], ai = (uint32_t)g.alphas[i];
-                    if (ap < 64 && ((m >> ap) & 1)) d.ga = ap;
-                    else if (ai < 64 && ((m >> ai) & 1)) d.ga = ai;
-                    else d.ga = (uint32_t)__builtin_ctzll(m);
                     d.slot = nslots++;
-                    d.pad = 0;
-                    groups.push_back(d);
+                    d.page = ga >> 6;
+                    d.ga = (uint32_t)(ga & 63);
+                    d.mask = m.w[d.page];
+                    groups.push_back(d);                       // the alpha's page runs the alpha
+                    for (int pg = 0; pg < RG_PW; ++pg)         // members of the other pages follow its directions
+                        if (pg != (ga >> 6) && m.w[pg]) {
+                            GroupDesc c = d;
+                            c.page = pg;
+                            c.ga = GroupDesc::GA_CONT;
+                            c.mask = m.w[pg];
+                            groups.push_back(c);
+                        }
                 };
                 if (fwd) {
                     if (g.pnwp[i]) for (int32_t e = g.eoff[i]; e < g.eoff[i + 1]; ++e) add(g.epred[e], g.emask[e]);
@@ -189,7 +193,7 @@ int finish_path_view(HostGraph& g) {
     build(false, g.rgoff, g.rgroups, g.rslots);
     std::vector<int32_t> cnt(P, 0);
     for (int32_t i = 1; i + 1 < L; ++i)
-        for (int32_t k = 0; k < P; ++k) cnt[k] += (g.row_mask[i] >> k) & 1;
+        for (int32_t k = 0; k < P; ++k) cnt[k] += g.row_mask[i].test(k) ? 1 : 0;
     g.max_path_rows = 0;
     for (int32_t k = 0; k < P; ++k) g.max_path_rows = std::max(g.max_path_rows, cnt[k]);
     g.has_path = true;
@@ -305,26 +309,26 @@ int build_from_gfa(const char* text, int64_t len, HostGraph& g) {
             return RG_OK;       // LnzGraph view stays usable (modes 0-3); rg_batch_create reports `why` for modes 4+
         };
         if (!path_error.empty()) return no_path_view(path_error);
-        if (paths.size() > 64) return no_path_view("more than 64 paths are not supported by the pathwise kernels");
+        if (paths.size() > (size_t)RG_MAXP) return no_path_view("more than 256 paths are not supported by the pathwise kernels");
         g.P = (int32_t)paths.size();
-        g.row_mask.assign(L, 0);
-        const uint64_t all = g.P == 64 ? ~0ull : ((1ull << g.P) - 1);
+        g.row_mask.assign(L, PMask());
+        const PMask all = PMask::first(g.P);
         g.row_mask[0] = all;
         g.row_mask[L - 1] = all;
-        std::vector<std::map<int32_t, uint64_t>> ed(L);
+        std::vector<std::map<int32_t, PMask>> ed(L);
         for (size_t k = 0; k < paths.size(); ++k) {
             const auto& st = paths[k];
             for (size_t s = 0; s < st.size(); ++s) {
                 auto it = idx.find(st[s]);
                 if (it == idx.end()) return no_path_view("path step on unknown segment");
                 const Segment& sg = segs[it->second];
-                for (int32_t r = sg.first; r <= sg.last; ++r) g.row_mask[r] |= 1ull << k;
-                if (s == 0) ed[sg.first][0] |= 1ull << k;
+                for (int32_t r = sg.first; r <= sg.last; ++r) g.row_mask[r].set((int)k);
+                if (s == 0) ed[sg.first][0].set((int)k);
                 else {
                     const Segment& pv = segs[idx[st[s - 1]]];
                     if (pv.last >= sg.first) return no_path_view("path steps must follow the topological id order");
-                    ed[sg.first][pv.last] |= 1ull << k;
-                    if (s + 1 == st.size()) ed[L - 1][sg.last] |= 1ull << k;   // pathwise_graph.rs:225-232
+                    ed[sg.first][pv.last].set((int)k);
+                    if (s + 1 == st.size()) ed[L - 1][sg.last].set((int)k);   // pathwise_graph.rs:225-232
                 }
             }
         }
@@ -393,18 +397,21 @@ int build_from_lnz(const char* lnz, int64_t L, const int64_t* pred_off, const in
 int build_from_path(const char* lnz, int64_t L, int32_t P, const uint64_t* row_mask, const int64_t* edge_off,
                     const int64_t* edge_pred, const uint64_t* edge_mask, const uint64_t* node_id, HostGraph& g) {
     if (!row_mask || !edge_off || !edge_pred || !edge_mask || !node_id) return fail(RG_ERR_ARG, "null path arrays");
-    if (P < 1 || P > 64) return fail(RG_ERR_GRAPH, "paths_number must be in 1..64");
+    if (P < 1 || P > RG_MAXP) return fail(RG_ERR_GRAPH, "paths_number must be in 1..256");
     int rc = fill_rows_from(lnz, L, node_id, g);
     if (rc) return rc;
     g.P = P;
-    g.row_mask.assign(row_mask, row_mask + L);
+    const int nw = (P + 63) / 64;                 // mask words per row / edge in the caller's arrays
+    auto load = [&](const uint64_t* src) { PMask m; for (int w = 0; w < nw; ++w) m.w[w] = src[w]; return m & PMask::first(P); };
+    g.row_mask.resize(L);
+    for (int64_t i = 0; i < L; ++i) g.row_mask[i] = load(row_mask + i * nw);
     g.eoff.resize(L + 1);
-    std::vector<std::map<int32_t, uint64_t>> ed(L);
+    std::vector<std::map<int32_t, PMask>> ed(L);
     for (int64_t i = 0; i < L; ++i)
         for (int64_t e = edge_off[i]; e < edge_off[i + 1]; ++e) {
             if (edge_pred[e] < 0 || edge_pred[e] >= L || (i < L - 1 && edge_pred[e] >= i))
                 return fail(RG_ERR_GRAPH, "edge predecessor must be an earlier row");
-            ed[i][(int32_t)edge_pred[e]] |= edge_mask[e];
+            ed[i][(int32_t)edge_pred[e]] |= load(edge_mask + e * nw);
         }
     g.epred.clear();
     g.emask.clear();
@@ -419,9 +426,9 @@ int build_from_path(const char* lnz, int64_t L, int32_t P, const uint64_t* row_m
 // text dumps in the same format as the test oracle's orc_graph_dump
 std::string dump_graph(const HostGraph& g, int which) {
     std::string s;
-    auto bits = [&](uint64_t m) { std::string o; for (int k = 0; k < g.P; ++k) o += ((m >> k) & 1) ? '1' : '0'; return o; };
+    auto bits = [&](const PMask& m) { std::string o; for (int k = 0; k < g.P; ++k) o += m.test(k) ? '1' : '0'; return o; };
     auto csv = [&](const std::vector<int32_t>& v) { std::string o; for (size_t i = 0; i < v.size(); ++i) { if (i) o += ","; o += std::to_string(v[i]); } return o; };
-    auto ph = [&](const std::vector<int32_t>& off, const std::vector<int32_t>& pr, const std::vector<uint64_t>& mk) {
+    auto ph = [&](const std::vector<int32_t>& off, const std::vector<int32_t>& pr, const std::vector<PMask>& mk) {
         std::string o;
         for (int32_t i = 0; i < g.L; ++i) {
             if (off[i + 1] == off[i]) continue;

@@ -15,14 +15,36 @@ namespace rg {
 extern thread_local std::string g_last_error;
 int fail(int code, const std::string& msg);
 
-// one edge group of a DP row in the pathwise modes: all paths entering `row` through the same
-// predecessor row share the direction chosen by the group's alpha path
+// Path sets: the reference uses BitVec(paths_number) (pathwise_graph.rs:10-18); here a fixed 256-bit mask (4 words),
+// of which the kernels see one 64-path PAGE at a time.
+constexpr int RG_MAXP = 256;
+constexpr int RG_PW = RG_MAXP / 64;
+struct PMask {
+    uint64_t w[RG_PW] = {0, 0, 0, 0};
+    bool any() const { return (w[0] | w[1] | w[2] | w[3]) != 0; }
+    bool test(int k) const { return k >= 0 && k < RG_MAXP && ((w[k >> 6] >> (k & 63)) & 1); }
+    void set(int k) { w[k >> 6] |= 1ull << (k & 63); }
+    int lowest() const { for (int i = 0; i < RG_PW; ++i) if (w[i]) return i * 64 + __builtin_ctzll(w[i]); return -1; }
+    int highest() const { for (int i = RG_PW - 1; i >= 0; --i) if (w[i]) return i * 64 + 63 - __builtin_clzll(w[i]); return -1; }
+    int count() const { int c = 0; for (int i = 0; i < RG_PW; ++i) c += __builtin_popcountll(w[i]); return c; }
+    PMask operator&(const PMask& o) const { PMask r; for (int i = 0; i < RG_PW; ++i) r.w[i] = w[i] & o.w[i]; return r; }
+    PMask& operator|=(const PMask& o) { for (int i = 0; i < RG_PW; ++i) w[i] |= o.w[i]; return *this; }
+    PMask andnot(const PMask& o) const { PMask r; for (int i = 0; i < RG_PW; ++i) r.w[i] = w[i] & ~o.w[i]; return r; }
+    bool operator==(const PMask& o) const { return w[0] == o.w[0] && w[1] == o.w[1] && w[2] == o.w[2] && w[3] == o.w[3]; }
+    static PMask first(int P) { PMask r; for (int k = 0; k < P; ++k) r.set(k); return r; }
+};
+
+// One edge group of a DP row in the pathwise modes: all paths entering `row` through the same predecessor row share the
+// direction chosen by the group's alpha path.  A group whose members span several 64-path pages is listed
+// once per page: the entry of the alpha's page first (it runs the alpha), then continuation entries (ga == GA_CONT) that
+// only follow the directions already chosen.
 struct GroupDesc {
+    static constexpr uint32_t GA_CONT = 0xffffffffu;
     int32_t pred;     // predecessor row (successor row in the reverse program)
-    uint32_t ga;      // group alpha path id
-    uint64_t mask;    // member paths
+    uint32_t ga;      // group alpha: bit index inside `page` (path id = page * 64 + ga), or GA_CONT
+    uint64_t mask;    // member paths of this page
     int32_t slot;     // index of this (row, group) in the direction-word store
-    int32_t pad;
+    int32_t page;     // 64-path page of `mask`
 };
 
 struct HostGraph {
@@ -43,13 +65,13 @@ struct HostGraph {
     bool has_path = false;
     std::string path_error;                     // why a GFA with P lines has no PathGraph view (reported for modes 4+)
     int32_t P = 0;
-    std::vector<uint64_t> row_mask;             // paths through each row (all ones for rows 0, L-1)
+    std::vector<PMask> row_mask;                // paths through each row (all ones for rows 0, L-1)
     std::vector<int32_t> alphas;
     std::vector<uint8_t> pnwp, rnwp;            // forward / reverse "row has listed predecessors"
     std::vector<int32_t> eoff, epred;           // forward PredHash, CSR, ascending pred row
-    std::vector<uint64_t> emask;
+    std::vector<PMask> emask;
     std::vector<int32_t> roff, rsucc;           // reverse PredHash
-    std::vector<uint64_t> rmask;
+    std::vector<PMask> rmask;
     std::vector<int32_t> dfs, dfe;              // pathwise_graph.rs:306-354; ndm[i][j] recomputed from these
     std::vector<int32_t> knm;                   // highest path id NOT through the row, -1 if none
     // DP programs: groups of row i are fgroups[fgoff[i] .. fgoff[i+1])

@@ -13,7 +13,7 @@ namespace rg {
 struct PathGraphDev {
     int L, P;
     const uint8_t* lnz;
-    const uint64_t* row_mask;
+    const uint64_t* row_mask;   // RG_PW words per row
     const int* knm;
     const int* dfs;
     const int* dfe;
@@ -27,10 +27,10 @@ struct PathGraphDev {
     const int* seglast;
     const int* eoff;
     const int* epred;
-    const uint64_t* emask;
+    const uint64_t* emask;      // RG_PW words per edge: path k is bit (k & 63) of word (k >> 6)
     const int* roff;
     const int* rsucc;
-    const uint64_t* rmask;
+    const uint64_t* rmask;      // RG_PW words per edge
     const uint8_t* pnwp;
     const uint8_t* rnwp;
 };

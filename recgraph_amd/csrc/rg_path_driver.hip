@@ -144,8 +144,8 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
             for (int step = 1; step + 1 < L; ++step) {
                 const int i = fwd ? step : L - 1 - step;
                 for (int gi = goff[i]; gi < goff[i + 1]; ++gi)
-                    for (int k = 0; k < P; ++k)
-                        if ((groups[gi].mask >> k) & 1) per[k].push_back({i, groups[gi].slot});
+                    for (int b = 0; b < 64; ++b)
+                        if ((groups[gi].mask >> b) & 1) per[groups[gi].page * 64 + b].push_back({i, groups[gi].slot});
             }
             poff.assign(P + 1, 0);
             prow.clear();
@@ -161,7 +161,7 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
         build(h.rgoff, h.rgroups, false, po, pr, ps);
         if ((rc = w.rpoff.upload(po)) || (rc = w.rprow.upload(pr)) || (rc = w.rpslot.upload(ps))) return rc;
         // step tables of the sweeps (record layout documented in k_sweep)
-        if (L >= (1 << 20) || h.fslots >= (1 << 24) || h.rslots >= (1 << 24)) return fail(RG_ERR_GRAPH, "graph too large for the sweep step table");
+        if (L >= (1 << 20) || h.fslots >= (1 << 20) || h.rslots >= (1 << 20)) return fail(RG_ERR_GRAPH, "graph too large for the sweep step table");
         auto steps = [&](const std::vector<int32_t>& goff, const std::vector<GroupDesc>& groups, bool fwd, std::vector<int4>& out) {
             out.clear();
             for (int step = 1; step + 1 < L; ++step) {
@@ -169,13 +169,18 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
                 const bool inner = fwd ? (h.node_id[i] == h.node_id[i - 1] && i > 1) : (h.node_id[i] == h.node_id[i + 1]);
                 const int li = (int)std::string("ACGTN").find(h.lnz[i]);
                 for (int gi = goff[i]; gi < goff[i + 1]; ++gi) {
+                    // x: row (20) | base code (3) | flags (3: first / last entry of the row, inner row of a one-entry
+                    //    segment run) | group alpha bit (6)
+                    // y: slot (20) | knm + 1 (9) | page (2) | continuation entry (1)        z, w: members of the page
                     int flags = 0;
                     if (gi == goff[i]) flags |= 1;
                     if (gi + 1 == goff[i + 1]) flags |= 2;
                     if (inner && goff[i + 1] - goff[i] == 1) flags |= 4;
+                    const bool cont = groups[gi].ga == GroupDesc::GA_CONT;
                     int4 r;
-                    r.x = (int)((unsigned)i | ((unsigned)li << 20) | ((unsigned)flags << 23) | (groups[gi].ga << 26));
-                    r.y = (int)((unsigned)groups[gi].slot | ((unsigned)(h.knm[i] + 1) << 24));
+                    r.x = (int)((unsigned)i | ((unsigned)li << 20) | ((unsigned)flags << 23) | ((cont ? 0u : groups[gi].ga) << 26));
+                    r.y = (int)((unsigned)groups[gi].slot | ((unsigned)(h.knm[i] + 1) << 20) | ((unsigned)groups[gi].page << 29) |
+                                (cont ? 0x80000000u : 0u));
                     r.z = (int)(unsigned)(groups[gi].mask & 0xffffffffull);
                     r.w = (int)(unsigned)(groups[gi].mask >> 32);
                     out.push_back(r);

@@ -14,9 +14,9 @@ struct ReadState {
     int fwd_path, rev_path, fen, rsn, rec_col, displacement;
     float fscore;
     int bound;         // integer lower bound of the final search maximum (>= s0), tightens the pruning
-    int sink_val[64];  // A[sink row][n][k]; semiglobal: best last-column value of path k over its rows >= 1
+    int sink_val[RG_MAXP];  // A[sink row][n][k]; semiglobal: best last-column value of path k over its rows >= 1
     int trace_score;        // value of the forward layer where the traceback starts (written by k_layer)
-    int path_end_row[64];   // semiglobal: first row attaining sink_val[k] (ending_node, pathwise_alignment_recombination.rs:885-897)
+    int path_end_row[RG_MAXP];   // semiglobal: first row attaining sink_val[k] (ending_node, pathwise_alignment_recombination.rs:885-897)
 };
 
 // one entry of the recombination candidate lists: best member of (row, col) that can still matter

@@ -191,7 +191,7 @@ __global__ __launch_bounds__(64, RG_SWEEP_WAVES) void k_sweep(SweepArgs a) {
 #pragma unroll
         for (int q = 0; q < C; ++q) {
             // argmax over ALL P entries where non-members hold 0: usable only if the winner is a member
-            const int bv = bkey[q] >> 6, bk = bkey[q] & 63;
+            const int bv = bkey[q] >> 8, bk = bkey[q] & 255;
             const bool valid = bkey[q] != INT32_MIN && (knm < 0 || bv > 0 || (bv == 0 && bk > knm));
             if (valid) {
                 if (bv > colmax[q]) { colmax[q] = bv; colarg[q] = (i << 8) | bk; }
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(64, RG_SWEEP_WAVES) void k_sweep(SweepArgs a) {
                     if (pos < a.cand_cap) {
                         const int c = lane * C + q;
                         Cand cd;
-                        cd.row = i; cd.col = rev ? n - c : c; cd.val = bkey[q] >> 6; cd.path = bkey[q] & 63;
+                        cd.row = i; cd.col = rev ? n - c : c; cd.val = bkey[q] >> 8; cd.path = bkey[q] & 255;
                         cand[pos] = cd;
                     }
                     ++pos;
@@ -247,8 +247,9 @@ __global__ __launch_bounds__(64, RG_SWEEP_WAVES) void k_sweep(SweepArgs a) {
     // The sweep walks a host-built step table (one 16-byte record per (row, edge group), in sweep order) instead
     // of chasing goff[] -> groups[] -> lnz[] -> knm[] with dependent uniform loads: a wave fetches 64 records with
     // one coalesced load (next batch in flight) and broadcasts record t with v_readlane.
-    //   x: row (20 bits) | base code (3) << 20 | flags (3) << 23 | group alpha (6) << 26
-    //   y: direction-word slot (24 bits) | (knm + 1) (7) << 24        z, w: member mask
+    //   x: row (20 bits) | base code (3) << 20 | flags (3) << 23 | group alpha bit (6) << 26
+    //   y: direction-word slot (20 bits) | (knm + 1) (9) << 20 | 64-path page (2) << 29 | continuation (1) << 31
+    //   z, w: member mask of the page
     const int4* steps = rev ? a.rsteps : a.fsteps;
     const int nsteps = rev ? a.nrsteps : a.nfsteps;
     int4 recs = make_int4(0, 0, 0, 0), recs_next = make_int4(0, 0, 0, 0);
@@ -276,9 +277,9 @@ __global__ __launch_bounds__(64, RG_SWEEP_WAVES) void k_sweep(SweepArgs a) {
     //     (best_ending_node, pathwise_alignment_semiglobal.rs:244-277; -m 9 seed :789-800 which also counts row 0)
     const bool semi_end = a.semi && !rev;
     const int ln_end = n / C, ql_end = n % C;
-    int* endv = sct + 64;          // [64]
-    int* endr = sct + 128;         // [64]
-    if (semi_end) { endv[lane] = INT32_MIN; endr[lane] = 0; }
+    int* endv = sct + 64;               // [RG_MAXP]
+    int* endr = sct + 64 + RG_MAXP;     // [RG_MAXP]
+    if (semi_end) for (int k = lane; k < RG_MAXP; k += WAVE) { endv[k] = INT32_MIN; endr[k] = 0; }
     __syncthreads();
     int gbest_val = INT32_MIN, gbest_row = 0, gbest_path = 0, rowkey = INT32_MIN;
     auto end_fold = [&](int k, int i, const int (&row)[C]) {
@@ -287,12 +288,12 @@ __global__ __launch_bounds__(64, RG_SWEEP_WAVES) void k_sweep(SweepArgs a) {
         for (int q = 0; q < C; ++q) if (q == ql_end) v = row[q];
         if (lane == ln_end) {
             if (v > endv[k]) { endv[k] = v; endr[k] = i; }
-            rowkey = max(rowkey, v * 64 + (63 - k));
+            rowkey = max(rowkey, v * 256 + (255 - k));
         }
     };
     auto end_row_done = [&](int i) {
         if (lane == ln_end && rowkey != INT32_MIN) {
-            const int rv = rowkey >> 6, rk = 63 - (rowkey & 63);
+            const int rv = rowkey >> 8, rk = 255 - (rowkey & 255);
             if (rv > gbest_val) { gbest_val = rv; gbest_row = i; gbest_path = rk; }
         }
         rowkey = INT32_MIN;
@@ -300,6 +301,8 @@ __global__ __launch_bounds__(64, RG_SWEEP_WAVES) void k_sweep(SweepArgs a) {
 
     int s[C];
     int bkey[C];
+    unsigned dmask = 0, lmask = 0;       // directions of the current group's alpha (live across continuation entries)
+    int src = 0;
     while (t < nsteps) {
         int w0, w1;
         unsigned long long gmask;
@@ -307,8 +310,10 @@ __global__ __launch_bounds__(64, RG_SWEEP_WAVES) void k_sweep(SweepArgs a) {
         int i = w0 & 0xfffff;
         int li = (w0 >> 20) & 7;
         int flags = (w0 >> 23) & 7;
-        int ga = (w0 >> 26) & 63;
-        int slot = w1 & 0xffffff;
+        int slot = w1 & 0xfffff;
+        const int kbase = ((w1 >> 29) & 3) * 64;        // first path id of the entry's 64-path page
+        const bool cont = w1 < 0;                       // continuation entry of a group that spans pages: members only
+        int ga = kbase + ((w0 >> 26) & 63);
         const int nm = __popcll(gmask);
         // ---- general (row, group) step ----
         const int g_i = __builtin_amdgcn_readfirstlane(sct[li * 6 + GAP]);
@@ -318,29 +323,30 @@ __global__ __launch_bounds__(64, RG_SWEEP_WAVES) void k_sweep(SweepArgs a) {
             for (int q = 0; q < C; ++q) { s[q] = sct[li * 6 + (int)((erp[q / 16] >> (4 * (q % 16))) & 7)]; bkey[q] = INT32_MIN; }
         }
         {
-            unsigned long long rest = gmask & ~(1ull << ga);
+            unsigned long long rest = cont ? gmask : gmask & ~(1ull << (ga - kbase));
             cells += (unsigned long long)nm;
             // loads: alpha row, and the first member's row in flight while the alpha recurrence runs
-            int rowa[C], nxt[C];
-#pragma unroll
-            for (int q = 0; q < C; ++q) rowa[q] = rows.ld(ga, q * WAVE + lane, wpad);
+            int nxt[C];
             int knext = -1;
             if (rest) {
-                knext = __builtin_ctzll(rest);
+                knext = kbase + __builtin_ctzll(rest);
                 rest &= rest - 1;
 #pragma unroll
                 for (int q = 0; q < C; ++q) nxt[q] = rows.ld(knext, q * WAVE + lane, wpad);
             }
-            unsigned dmask, lmask;
-            int src;
-            RowOps<C, kUni>::alpha(rowa, s, GP, gcost, g_i, g0, lane, ncols, dmask, lmask, src);
+            if (!cont) {        // (a continuation entry keeps dmask / lmask / src of the entry that ran the group's alpha)
+                int rowa[C];
 #pragma unroll
-            for (int q = 0; q < C; ++q) {
-                rows.st(ga, q * WAVE + lane, wpad, rowa[q]);
-                if (track && (lane * C + q) < ncols) bkey[q] = max(bkey[q], rowa[q] * 64 + ga);
+                for (int q = 0; q < C; ++q) rowa[q] = rows.ld(ga, q * WAVE + lane, wpad);
+                RowOps<C, kUni>::alpha(rowa, s, GP, gcost, g_i, g0, lane, ncols, dmask, lmask, src);
+#pragma unroll
+                for (int q = 0; q < C; ++q) {
+                    rows.st(ga, q * WAVE + lane, wpad, rowa[q]);
+                    if (track && (lane * C + q) < ncols) bkey[q] = max(bkey[q], rowa[q] * 256 + ga);
+                }
+                if (semi_end) end_fold(ga, i, rowa);
+                if (dirs) store_dirs(slot, dmask, lmask);
             }
-            if (semi_end) end_fold(ga, i, rowa);
-            if (dirs) store_dirs(slot, dmask, lmask);
             // other members follow the alpha's directions; the next member's row is always in flight
             while (knext >= 0) {
                 const int k = knext;
@@ -348,7 +354,7 @@ __global__ __launch_bounds__(64, RG_SWEEP_WAVES) void k_sweep(SweepArgs a) {
 #pragma unroll
                 for (int q = 0; q < C; ++q) cur[q] = nxt[q];
                 if (rest) {
-                    knext = __builtin_ctzll(rest);
+                    knext = kbase + __builtin_ctzll(rest);
                     rest &= rest - 1;
 #pragma unroll
                     for (int q = 0; q < C; ++q) nxt[q] = rows.ld(knext, q * WAVE + lane, wpad);
@@ -357,14 +363,14 @@ __global__ __launch_bounds__(64, RG_SWEEP_WAVES) void k_sweep(SweepArgs a) {
 #pragma unroll
                 for (int q = 0; q < C; ++q) {
                     rows.st(k, q * WAVE + lane, wpad, cur[q]);
-                    if (track && (lane * C + q) < ncols) bkey[q] = max(bkey[q], cur[q] * 64 + k);
+                    if (track && (lane * C + q) < ncols) bkey[q] = max(bkey[q], cur[q] * 256 + k);
                 }
                 if (semi_end) end_fold(k, i, cur);
             }
             // no barrier: every lane only ever re-reads the row words it wrote itself
         }
         if (semi_end && (flags & F_LAST)) end_row_done(i);
-        if (track && (flags & F_LAST)) row_end(i, ((w1 >> 24) & 127) - 1, bkey);
+        if (track && (flags & F_LAST)) row_end(i, ((w1 >> 20) & 511) - 1, bkey);
         ++t;
     }
 
@@ -387,7 +393,7 @@ __global__ __launch_bounds__(64, RG_SWEEP_WAVES) void k_sweep(SweepArgs a) {
         for (int k = lane; k < P; k += WAVE) rs->sink_val[k] = rows.ld(k, ql * WAVE + ln, wpad);
     }
     if (semi_end) {
-        if (lane < P) { rs->sink_val[lane] = endv[lane]; rs->path_end_row[lane] = endr[lane]; }
+        for (int k = lane; k < P; k += WAVE) { rs->sink_val[k] = endv[k]; rs->path_end_row[k] = endr[k]; }
         if (lane == ln_end) { rs->s0 = gbest_val; rs->end_row_best = gbest_row; rs->seed_path = gbest_path; }
     }
     if (lane == 0 && a.count_cells) atomicAdd(a.cells, cells * (unsigned long long)(n + 1));
@@ -502,7 +508,7 @@ __global__ void k_seed(SeedArgs a) {
         for (int k = 0; k < P; ++k) {
             int v = 0, end = 0;
             for (int e = g.eoff[L - 1]; e < g.eoff[L]; ++e)
-                if ((g.emask[e] >> k) & 1) { v = rs->sink_val[k]; end = g.epred[e]; }
+                if ((g.emask[(long long)e * RG_PW + (k >> 6)] >> (k & 63)) & 1) { v = rs->sink_val[k]; end = g.epred[e]; }
             if (first || v >= best) { best = v; bp = k; bend = end; first = false; }
         }
         rs->s0 = best; rs->bound = best; rs->seed_path = bp; rs->end_row = bend; rs->fwd_path = bp; rs->rev_path = bp;
@@ -511,12 +517,12 @@ __global__ void k_seed(SeedArgs a) {
         bool have = false; int mx = 0, bp = 0;
         for (int e = g.eoff[L - 1]; e < g.eoff[L]; ++e)
             for (int k = 0; k < P; ++k)
-                if ((g.emask[e] >> k) & 1) {
+                if ((g.emask[(long long)e * RG_PW + (k >> 6)] >> (k & 63)) & 1) {
                     const int v = rs->sink_val[k];
                     if (!have || mx < v) { mx = v; bp = k; have = true; }
                 }
         int end = 0;
-        for (int e = g.eoff[L - 1]; e < g.eoff[L]; ++e) if ((g.emask[e] >> bp) & 1) end = g.epred[e];
+        for (int e = g.eoff[L - 1]; e < g.eoff[L]; ++e) if ((g.emask[(long long)e * RG_PW + (bp >> 6)] >> (bp & 63)) & 1) end = g.epred[e];
         rs->s0 = mx; rs->bound = mx; rs->seed_path = bp; rs->end_row = end; rs->fwd_path = bp; rs->rev_path = bp;
         if (!have) rs->status |= ST_WOULD_PANIC;
     }
@@ -934,7 +940,7 @@ static void launch_sweep_c(const SweepArgs& a, int nreads, hipStream_t s) {
     // uniform read-gap cost: every (base, '-') entry equal (reads hold ACGTN only)
     bool uni = true;
     for (int b = 1; b < 5; ++b) uni = uni && a.sc.t[b * 6 + 5] == a.sc.t[5];
-    const size_t sct_bytes = 192 * sizeof(int);
+    const size_t sct_bytes = (64 + 2 * RG_MAXP) * sizeof(int);
     if (uni) hipLaunchKernelGGL((k_sweep<C, true>), dim3(nreads), dim3(64), sct_bytes, s, a);
     else hipLaunchKernelGGL((k_sweep<C, false>), dim3(nreads), dim3(64), sct_bytes, s, a);
 }

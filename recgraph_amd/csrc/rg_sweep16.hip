@@ -181,9 +181,9 @@ __global__ __launch_bounds__(64, 2) void k_sweep16(SweepArgs a) {
     const int GAP = 5;
     extern __shared__ __attribute__((aligned(16))) int lds16[];
     int* sct = lds16;                    // [36] score table
-    int* endv = lds16 + 64;              // [64]
-    int* endr = lds16 + 128;             // [64]
-    int* s2 = lds16 + 192;               // [5][64] packed score pairs: s2[li*64 + (code_lo | code_hi << 3)]
+    int* endv = lds16 + 64;              // [RG_MAXP]
+    int* endr = lds16 + 64 + RG_MAXP;    // [RG_MAXP]
+    int* s2 = lds16 + 64 + 2 * RG_MAXP;  // [5][64] packed score pairs: s2[li*64 + (code_lo | code_hi << 3)]
     if (lane < 36) sct[lane] = a.sc.t[lane];
     __syncthreads();
     const int gcost = sct[GAP];          // uniform read-gap cost (checked by the launcher): the z-space slope
@@ -311,7 +311,9 @@ __global__ __launch_bounds__(64, 2) void k_sweep16(SweepArgs a) {
 #pragma unroll
             for (int q = 0; q < C; ++q) {
                 const int tkey = bkey[q] + (lane * C + q) * gz;    // true key: value << 16 | path
-                emask |= (knm >= 0 ? (bkey[q] >= thrk[q] && tkey > knm) : bkey[q] >= minplain) ? (1u << q) : 0u;
+                // (rows every path visits: the lane's lowest plain threshold, but never a column whose own threshold is
+                // "never": outside the read or outside the recombination band)
+                emask |= (knm >= 0 ? (bkey[q] >= thrk[q] && tkey > knm) : (bkey[q] >= minplain && thrk[q] != INT32_MAX)) ? (1u << q) : 0u;
             }
         }
         if (cand && __any(emask != 0)) {
@@ -375,7 +377,7 @@ __global__ __launch_bounds__(64, 2) void k_sweep16(SweepArgs a) {
     // semiglobal end-row selection (see k_sweep)
     const bool semi_end = a.semi && !rev;
     const int ln_end = n / C, ql_end = n % C;
-    if (semi_end) { endv[lane] = INT32_MIN; endr[lane] = 0; }
+    if (semi_end) for (int k = lane; k < RG_MAXP; k += WAVE) { endv[k] = INT32_MIN; endr[k] = 0; }
     __syncthreads();
     int gbest_val = INT32_MIN, gbest_row = 0, gbest_path = 0, rowkey = INT32_MIN;
     auto end_fold = [&](int k, int i, const int (&row)[H]) {
@@ -385,12 +387,12 @@ __global__ __launch_bounds__(64, 2) void k_sweep16(SweepArgs a) {
         const int v = (ql_end >= H ? hi16(pv) : lo16(pv)) + n * gcost;      // column n: A = z + n * g
         if (lane == ln_end) {
             if (v > endv[k]) { endv[k] = v; endr[k] = i; }
-            rowkey = max(rowkey, v * 64 + (63 - k));
+            rowkey = max(rowkey, v * 256 + (255 - k));
         }
     };
     auto end_row_done = [&](int i) {
         if (lane == ln_end && rowkey != INT32_MIN) {
-            const int rv = rowkey >> 6, rk = 63 - (rowkey & 63);
+            const int rv = rowkey >> 8, rk = 255 - (rowkey & 255);
             if (rv > gbest_val) { gbest_val = rv; gbest_row = i; gbest_path = rk; }
         }
         rowkey = INT32_MIN;
@@ -420,6 +422,8 @@ __global__ __launch_bounds__(64, 2) void k_sweep16(SweepArgs a) {
     int s[H];
     int bkey[C];
     int MU[H], ML[H], SEL[H];
+    unsigned lmask = 0;                  // L mask and fill-forward source lane of the current group's alpha: live across
+    int src = 0;                         // the continuation entries of a group that spans 64-path pages
     while (t < nsteps) {
         int w0, w1;
         unsigned long long gmask;
@@ -427,8 +431,10 @@ __global__ __launch_bounds__(64, 2) void k_sweep16(SweepArgs a) {
         const int i = w0 & 0xfffff;
         const int li = (w0 >> 20) & 7;
         const int flags = (w0 >> 23) & 7;
-        const int ga = (w0 >> 26) & 63;
-        const int slot = w1 & 0xffffff;
+        const int slot = w1 & 0xfffff;
+        const int kbase = ((w1 >> 29) & 3) * 64;        // first path id of the entry's 64-path page
+        const bool cont = w1 < 0;                       // continuation entry of a group that spans pages: members only
+        const int ga = kbase + ((w0 >> 26) & 63);
         const int nm = __popcll(gmask);
         if (KRUN > 0 && (flags & F_INNER) && nm <= KRUN) {
             // ---- inner rows of a segment with a small group: the same paths, one group, predecessor = previous row.
@@ -438,7 +444,7 @@ __global__ __launch_bounds__(64, 2) void k_sweep16(SweepArgs a) {
             {
                 unsigned long long tm = gmask;
 #pragma unroll
-                for (int kk = 0; kk < KRUN; ++kk) { mk[kk] = tm ? __builtin_ctzll(tm) : 0; tm = tm ? (tm & (tm - 1)) : 0; }
+                for (int kk = 0; kk < KRUN; ++kk) { mk[kk] = tm ? kbase + __builtin_ctzll(tm) : 0; tm = tm ? (tm & (tm - 1)) : 0; }
             }
             int rr[KRUN > 0 ? KRUN : 1][H];
 #pragma unroll
@@ -453,8 +459,7 @@ __global__ __launch_bounds__(64, 2) void k_sweep16(SweepArgs a) {
                 const int g0 = a.semi ? 0 : g_i;
 #pragma unroll
                 for (int r = 0; r < H; ++r) s[r] = s2[rli * 64 + (int)((pcode[r / 8] >> (8 * (r % 8))) & 63)];
-                unsigned umask, lmask;
-                int src;
+                unsigned umask;
                 RowOps16<C>::alpha(rr[0], s, g_i, g0, lane, MU, ML, umask, lmask, src);
                 if (nm > 1) RowOps16<C>::select_steps(SEL, s, MU, g_i, g0, lane);
                 if (dirs) store_dirs(rslot, umask, lmask);
@@ -466,7 +471,7 @@ __global__ __launch_bounds__(64, 2) void k_sweep16(SweepArgs a) {
                     set_keys(bkey, rr[0], mk[0]);
 #pragma unroll
                     for (int kk = 1; kk < KRUN; ++kk) if (kk < nm) fold_keys(bkey, rr[kk], mk[kk]);
-                    row_end(ri, ((rw1 >> 24) & 127) - 1, bkey);
+                    row_end(ri, ((rw1 >> 20) & 511) - 1, bkey);
                 }
                 if (semi_end) {
 #pragma unroll
@@ -479,7 +484,7 @@ __global__ __launch_bounds__(64, 2) void k_sweep16(SweepArgs a) {
                 int nw0, nw1;
                 unsigned long long ngm;
                 fetch(t, nw0, nw1, ngm);
-                ri = nw0 & 0xfffff; rli = (nw0 >> 20) & 7; rslot = nw1 & 0xffffff; rw1 = nw1;
+                ri = nw0 & 0xfffff; rli = (nw0 >> 20) & 7; rslot = nw1 & 0xfffff; rw1 = nw1;
             }
 #pragma unroll
             for (int kk = 0; kk < KRUN; ++kk)
@@ -496,34 +501,39 @@ __global__ __launch_bounds__(64, 2) void k_sweep16(SweepArgs a) {
             for (int r = 0; r < H; ++r) s[r] = s2[li * 64 + (int)((pcode[r / 8] >> (8 * (r % 8))) & 63)];
         }
         {
-            unsigned long long rest = gmask & ~(1ull << ga);
+            unsigned long long rest = cont ? gmask : gmask & ~(1ull << (ga - kbase));
             cells += (unsigned long long)nm;
-            int rowa[H], nxt[H];
-#pragma unroll
-            for (int r = 0; r < H; ++r) rowa[r] = rows[(long long)ga * wrow + r * WAVE + lane];
+            int nxt[H];
             int knext = -1;
             if (rest) {
-                knext = __builtin_ctzll(rest);
+                knext = kbase + __builtin_ctzll(rest);
                 rest &= rest - 1;
 #pragma unroll
                 for (int r = 0; r < H; ++r) nxt[r] = rows[(long long)knext * wrow + r * WAVE + lane];
             }
-            unsigned umask, lmask;
-            int src;
-            RowOps16<C>::alpha(rowa, s, g_i, g0, lane, MU, ML, umask, lmask, src);
-            if (nm > 1) RowOps16<C>::select_steps(SEL, s, MU, g_i, g0, lane);
+            if (!cont) {
+                int rowa[H];
 #pragma unroll
-            for (int r = 0; r < H; ++r) rows[(long long)ga * wrow + r * WAVE + lane] = rowa[r];
-            if (track) { if (flags & F_FIRST) set_keys(bkey, rowa, ga); else fold_keys(bkey, rowa, ga); }
-            if (semi_end) end_fold(ga, i, rowa);
-            if (dirs) store_dirs(slot, umask, lmask);
+                for (int r = 0; r < H; ++r) rowa[r] = rows[(long long)ga * wrow + r * WAVE + lane];
+                unsigned umask;
+                RowOps16<C>::alpha(rowa, s, g_i, g0, lane, MU, ML, umask, lmask, src);
+                if (nm > 1) RowOps16<C>::select_steps(SEL, s, MU, g_i, g0, lane);
+#pragma unroll
+                for (int r = 0; r < H; ++r) rows[(long long)ga * wrow + r * WAVE + lane] = rowa[r];
+                if (track) { if (flags & F_FIRST) set_keys(bkey, rowa, ga); else fold_keys(bkey, rowa, ga); }
+                if (semi_end) end_fold(ga, i, rowa);
+                if (dirs) store_dirs(slot, umask, lmask);
+            } else {
+                // members of another page of the group the previous entry started: MU / ML / lmask / src are its alpha's
+                RowOps16<C>::select_steps(SEL, s, MU, g_i, g0, lane);
+            }
             while (knext >= 0) {
                 const int k = knext;
                 int cur[H];
 #pragma unroll
                 for (int r = 0; r < H; ++r) cur[r] = nxt[r];
                 if (rest) {
-                    knext = __builtin_ctzll(rest);
+                    knext = kbase + __builtin_ctzll(rest);
                     rest &= rest - 1;
 #pragma unroll
                     for (int r = 0; r < H; ++r) nxt[r] = rows[(long long)knext * wrow + r * WAVE + lane];
@@ -536,7 +546,7 @@ __global__ __launch_bounds__(64, 2) void k_sweep16(SweepArgs a) {
             }
         }
         if (semi_end && (flags & F_LAST)) end_row_done(i);
-        if (track && (flags & F_LAST)) row_end(i, ((w1 >> 24) & 127) - 1, bkey);
+        if (track && (flags & F_LAST)) row_end(i, ((w1 >> 20) & 511) - 1, bkey);
         ++t;
     }
 
@@ -547,7 +557,7 @@ __global__ __launch_bounds__(64, 2) void k_sweep16(SweepArgs a) {
             const int c = lane * C + q;
             if (c < ncols) {
                 a.colmax_out[(long long)rd * wpad + (rev ? n - c : c)] = ckey[kColmax ? q : 0] == INT32_MIN ? NEG32 : (ckey[kColmax ? q : 0] >> 16) + c * gcost;
-                if (a.colarg_out) a.colarg_out[(long long)rd * wpad + (rev ? n - c : c)] = (crow[kColmax ? q : 0] << 8) | (ckey[kColmax ? q : 0] & 63);
+                if (a.colarg_out) a.colarg_out[(long long)rd * wpad + (rev ? n - c : c)] = (crow[kColmax ? q : 0] << 8) | (ckey[kColmax ? q : 0] & 255);
             }
         }
     }
@@ -561,7 +571,7 @@ __global__ __launch_bounds__(64, 2) void k_sweep16(SweepArgs a) {
         }
     }
     if (semi_end) {
-        if (lane < P) { rs->sink_val[lane] = endv[lane]; rs->path_end_row[lane] = endr[lane]; }
+        for (int k = lane; k < P; k += WAVE) { rs->sink_val[k] = endv[k]; rs->path_end_row[k] = endr[k]; }
         if (lane == ln_end) { rs->s0 = gbest_val; rs->end_row_best = gbest_row; rs->seed_path = gbest_path; }
     }
     if (lane == 0 && a.count_cells) atomicAdd(a.cells, cells * (unsigned long long)(n + 1));
@@ -675,7 +685,7 @@ __global__ __launch_bounds__(256) void k_colmax_rec(ExpandArgs a, int* colmax_ou
         const unsigned long long b = cm_best[j];
         const int key = (int)((unsigned)(b >> 32) ^ 0x80000000u);
         colmax_out[(long long)rd * a.wpad + j] = b ? key >> 16 : NEG32;
-        colarg_out[(long long)rd * a.wpad + j] = b ? (int)(((unsigned)b << 8) | ((unsigned)key & 63u)) : 0;
+        colarg_out[(long long)rd * a.wpad + j] = b ? (int)(((unsigned)b << 8) | ((unsigned)key & 255u)) : 0;
     }
 }
 
@@ -691,7 +701,7 @@ void launch_colmax_rec(const ExpandArgs& a, int* colmax_out, int* colarg_out, in
 
 template <bool kColmax, bool kRec>
 static void launch_sweep16_c(const SweepArgs& a, int nreads, int C, hipStream_t s) {
-    const size_t bytes = (size_t)(192 + 5 * 64) * sizeof(int);
+    const size_t bytes = (size_t)(64 + 2 * RG_MAXP + 5 * 64) * sizeof(int);
     switch (C) {
         case 4: hipLaunchKernelGGL((k_sweep16<4, kColmax, kRec>), dim3(nreads), dim3(64), bytes, s, a); break;
         case 8: hipLaunchKernelGGL((k_sweep16<8, kColmax, kRec>), dim3(nreads), dim3(64), bytes, s, a); break;

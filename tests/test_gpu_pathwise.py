@@ -140,6 +140,15 @@ def test_sweep_kernel_variants_agree(oracle, monkeypatch):
             texts, _ = api.align_batch(gg, reads, ["r%d" % i for i in range(len(reads))], mode=mode)
             monkeypatch.delenv(var)
             assert texts == base, var
+    # a narrow recombination band and very short reads (thresholds of "never" columns, rows every path visits)
+    tiny = ["GG", "A", "ACG", "TTTTT", rd[0][:7], rd[1][:30]] + rd[:6]
+    for mode, om in ((api.MODE_RECOMBINATION, oracle.M8_ABS), (api.MODE_RECOMBINATION_SEMI, oracle.M9_ABS)):
+        base = _check(oracle, g.gfa(), tiny, mode, om, R=0, r=0.1, B=0.8)
+        for var in ("RG_SWEEP_I32", "RG_NO_FREC", "RG_THREE_SWEEPS"):
+            monkeypatch.setenv(var, "1")
+            texts, _ = api.align_batch(gg, tiny, ["r%d" % i for i in range(len(tiny))], mode=mode, R=0, r=0.1, B=0.8)
+            monkeypatch.delenv(var)
+            assert texts == base, (var, mode)
     # scores outside the 16-bit budget: (rows on a path + read length) * max |score| > 24000
     sm = api.create_score_matrix_i32(90, -120)
     table = api._table_from_dict(sm)
@@ -186,3 +195,34 @@ def test_three_sweep_pipeline(oracle, monkeypatch):
         texts, _ = api.align_batch(gg, rd[:2], None, mode=api.MODE_RECOMBINATION, score_matrix=sm)
         for i in range(2):
             assert texts[i] == og.align(oracle.M8_PRUNED, rd[i], name="read%d" % i, scores=table)[0]
+
+
+def test_more_than_64_paths(oracle, monkeypatch):
+    """Path sets wider than one 64-bit word (P up to 256): groups whose members span several 64-path pages run as one
+    alpha entry + continuation entries; packed and i32 sweeps, global and semiglobal, two- and three-sweep pipelines."""
+    from recgraph_amd import api, synth
+    for P, rows, plen, seed in ((70, 900, 120, 51), (130, 1400, 150, 52), (256, 1500, 90, 53)):
+        g = synth.haplotype_graph(rows, P, path_len=plen, seed=seed)
+        rd = synth.haplotype_reads(g, 20, length=plen, seed=seed + 100, mosaic_frac=0.5)
+        rd += [g.path_sequence(P - 1)[:plen], g.path_sequence(64 if P > 64 else 0)[:plen // 2] + g.path_sequence(P - 2)[plen // 2:plen]]
+        base = {}
+        for mode, om in ((api.MODE_PATHWISE, oracle.M4_ABS), (api.MODE_RECOMBINATION, oracle.M8_ABS),
+                         (api.MODE_PATHWISE_SEMI, oracle.M5_ABS), (api.MODE_RECOMBINATION_SEMI, oracle.M9_ABS)):
+            reads = rd if mode in (api.MODE_PATHWISE, api.MODE_RECOMBINATION) else [r[:plen * 2 // 3] for r in rd[:10]]
+            base[mode] = (reads, _check(oracle, g.gfa(), reads, mode, om))
+        gg = api.Graph.from_gfa_text(g.gfa())
+        for var in ("RG_SWEEP_I32", "RG_THREE_SWEEPS"):
+            monkeypatch.setenv(var, "1")
+            for mode in (api.MODE_RECOMBINATION, api.MODE_RECOMBINATION_SEMI):
+                reads, exp = base[mode]
+                texts, _ = api.align_batch(gg, reads, ["r%d" % i for i in range(len(reads))], mode=mode)
+                assert texts == exp, (P, var, mode)
+            monkeypatch.delenv(var)
+        _check(oracle, g.gfa(), rd[:3], api.MODE_RECOMBINATION, oracle.M8_PRUNED)      # the literal restatement
+        tiny = ["GG", "A", "ACG", rd[0][:9]] + rd[:4]
+        exp = _check(oracle, g.gfa(), tiny, api.MODE_RECOMBINATION, oracle.M8_ABS, R=0, r=0.1, B=0.8)
+        for var in ("RG_SWEEP_I32", "RG_NO_FREC", "RG_THREE_SWEEPS"):
+            monkeypatch.setenv(var, "1")
+            texts, _ = api.align_batch(gg, tiny, ["r%d" % i for i in range(len(tiny))], mode=api.MODE_RECOMBINATION, R=0, r=0.1, B=0.8)
+            monkeypatch.delenv(var)
+            assert texts == exp, (P, var)

@@ -121,7 +121,7 @@ def test_gfa_without_a_usable_path_view_keeps_the_lnz_view(rg):
     base = "S\t1\tA\nS\t2\tC\nS\t3\tG\nL\t1\t+\t2\t+\t0M\nL\t1\t+\t3\t+\t0M\nL\t2\t+\t3\t+\t0M\n"
     cases = {
         "segment of row": base + "P\tp\t1+,3+\t*\n",                                   # segment 2 on no path
-        "64 paths": base + "".join("P\tp%d\t1+,2+,3+\t*\n" % k for k in range(65)),
+        "256 paths": base + "".join("P\tp%d\t1+,2+,3+\t*\n" % k for k in range(257)),
         "'+' path steps": base + "P\tp\t1+,2-,3+\t*\n",
         "unknown segment": base + "P\tp\t1+,9+\t*\n",
         "topological id order": base + "P\tp\t1+,3+,2+\t*\n",
@@ -158,3 +158,14 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".cpp", ".hip", ".hpp", ".h")) or f == "Makefile":
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "oracle/" not in txt and "liboracle" not in txt and "import oracle" not in txt, f
+
+
+def test_wide_graphs_flatten_like_the_oracle(rg, oracle):
+    """More than 64 paths (up to 256): path sets are four 64-bit words, groups are listed per 64-path page."""
+    from recgraph_amd import api, synth
+    for P, seed in ((65, 1), (100, 2), (130, 3), (256, 4)):
+        t = synth.haplotype_graph(500, P, path_len=60, seed=seed).gfa()
+        g, og = api.Graph.from_gfa_text(t), oracle.Graph.from_gfa_text(t)
+        assert g.paths_number == P and g.path_error == ""
+        for which in (10, 11, 12, 13, 14, 15, 16, 17, 18, 19):
+            assert g.dump(which) == og.dump(which), (P, which)
