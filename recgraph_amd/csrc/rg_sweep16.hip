@@ -158,7 +158,9 @@ struct RowOps16 {
 // kColmax = false: no per-column maxima (the reverse sweep of the record pipeline: its maxima and their cells are
 // taken from its own records by k_colmax_rec)
 // kRec = true: emissions leave as (row, lane) records (a.frec); false: as Cand entries (a.cand) or not at all
-template <int C, bool kColmax, bool kRec>
+// kWide = true: graphs with more than 64 paths (step entries carry a 64-path page and continuation entries exist); the
+// narrow variant compiles that logic out (page 0, no continuation: it costs registers the forward sweep does not have)
+template <int C, bool kColmax, bool kRec, bool kWide>
 __global__ __launch_bounds__(64, 2) void k_sweep16(SweepArgs a) {
     constexpr int H = C / 2;
     constexpr int KRUN = C <= 16 ? RG_SWEEP16_KRUN : 0;   // rows kept in registers across the inner rows of a segment
@@ -432,8 +434,8 @@ __global__ __launch_bounds__(64, 2) void k_sweep16(SweepArgs a) {
         const int li = (w0 >> 20) & 7;
         const int flags = (w0 >> 23) & 7;
         const int slot = w1 & 0xfffff;
-        const int kbase = ((w1 >> 29) & 3) * 64;        // first path id of the entry's 64-path page
-        const bool cont = w1 < 0;                       // continuation entry of a group that spans pages: members only
+        const int kbase = kWide ? ((w1 >> 29) & 3) * 64 : 0;   // first path id of the entry's 64-path page
+        const bool cont = kWide && w1 < 0;                     // continuation entry of a group that spans pages: members only
         const int ga = kbase + ((w0 >> 26) & 63);
         const int nm = __popcll(gmask);
         if (KRUN > 0 && (flags & F_INNER) && nm <= KRUN) {
@@ -699,15 +701,20 @@ void launch_colmax_rec(const ExpandArgs& a, int* colmax_out, int* colarg_out, in
     }
 }
 
-template <bool kColmax, bool kRec>
-static void launch_sweep16_c(const SweepArgs& a, int nreads, int C, hipStream_t s) {
+template <bool kColmax, bool kRec, bool kWide>
+static void launch_sweep16_w(const SweepArgs& a, int nreads, int C, hipStream_t s) {
     const size_t bytes = (size_t)(64 + 2 * RG_MAXP + 5 * 64) * sizeof(int);
     switch (C) {
-        case 4: hipLaunchKernelGGL((k_sweep16<4, kColmax, kRec>), dim3(nreads), dim3(64), bytes, s, a); break;
-        case 8: hipLaunchKernelGGL((k_sweep16<8, kColmax, kRec>), dim3(nreads), dim3(64), bytes, s, a); break;
-        case 16: hipLaunchKernelGGL((k_sweep16<16, kColmax, kRec>), dim3(nreads), dim3(64), bytes, s, a); break;
-        default: hipLaunchKernelGGL((k_sweep16<32, kColmax, kRec>), dim3(nreads), dim3(64), bytes, s, a); break;
+        case 4: hipLaunchKernelGGL((k_sweep16<4, kColmax, kRec, kWide>), dim3(nreads), dim3(64), bytes, s, a); break;
+        case 8: hipLaunchKernelGGL((k_sweep16<8, kColmax, kRec, kWide>), dim3(nreads), dim3(64), bytes, s, a); break;
+        case 16: hipLaunchKernelGGL((k_sweep16<16, kColmax, kRec, kWide>), dim3(nreads), dim3(64), bytes, s, a); break;
+        default: hipLaunchKernelGGL((k_sweep16<32, kColmax, kRec, kWide>), dim3(nreads), dim3(64), bytes, s, a); break;
     }
+}
+template <bool kColmax, bool kRec>
+static void launch_sweep16_c(const SweepArgs& a, int nreads, int C, hipStream_t s) {
+    if (a.g.P > 64) launch_sweep16_w<kColmax, kRec, true>(a, nreads, C, s);
+    else launch_sweep16_w<kColmax, kRec, false>(a, nreads, C, s);
 }
 void launch_sweep16(const SweepArgs& a, int nreads, int C, hipStream_t s) {
     // a sweep that writes records and is not asked for column maxima skips their tracking
