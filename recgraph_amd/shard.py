@@ -30,8 +30,13 @@ def gather_text(text: bytes, rank, world, device="cpu", dst=0):
     mx = max(1, max(sizes))
     pad = torch.zeros(mx, dtype=torch.uint8, device=device)
     pad[:n] = t
-    outs = [torch.zeros_like(pad) for _ in range(world)] if rank == dst else None
-    dist.gather(pad, outs, dst=dst)
+    try:
+        outs = [torch.zeros_like(pad) for _ in range(world)] if rank == dst else None
+        dist.gather(pad, outs, dst=dst)
+    except (RuntimeError, NotImplementedError):
+        # a backend without gather: every rank receives every part (the same bytes arrive on `dst`)
+        outs = [torch.zeros_like(pad) for _ in range(world)]
+        dist.all_gather(outs, pad)
     if rank != dst:
         return None
     return [bytes(o[:s].cpu().numpy().tobytes()) for o, s in zip(outs, sizes)]
