@@ -43,4 +43,6 @@ def test_c_program_prints_the_reference_stdout(exe, oracle, example_gfa, example
         assert r.returncode == 0, r.stderr
         exp = "".join(og.align(om, rd, name=names[i], idx=i + 1)[0] for i, rd in enumerate(reads))
         assert r.stdout == exp, mode
-        assert "has_record 1, query_length 150" in r.stderr
+        # rg_result_fields of read 0: modes 4 / 8 align it end to end; -m 0 / -m 2 may answer with the empty record of a
+        # band failure (GAFStruct::new(): query_length 0)
+        assert "has_record 1" in r.stderr and ("query_length 150" in r.stderr or mode in (0, 2))
