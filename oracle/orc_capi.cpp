@@ -6,6 +6,8 @@
 #include <cstdio>
 #include <thread>
 
+#include <malloc.h>
+
 #include "orc_common.hpp"
 
 using namespace orc;
@@ -25,6 +27,19 @@ static Scores scores_from(const int* t36) {
     for (int i = 0; i < 6; ++i)
         for (int j = 0; j < 6; ++j) s.t[i][j] = t36[i * 6 + j];
     return s;
+}
+
+// The timed runners keep large blocks inside the malloc arenas: with glibc's defaults every matrix / row vector above
+// 128 KB is an mmap + munmap per read, and on a many-core host the threads then serialise on the address-space lock
+// (the reference itself links jemalloc on linux for the same reason, main.rs:21-23).
+static void tune_malloc_once() {
+    static const bool done = [] {
+        mallopt(M_MMAP_THRESHOLD, 32 << 20);   // (the largest value glibc accepts)
+        mallopt(M_TRIM_THRESHOLD, 1 << 30);
+        mallopt(M_TOP_PAD, 64 << 20);
+        return true;
+    }();
+    (void)done;
 }
 
 extern "C" {
@@ -196,6 +211,7 @@ long long orc_align(void* h, int mode, const char* read, const char* name, long 
 double orc_bench(void* h, int mode, const char* reads_concat, const long long* offsets, long long nreads,
                  const int* scores36, int o, int e, float b, float f, int brc, float mrc, float rbw, int nthreads,
                  unsigned long long* cells_out, unsigned long long* checksum_out) {
+    tune_malloc_once();
     auto* g = (OrcGraph*)h;
     Scores sc0 = scores_from(scores36);
     std::atomic<long long> next{0};
@@ -233,6 +249,7 @@ double orc_bench_text(void* h, int mode, const char* reads_concat, const long lo
                       const int* scores36, int o, int e, float b, float f, int brc, float mrc, float rbw, int nthreads,
                       const char* name_prefix, long long idx_base, char* text_out, long long cap, long long* text_off,
                       long long* need, unsigned long long* cells_out) {
+    tune_malloc_once();
     auto* g = (OrcGraph*)h;
     Scores sc0 = scores_from(scores36);
     std::atomic<long long> next{0};
@@ -278,6 +295,7 @@ double orc_bench_text(void* h, int mode, const char* reads_concat, const long lo
 double orc_bench_faithful(void* h, const char* reads_concat, const long long* offsets, long long nreads, const int* scores36,
                           int brc, float mrc, float rbw, int nthreads, int col_stride, double* dp_secs, double* scan_secs,
                           long long* cols_visited, long long* cols_total) {
+    tune_malloc_once();
     auto* g = (OrcGraph*)h;
     Scores sc0 = scores_from(scores36);
     std::atomic<long long> next{0};
