@@ -164,6 +164,31 @@ class Graph:
         check(lib.rg_graph_create_lnz(lnz.encode(), L, offa, rowa, ida, C.byref(h)))
         return cls(h)
 
+    @classmethod
+    def from_path_arrays(cls, lnz, paths_number, row_paths, pred_hash, node_id):
+        """PathGraph literal (pathwise_graph.rs:10-18) through rg_graph_create_path: ``row_paths[i]`` = set of path ids
+        through row i, ``pred_hash`` = {row: {pred_row: set of path ids}} (PredHash, pathwise_graph.rs:75-125)."""
+        lib = _lib.load()
+        L, W = len(lnz), (paths_number + 63) // 64
+
+        def words(paths):
+            w = [0] * W
+            for k in paths:
+                w[k >> 6] |= 1 << (k & 63)
+            return w
+        rm = [x for i in range(L) for x in words(row_paths[i])]
+        off, preds, masks = [0], [], []
+        for i in range(L):
+            for p_, ks in sorted(pred_hash.get(i, {}).items()):
+                preds.append(p_)
+                masks += words(ks)
+            off.append(len(preds))
+        h = C.c_void_p()
+        check(lib.rg_graph_create_path(lnz.encode(), L, paths_number, (C.c_uint64 * len(rm))(*rm), (C.c_int64 * len(off))(*off),
+                                       (C.c_int64 * max(1, len(preds)))(*preds), (C.c_uint64 * max(1, len(masks)))(*masks),
+                                       (C.c_uint64 * L)(*node_id), C.byref(h)))
+        return cls(h)
+
     def __del__(self):
         try:
             _lib.load().rg_graph_destroy(self._h)

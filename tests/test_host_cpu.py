@@ -169,3 +169,24 @@ def test_wide_graphs_flatten_like_the_oracle(rg, oracle):
         assert g.paths_number == P and g.path_error == ""
         for which in (10, 11, 12, 13, 14, 15, 16, 17, 18, 19):
             assert g.dump(which) == og.dump(which), (P, which)
+
+
+def test_create_path_from_flat_arrays(rg):
+    """rg_graph_create_path (what a caller holding a PathGraph passes: W = ceil(P / 64) mask words per row / edge) builds
+    the same tables as the GFA route, for narrow and wide graphs."""
+    from recgraph_amd import api, synth
+    for P, seed in ((3, 1), (40, 2), (100, 3)):
+        t = synth.haplotype_graph(300, P, path_len=50, seed=seed).gfa()
+        g = api.Graph.from_gfa_text(t)
+        lnz = g.dump(10)
+        rows = g.dump(13).strip(";").split(";")
+        row_paths = [{k for k, b in enumerate(bits) if b == "1"} for bits in rows]
+        pred_hash = {}
+        for item in g.dump(12).strip(";").split(";"):
+            node, lst = item.split(":")
+            pred_hash[int(node)] = {int(x.split("=")[0]): {k for k, b in enumerate(x.split("=")[1]) if b == "1"} for x in lst.split(",")}
+        node_id = [int(x) for x in g.dump(15).split(",")]
+        g2 = api.Graph.from_path_arrays(lnz, P, row_paths, pred_hash, node_id)
+        assert g2.paths_number == P
+        for which in (10, 11, 12, 13, 14, 15, 16, 17, 18, 19):
+            assert g2.dump(which) == g.dump(which), (P, which)
