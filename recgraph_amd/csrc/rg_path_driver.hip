@@ -122,16 +122,24 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
     const int mode = pmode == RG_MODE_PATHWISE_SEMI ? RG_MODE_PATHWISE : pmode == RG_MODE_RECOMBINATION_SEMI ? RG_MODE_RECOMBINATION : pmode;
     const int P = h.P, L = h.L;
     int C = 4;
-    while (C * WAVE < max_n + 1) C *= 2;
-    if (C > 32) return fail(RG_ERR_ARG, "reads longer than 2047 bases are not supported by the pathwise kernels");
-    const int wpad = C * WAVE;
-    const int dir_words = WAVE * (C <= 16 ? 1 : 2);
+    while (C * WAVE < max_n + 1 && C < 32) C *= 2;
+    // Reads longer than 2047 bases: column stripes of 2048, one wave per stripe in one workgroup (k_sweep / k_layer
+    // <32, true>): i32 rows, Cand lists, three sweeps; needs a uniform read-gap cost (every matrix the reference's CLI builds)
+    const int nwv = (max_n + 1 + C * WAVE - 1) / (C * WAVE);
+    if (nwv > 8) return fail(RG_ERR_ARG, "reads longer than 16383 bases are not supported by the pathwise kernels");
+    if (nwv > 1)
+        for (int b = 1; b < 5; ++b)
+            if (p.scores[b * 6 + 5] != p.scores[5]) return fail(RG_ERR_ARG, "reads longer than 2047 bases need a uniform read-gap cost");
+    const int wpad = nwv * C * WAVE;
+    const int dir_words = nwv * WAVE * (C <= 16 ? 1 : 2);
     // packed 16-bit rows (rg_sweep16.hip) whenever the scores of this batch provably fit; RG_SWEEP_I32=1 forces the i32
     // kernel (test hook: the two must agree byte for byte)
     DevScores dsc;
     for (int i = 0; i < 36; ++i) dsc.t[i] = p.scores[i];
-    const bool use16 = !getenv("RG_SWEEP_I32") && sweep16_admissible(dsc, h.max_path_rows, max_n, C);
+    const bool use16 = nwv == 1 && !getenv("RG_SWEEP_I32") && sweep16_admissible(dsc, h.max_path_rows, max_n, C);
     auto sweep = [&](const SweepArgs& sa_, int nr) {
+        // (striped sweeps advance the candidate counter of a read atomically from several waves: start it at zero)
+        if (nwv > 1 && sa_.cand && sa_.ncand_out) (void)hipMemsetAsync(sa_.ncand_out, 0, sizeof(unsigned) * nr, stream);
         if (use16) launch_sweep16(sa_, nr, C, stream);
         else launch_sweep(sa_, nr, C, stream);
     };
@@ -216,7 +224,7 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
         gaps_nonpos = gaps_nonpos && p.scores[x * 6 + 5] <= 0 && p.scores[5 * 6 + x] <= 0;
         for (int y = 0; y < 5; ++y) maxmatch = std::max(maxmatch, p.scores[x * 6 + y]);
     }
-    const bool two_sweep = mode == RG_MODE_RECOMBINATION && gaps_nonpos && !getenv("RG_THREE_SWEEPS");
+    const bool two_sweep = mode == RG_MODE_RECOMBINATION && gaps_nonpos && nwv == 1 && !getenv("RG_THREE_SWEEPS");
     // forward emissions of the two-sweep pipeline are loose (threshold from the path-0 score): k_sweep16 writes them as
     // (row, lane) records that k_expand filters with the final bound; k_sweep writes plain Cand entries
     const bool use_rec = two_sweep && use16 && !getenv("RG_NO_FREC");
@@ -260,6 +268,7 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
         sa.reads = d_reads; sa.read_off = off; sa.bad = bad; sa.state = w.state.p; sa.roll = w.roll.p;
         sa.fsteps = w.fsteps.p; sa.rsteps = w.rsteps.p; sa.nfsteps = w.nfsteps; sa.nrsteps = w.nrsteps;
         sa.semi = semi ? 1 : 0;
+        sa.nwv = nwv;
         sa.rbw = p.rec_band_width; sa.cand_cap = 0; sa.dir_words = dir_words; sa.cells = d_cells;
         SeedArgs se;
         se.g = gd; se.state = w.state.p; se.nreads = chunk; se.mode = pmode; se.sc = sa.sc; se.reads = d_reads; se.read_off = off;
@@ -375,6 +384,7 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
         LayerArgs la;
         memset(&la, 0, sizeof la);
         la.semi = semi ? 1 : 0;
+        la.nwv = nwv;
         la.g = gd; la.sc = sa.sc; la.reads = d_reads; la.read_off = off; la.state = w.state.p; la.dir_words = dir_words; la.dir_fmt = use16 ? 1 : 0;
         la.layer_stride = layer_stride; la.fpoff = w.fpoff.p; la.fprow = w.fprow.p; la.fpslot = w.fpslot.p;
         la.rpoff = w.rpoff.p; la.rprow = w.rprow.p; la.rpslot = w.rpslot.p;
@@ -389,7 +399,7 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
         ta.g = gd; ta.sc = sa.sc; ta.reads = d_reads; ta.read_off = off; ta.state = w.state.p; ta.rec = d_rec + done;
         ta.ops = d_ops + (long long)done * ops_stride; ta.ops_stride = ops_stride; ta.flayer = w.flayer.p;
         ta.rlayer = w.rlayer.p; ta.layer_stride = layer_stride; ta.fpoff = w.fpoff.p; ta.fprow = w.fprow.p;
-        ta.rpoff = w.rpoff.p; ta.rprow = w.rprow.p; ta.nreads = chunk; ta.mode = pmode; ta.semi = semi ? 1 : 0;
+        ta.rpoff = w.rpoff.p; ta.rprow = w.rprow.p; ta.nreads = chunk; ta.mode = pmode; ta.semi = semi ? 1 : 0; ta.nwv = nwv;
         TIMED(T, "k_trace", launch_trace(ta, C, stream));
         if ((rc = T.collect(stats))) return rc;
         HIPCHK(hipMemcpy(&cells_done, d_cells, sizeof cells_done, hipMemcpyDeviceToHost));

@@ -57,6 +57,7 @@ struct SweepArgs {
     // k_sweep16, two-sweep pipeline: emissions go out as one record per (row, lane) instead of one Cand per cell: (4 + C) ints = {row << 6 | lane, column mask, 0, 0, key[C]} with key = value << 16 | path
     int* frec;                 // [reads][frec_cap][4 + C] or null
     unsigned frec_cap;
+    int nwv;                   // waves (column stripes of 2048) per read: > 1 for reads longer than 2047 bases (k_sweep<32, true, true>)
 };
 
 // expands the (row, lane) records of the forward sweep into Cand entries, keeping only cells that can still reach
@@ -153,6 +154,7 @@ struct LayerArgs {
     long long layer_stride;
     const int* fpoff; const int* fprow; const int* fpslot;   // rows of every path, forward order
     const int* rpoff; const int* rprow; const int* rpslot;   // rows of every path, reverse order
+    int nwv;                   // column stripes per read (see SweepArgs)
 };
 
 struct TraceArgs {
@@ -172,6 +174,7 @@ struct TraceArgs {
     int nreads;
     int mode;
     int semi;
+    int nwv;                   // column stripes per read (see SweepArgs)
 };
 
 void launch_sweep(const SweepArgs& a, int nreads, int C, hipStream_t s);

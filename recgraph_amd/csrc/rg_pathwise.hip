@@ -38,10 +38,50 @@ __device__ __forceinline__ int wave_excl_max(int v, int lane) {
     return dpp_shr1(dpp_incl_max(v, NEG), NEG);
 }
 
+// ---- striped long reads --------------------------------------------------------------------------------------------------
+// A read longer than 2047 bases is cut into stripes of 64 * 32 columns, one wave per stripe in ONE workgroup.  Every wave
+// runs the whole step table on its stripe; the recurrences only look left, so wave w needs from wave w - 1, per row
+// update, the old value of its last column (the diagonal source of w's first column) and one carry (the alpha's running
+// maximum / a member's last non-L value).  They travel through a single-producer single-consumer FIFO in LDS: wave w runs
+// a few steps behind wave w - 1 (a systolic pipeline, no workgroup barrier in the row loop).
+constexpr int FIFO_WORDS = 128;
+struct StripeFifo {
+    volatile int* buf;        // [FIFO_WORDS]
+    unsigned* head;           // written by the producer (wave w - 1)
+    unsigned* tail;           // written by the consumer (wave w)
+    unsigned pos;             // this wave's own count (head as producer / tail as consumer)
+    __device__ __forceinline__ void push2(int v0, int v1, int lane) {
+        if (lane == 0) {
+            while (pos + 2 - __hip_atomic_load(tail, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) > (unsigned)FIFO_WORDS) __builtin_amdgcn_s_sleep(1);
+            buf[pos % FIFO_WORDS] = v0;
+            buf[(pos + 1) % FIFO_WORDS] = v1;
+            __hip_atomic_store(head, pos + 2, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        pos += 2;
+    }
+    __device__ __forceinline__ void pop2(int& v0, int& v1, int lane) {
+        int a = 0, b = 0;
+        if (lane == 0) {
+            while (__hip_atomic_load(head, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < pos + 2) __builtin_amdgcn_s_sleep(1);
+            a = buf[pos % FIFO_WORDS];
+            b = buf[(pos + 1) % FIFO_WORDS];
+            __hip_atomic_store(tail, pos + 2, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        pos += 2;
+        v0 = __builtin_amdgcn_readfirstlane(a);
+        v1 = __builtin_amdgcn_readfirstlane(b);
+    }
+};
+struct StripeIO {            // carries of one row update: in from the stripe on the left, out to the stripe on the right
+    int in_prev, in_carry;   // old value of the left stripe's last column; alpha: its running maximum (z-space), member: its last non-L value
+    int out_prev, out_carry;
+};
+
 // In-place row operators.  kUni: every read base has the same gap cost (all matrices the reference CLI can
 // build, score_matrix.rs:35-105), so the prefix sum of the read-gap cost up to column c is c * gcost and needs no
 // registers.
-template <int C, bool kUni>
+// kStripes: `lane` in column arithmetic is the GLOBAL lane (stripe * 64 + lane), `wl` the lane inside the wave.
+template <int C, bool kUni, bool kStripes = false>
 struct RowOps {
     static __device__ __forceinline__ int gp(const int (&GP)[kUni ? 1 : C], int gcost, int lane, int q) {
         if (kUni) return (lane * C + q) * gcost;
@@ -50,8 +90,13 @@ struct RowOps {
     // group alpha: max(d, u, l) as a lane-local serial scan + one wave prefix-max; returns the direction masks and
     // the fill-forward source lane (nearest lane to the left that owns a non-L column)
     static __device__ __forceinline__ void alpha(int (&row)[C], const int (&s)[C], const int (&GP)[kUni ? 1 : C], int gcost,
-                                                 int g_i, int g0, int lane, int ncols, unsigned& dmask, unsigned& lmask, int& src) {
+                                                 int g_i, int g0, int lane, int ncols, unsigned& dmask, unsigned& lmask, int& src,
+                                                 int wl = 0, StripeIO* io = nullptr) {
         int prev_old = dpp_shr1(row[C - 1], NEG);
+        if (kStripes) {
+            io->out_prev = __builtin_amdgcn_readlane(row[C - 1], WAVE - 1);
+            if (wl == 0) prev_old = io->in_prev;
+        }
         int runmax = NEG;
         unsigned dm = 0, lm = 0;
 #pragma unroll
@@ -69,7 +114,12 @@ struct RowOps {
             row[q] = x;
             runmax = max(runmax, x);
         }
-        int run = dpp_shr1(dpp_incl_max(runmax, NEG), NEG);
+        const int incl = dpp_incl_max(runmax, NEG);
+        int run = dpp_shr1(incl, NEG);
+        if (kStripes) {
+            run = max(run, io->in_carry);
+            io->out_carry = max(io->in_carry, __builtin_amdgcn_readlane(incl, WAVE - 1));
+        }
 #pragma unroll
         for (int q = 0; q < C; ++q) {
             const int c = lane * C + q;
@@ -80,13 +130,19 @@ struct RowOps {
             run = y;
         }
         const unsigned full = C >= 32 ? 0xffffffffu : ((1u << C) - 1u);
-        src = dpp_shr1(dpp_incl_max((lm & full) != full ? lane : -1, -1), 0);
+        // (kStripes: wave-local lanes; -1 = no non-L column to the left inside this stripe)
+        src = dpp_shr1(dpp_incl_max((lm & full) != full ? (kStripes ? wl : lane) : -1, -1), kStripes ? -1 : 0);
         dmask = dm; lmask = lm;
     }
     // member: follow the alpha's directions with the path's own values
     static __device__ __forceinline__ void member(int (&row)[C], const int (&s)[C], const int (&GP)[kUni ? 1 : C], int gcost,
-                                                  int g_i, int g0, int lane, int ncols, unsigned dmask, unsigned lmask, int src) {
+                                                  int g_i, int g0, int lane, int ncols, unsigned dmask, unsigned lmask, int src,
+                                                  int wl = 0, StripeIO* io = nullptr) {
         int prev_old = dpp_shr1(row[C - 1], NEG);
+        if (kStripes) {
+            io->out_prev = __builtin_amdgcn_readlane(row[C - 1], WAVE - 1);
+            if (wl == 0) prev_old = io->in_prev;
+        }
         int last = NEG;
 #pragma unroll
         for (int q = 0; q < C; ++q) {
@@ -97,24 +153,31 @@ struct RowOps {
             row[q] = y;
             last = ((lmask >> q) & 1) ? last : y;
         }
-        int cur = __shfl(last, src, WAVE);                         // y of the last non-L column before this lane
+        int cur = __shfl(last, kStripes ? max(src, 0) : src, WAVE);   // y of the last non-L column before this lane
+        if (kStripes && src < 0) cur = io->in_carry;                // ... which lies in a stripe further left
 #pragma unroll
         for (int q = 0; q < C; ++q) {
             const int c = lane * C + q;
             cur = ((lmask >> q) & 1) ? cur : row[q];
             row[q] = c < ncols ? cur + gp(GP, gcost, lane, q) : NEG;
         }
+        if (kStripes) io->out_carry = __builtin_amdgcn_readlane(cur, WAVE - 1);
     }
 };
 
 // One DP sweep over the whole graph for one read.
-template <int C, bool kUni>
-__global__ __launch_bounds__(64, RG_SWEEP_WAVES) void k_sweep(SweepArgs a) {
+// kStripes: a.nwv waves per read, wave w owns columns [w * 64 * C, (w + 1) * 64 * C) (see StripeFifo above).
+template <int C, bool kUni, bool kStripes = false>
+__global__ __launch_bounds__(kStripes ? 512 : 64, kStripes ? 1 : RG_SWEEP_WAVES) void k_sweep(SweepArgs a) {
     const int rd = blockIdx.x;
-    const int lane = threadIdx.x;
+    const int wl = kStripes ? (int)(threadIdx.x & (WAVE - 1)) : (int)threadIdx.x;      // lane inside the wave
+    const int wv = kStripes ? (int)(threadIdx.x >> 6) : 0;                             // stripe of this wave
+    const int nwv = kStripes ? a.nwv : 1;
+    const int lane = wv * WAVE + wl;                                                   // global lane: column = lane * C + q
     const PathGraphDev& g = a.g;
     const int P = g.P;
-    const int wpad = C * WAVE;
+    const int wpadw = C * WAVE;                 // columns of one stripe
+    const int wpad = nwv * wpadw;               // columns per read (side buffers)
     ReadState* rs = a.state + rd;
     const long long ro = a.read_off[rd];
     const int n = __builtin_amdgcn_readfirstlane((int)(a.read_off[rd + 1] - ro));
@@ -129,9 +192,20 @@ __global__ __launch_bounds__(64, RG_SWEEP_WAVES) void k_sweep(SweepArgs a) {
     // score table in LDS
     int* sct = g_lds;
     if (lane < 36) sct[lane] = a.sc.t[lane];
+    // stripe FIFOs (after the score table and the semiglobal end arrays): queue w carries wave w - 1 -> wave w
+    int* fifo_lds = g_lds + 64 + 2 * RG_MAXP;
+    StripeFifo fin{}, fout{};
+    if (kStripes) {
+        constexpr int QW = FIFO_WORDS + 2;
+        if (lane < nwv) { fifo_lds[lane * QW + FIFO_WORDS] = 0; fifo_lds[lane * QW + FIFO_WORDS + 1] = 0; }
+        fin = StripeFifo{fifo_lds + wv * QW, (unsigned*)(fifo_lds + wv * QW + FIFO_WORDS), (unsigned*)(fifo_lds + wv * QW + FIFO_WORDS + 1), 0u};
+        const int nx = wv + 1 < nwv ? wv + 1 : 0;
+        fout = StripeFifo{fifo_lds + nx * QW, (unsigned*)(fifo_lds + nx * QW + FIFO_WORDS), (unsigned*)(fifo_lds + nx * QW + FIFO_WORDS + 1), 0u};
+    }
     __syncthreads();
 
-    Rows rows{a.roll + (long long)rd * P * wpad};
+    // rolling rows of this stripe: [P][wpadw], stripes of a read back to back
+    Rows rows{a.roll + ((long long)rd * nwv + wv) * P * wpadw};
     // per-column constants of this lane
     unsigned long long erp[(C + 15) / 16] = {};   // 4 bits per column: read base facing column c (forward read[c]; reverse read[n-c+1])
     int GP[kUni ? 1 : C];         // prefix sums of the read-gap cost up to column c (general matrices only)
@@ -151,7 +225,9 @@ __global__ __launch_bounds__(64, RG_SWEEP_WAVES) void k_sweep(SweepArgs a) {
             run += (c >= 1 && c < ncols) ? sct[code * 6 + GAP] : 0;
             gpl[q] = run;
         }
-        const int pre = dpp_incl_sum(run) - run;
+        static_assert(!kStripes || kUni, "striped long reads: uniform read-gap cost only");
+        // gap cost of the columns before this lane (stripes: uniform cost, columns 1 .. min(lane * C, ncols) - 1)
+        const int pre = kStripes ? max(0, min(lane * C, ncols) - 1) * gcost : dpp_incl_sum(run) - run;
         if (kUni) GP[0] = 0;
 #pragma unroll
         for (int q = 0; q < C; ++q) {
@@ -171,7 +247,7 @@ __global__ __launch_bounds__(64, RG_SWEEP_WAVES) void k_sweep(SweepArgs a) {
         // start rows: row 0 (forward) / row L-1 (reverse) is the gap-only row, identical for every path
         for (int k = 0; k < P; ++k) {
 #pragma unroll
-            for (int q = 0; q < C; ++q) rows.st(k, q * WAVE + lane, wpad, (lane * C + q) < ncols ? gpl[q] : NEG);
+            for (int q = 0; q < C; ++q) rows.st(k, q * WAVE + wl, wpadw, (lane * C + q) < ncols ? gpl[q] : NEG);
         }
     }
     __syncthreads();
@@ -202,6 +278,13 @@ __global__ __launch_bounds__(64, RG_SWEEP_WAVES) void k_sweep(SweepArgs a) {
             const int cnt = __popc(emask);
             const int incl = dpp_incl_sum(cnt);
             const int total = __shfl(incl, WAVE - 1, WAVE);
+            if (kStripes) {
+                // the stripes of a read append to one list: positions from the read's global counter (zeroed by the
+                // driver; k_search's result does not depend on the order of the candidates)
+                unsigned base = 0;
+                if (wl == 0) base = atomicAdd(&a.ncand_out[rd], (unsigned)total);
+                ncand = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+            }
             unsigned pos = ncand + (unsigned)(incl - cnt);
 #pragma unroll
             for (int q = 0; q < C; ++q) {
@@ -218,9 +301,11 @@ __global__ __launch_bounds__(64, RG_SWEEP_WAVES) void k_sweep(SweepArgs a) {
             ncand += (unsigned)total;
         }
     };
+    const int dww = WAVE * (C <= 16 ? 1 : 2);           // direction words of one stripe per (row, group) slot
     auto store_dirs = [&](int slot, unsigned dmask, unsigned lmask) {
         // 2 bits per column: 1 = D, 2 = U, 3 = L
         static_assert(C <= 16 || C == 32, "direction packing");
+        const int lane = wv * dww + wl;                 // (shadows the global lane: word index inside the slot)
         if (C <= 16) {
             uint32_t wv = 0;
 #pragma unroll
@@ -253,15 +338,15 @@ __global__ __launch_bounds__(64, RG_SWEEP_WAVES) void k_sweep(SweepArgs a) {
     const int4* steps = rev ? a.rsteps : a.fsteps;
     const int nsteps = rev ? a.nrsteps : a.nfsteps;
     int4 recs = make_int4(0, 0, 0, 0), recs_next = make_int4(0, 0, 0, 0);
-    if (lane < nsteps) recs = steps[lane];
-    if (WAVE + lane < nsteps) recs_next = steps[WAVE + lane];
+    if (wl < nsteps) recs = steps[wl];
+    if (WAVE + wl < nsteps) recs_next = steps[WAVE + wl];
     int t = 0;
     // fetch record t (uniform) -> SGPRs; advances the double buffer at batch boundaries
     auto fetch = [&](int tt, int& w0, int& w1, unsigned long long& gmask) {
         const int idx = tt & (WAVE - 1);
         if (idx == 0 && tt > 0) {
             recs = recs_next;
-            const int nb = tt + WAVE + lane;
+            const int nb = tt + WAVE + wl;
             recs_next = nb < nsteps ? steps[nb] : make_int4(0, 0, 0, 0);
         }
         w0 = __builtin_amdgcn_readlane(recs.x, idx);
@@ -303,6 +388,7 @@ __global__ __launch_bounds__(64, RG_SWEEP_WAVES) void k_sweep(SweepArgs a) {
     int bkey[C];
     unsigned dmask = 0, lmask = 0;       // directions of the current group's alpha (live across continuation entries)
     int src = 0;
+    StripeIO io{NEG, NEG, NEG, NEG};
     while (t < nsteps) {
         int w0, w1;
         unsigned long long gmask;
@@ -332,16 +418,18 @@ __global__ __launch_bounds__(64, RG_SWEEP_WAVES) void k_sweep(SweepArgs a) {
                 knext = kbase + __builtin_ctzll(rest);
                 rest &= rest - 1;
 #pragma unroll
-                for (int q = 0; q < C; ++q) nxt[q] = rows.ld(knext, q * WAVE + lane, wpad);
+                for (int q = 0; q < C; ++q) nxt[q] = rows.ld(knext, q * WAVE + wl, wpadw);
             }
             if (!cont) {        // (a continuation entry keeps dmask / lmask / src of the entry that ran the group's alpha)
                 int rowa[C];
 #pragma unroll
-                for (int q = 0; q < C; ++q) rowa[q] = rows.ld(ga, q * WAVE + lane, wpad);
-                RowOps<C, kUni>::alpha(rowa, s, GP, gcost, g_i, g0, lane, ncols, dmask, lmask, src);
+                for (int q = 0; q < C; ++q) rowa[q] = rows.ld(ga, q * WAVE + wl, wpadw);
+                if (kStripes) { io.in_prev = NEG; io.in_carry = NEG; if (wv > 0) fin.pop2(io.in_prev, io.in_carry, wl); }
+                RowOps<C, kUni, kStripes>::alpha(rowa, s, GP, gcost, g_i, g0, lane, ncols, dmask, lmask, src, wl, &io);
+                if (kStripes && wv + 1 < nwv) fout.push2(io.out_prev, io.out_carry, wl);
 #pragma unroll
                 for (int q = 0; q < C; ++q) {
-                    rows.st(ga, q * WAVE + lane, wpad, rowa[q]);
+                    rows.st(ga, q * WAVE + wl, wpadw, rowa[q]);
                     if (track && (lane * C + q) < ncols) bkey[q] = max(bkey[q], rowa[q] * 256 + ga);
                 }
                 if (semi_end) end_fold(ga, i, rowa);
@@ -357,12 +445,14 @@ __global__ __launch_bounds__(64, RG_SWEEP_WAVES) void k_sweep(SweepArgs a) {
                     knext = kbase + __builtin_ctzll(rest);
                     rest &= rest - 1;
 #pragma unroll
-                    for (int q = 0; q < C; ++q) nxt[q] = rows.ld(knext, q * WAVE + lane, wpad);
+                    for (int q = 0; q < C; ++q) nxt[q] = rows.ld(knext, q * WAVE + wl, wpadw);
                 } else knext = -1;
-                RowOps<C, kUni>::member(cur, s, GP, gcost, g_i, g0, lane, ncols, dmask, lmask, src);
+                if (kStripes) { io.in_prev = NEG; io.in_carry = NEG; if (wv > 0) fin.pop2(io.in_prev, io.in_carry, wl); }
+                RowOps<C, kUni, kStripes>::member(cur, s, GP, gcost, g_i, g0, lane, ncols, dmask, lmask, src, wl, &io);
+                if (kStripes && wv + 1 < nwv) fout.push2(io.out_prev, io.out_carry, wl);
 #pragma unroll
                 for (int q = 0; q < C; ++q) {
-                    rows.st(k, q * WAVE + lane, wpad, cur[q]);
+                    rows.st(k, q * WAVE + wl, wpadw, cur[q]);
                     if (track && (lane * C + q) < ncols) bkey[q] = max(bkey[q], cur[q] * 256 + k);
                 }
                 if (semi_end) end_fold(k, i, cur);
@@ -385,15 +475,16 @@ __global__ __launch_bounds__(64, RG_SWEEP_WAVES) void k_sweep(SweepArgs a) {
             }
         }
     }
-    if (a.ncand_out && lane == 0) a.ncand_out[rd] = ncand;
+    if (!kStripes && a.ncand_out && lane == 0) a.ncand_out[rd] = ncand;     // (stripes: the counter was advanced atomically)
     __syncthreads();
     if (!rev && !a.semi) {
         // value of every path at its sink row, column n (lane/slot that owns column n)
-        const int cn = n, ql = cn % C, ln = cn / C;
-        for (int k = lane; k < P; k += WAVE) rs->sink_val[k] = rows.ld(k, ql * WAVE + ln, wpad);
+        const int cn = n, ql = cn % C, ln = cn / C;         // ln: global lane that owns column n
+        if (wv == ln / WAVE)
+            for (int k = wl; k < P; k += WAVE) rs->sink_val[k] = rows.ld(k, ql * WAVE + (ln % WAVE), wpadw);
     }
-    if (semi_end) {
-        for (int k = lane; k < P; k += WAVE) { rs->sink_val[k] = endv[k]; rs->path_end_row[k] = endr[k]; }
+    if (semi_end && wv == ln_end / WAVE) {       // the stripe that owns column n folded every value
+        for (int k = wl; k < P; k += WAVE) { rs->sink_val[k] = endv[k]; rs->path_end_row[k] = endr[k]; }
         if (lane == ln_end) { rs->s0 = gbest_val; rs->end_row_best = gbest_row; rs->seed_path = gbest_path; }
     }
     if (lane == 0 && a.count_cells) atomicAdd(a.cells, cells * (unsigned long long)(n + 1));
@@ -701,10 +792,14 @@ __global__ __launch_bounds__(64) void k_search(SearchArgs a) {
 // u = A[t-1][j] + s(row, '-'), l = A[t][j-1] + s('-', read[j]), D if max == d, else U if max == u, else L.  All three
 // are in registers while the row is rebuilt, so the kernel stores 2 bits per cell (tdir[t][lane] words, 1 = D, 2 = U,
 // 3 = L) instead of the layer itself: 16x fewer bytes, and k_trace reads one word per step instead of three values.
-template <int C>
-__global__ __launch_bounds__(64) void k_layer(LayerArgs a) {
+template <int C, bool kStripes = false>
+__global__ __launch_bounds__(kStripes ? 512 : 64) void k_layer(LayerArgs a) {
     const int rd = blockIdx.x;
-    const int lane = threadIdx.x;
+    const int wl = kStripes ? (int)(threadIdx.x & (WAVE - 1)) : (int)threadIdx.x;      // lane inside the wave
+    const int wv = kStripes ? (int)(threadIdx.x >> 6) : 0;                             // stripe (striped long reads, see k_sweep)
+    const int nwv = kStripes ? a.nwv : 1;
+    const int lane = wv * WAVE + wl;                                                   // global lane: column = lane * C + q
+    const int dww = WAVE * (C <= 16 ? 1 : 2);                                          // words of one stripe per row
     const PathGraphDev& g = a.g;
     ReadState* rs = a.state + rd;
     if (rs->status & (ST_BAD_BASE | ST_WOULD_PANIC | ST_OVERFLOW)) return;
@@ -718,7 +813,16 @@ __global__ __launch_bounds__(64) void k_layer(LayerArgs a) {
     const int ncols = rev ? n : n + 1;
     const int GAP = 5;
     __shared__ int sct[36];
+    __shared__ int fifo_lds[kStripes ? 8 * (FIFO_WORDS + 2) : 1];
     if (lane < 36) sct[lane] = a.sc.t[lane];
+    StripeFifo fin{}, fout{};
+    if (kStripes) {
+        constexpr int QW = FIFO_WORDS + 2;
+        if (lane < nwv) { fifo_lds[lane * QW + FIFO_WORDS] = 0; fifo_lds[lane * QW + FIFO_WORDS + 1] = 0; }
+        fin = StripeFifo{fifo_lds + wv * QW, (unsigned*)(fifo_lds + wv * QW + FIFO_WORDS), (unsigned*)(fifo_lds + wv * QW + FIFO_WORDS + 1), 0u};
+        const int nx = wv + 1 < nwv ? wv + 1 : 0;
+        fout = StripeFifo{fifo_lds + nx * QW, (unsigned*)(fifo_lds + nx * QW + FIFO_WORDS), (unsigned*)(fifo_lds + nx * QW + FIFO_WORDS + 1), 0u};
+    }
     __syncthreads();
     int er[C], GP[C];
     bool act[C];
@@ -734,7 +838,8 @@ __global__ __launch_bounds__(64) void k_layer(LayerArgs a) {
             run += (c >= 1 && c < ncols) ? sct[code * 6 + GAP] : 0;
             GP[q] = run;
         }
-        const int pre = wave_incl_sum(run, lane) - run;
+        // gap cost of the columns before this lane (stripes run with a uniform read-gap cost: columns 1 .. min(c0, ncols) - 1)
+        const int pre = kStripes ? max(0, min(lane * C, ncols) - 1) * sct[GAP] : wave_incl_sum(run, lane) - run;
 #pragma unroll
         for (int q = 0; q < C; ++q) GP[q] += pre;
     }
@@ -765,8 +870,8 @@ __global__ __launch_bounds__(64) void k_layer(LayerArgs a) {
             const int sl = pslot[poff[path] + tt];
             row_o = ii;
             li_o = g.lnz[ii];
-            w0_o = dirs[(long long)sl * a.dir_words + lane];
-            if (C > 16) w1_o = dirs[(long long)sl * a.dir_words + WAVE + lane];
+            w0_o = dirs[(long long)sl * a.dir_words + wv * dww + wl];
+            if (C > 16) w1_o = dirs[(long long)sl * a.dir_words + wv * dww + WAVE + wl];
         }
     };
 #pragma unroll
@@ -806,8 +911,15 @@ __global__ __launch_bounds__(64) void k_layer(LayerArgs a) {
 #pragma unroll
         for (int q = 0; q < C; ++q) if (act[q]) actmask |= 1u << q;
         const bool any_nonl = ((~lmask) & actmask) != 0;
-        const int src = dpp_shr1(dpp_incl_max(any_nonl ? lane : -1, -1), 0);
-        const int pk = dpp_shr1(cur[C - 1], NEG);
+        const int src = dpp_shr1(dpp_incl_max(any_nonl ? wl : -1, -1), kStripes ? -1 : 0);
+        int pk = dpp_shr1(cur[C - 1], NEG);
+        int in_carry = NEG, in_new = NEG;
+        const int out_prev = kStripes ? __builtin_amdgcn_readlane(cur[C - 1], WAVE - 1) : 0;   // old last column of this stripe
+        if (kStripes && wv > 0) {
+            int in_prev;
+            fin.pop2(in_prev, in_carry, wl);
+            if (wl == 0) pk = in_prev;
+        }
         int old[C];
         int y[C];
         int sq[C];
@@ -821,18 +933,27 @@ __global__ __launch_bounds__(64) void k_layer(LayerArgs a) {
             y[q] = base - GP[q];
             if (!((lmask >> q) & 1) && act[q]) last = y[q];
         }
-        const int cin = __shfl(last, src, WAVE);
+        int cin = __shfl(last, kStripes ? max(src, 0) : src, WAVE);
+        if (kStripes && src < 0) cin = in_carry;            // the last non-L column lies in a stripe further left
         int run = cin;
 #pragma unroll
         for (int q = 0; q < C; ++q) {
             if ((lmask >> q) & 1) y[q] = run; else run = y[q];
             cur[q] = act[q] ? y[q] + GP[q] : NEG;
         }
+        if (kStripes) {
+            if (wv + 1 < nwv) {
+                fout.push2(out_prev, __builtin_amdgcn_readlane(run, WAVE - 1), wl);
+                fout.push2(__builtin_amdgcn_readlane(cur[C - 1], WAVE - 1), 0, wl);      // new last column: the `l` source of the next stripe
+            }
+            if (wv > 0) { int pad; fin.pop2(in_new, pad, wl); }
+        }
         // ---- traceback decisions of this row ----
         // the reverse matrix keeps its start row (row L-1) delta-encoded in the reference (absolute_scores skips it):
         // path 0 reads its absolute value there, every other path reads 0 (pathwise_alignment_recombination.rs:748)
         const bool zero_prev = rev && t == 0 && path != 0;
-        const int nk = dpp_shr1(cur[C - 1], NEG);          // new value of column c-1 for the lane's first column
+        int nk = dpp_shr1(cur[C - 1], NEG);                // new value of column c-1 for the lane's first column
+        if (kStripes && wv > 0 && wl == 0) nk = in_new;
         uint32_t tw[C <= 16 ? 1 : 2] = {};
 #pragma unroll
         for (int q = 0; q < C; ++q) {
@@ -845,8 +966,8 @@ __global__ __launch_bounds__(64) void k_layer(LayerArgs a) {
             const uint32_t code = mx == d ? 1u : (mx == u ? 2u : 3u);
             tw[q / 16] |= code << (2 * (q % 16));
         }
-        tdir[(long long)(t + 1) * a.dir_words + lane] = tw[0];
-        if (C > 16) tdir[(long long)(t + 1) * a.dir_words + WAVE + lane] = tw[C <= 16 ? 0 : 1];
+        tdir[(long long)(t + 1) * a.dir_words + wv * dww + wl] = tw[0];
+        if (C > 16) tdir[(long long)(t + 1) * a.dir_words + wv * dww + WAVE + wl] = tw[C <= 16 ? 0 : 1];
         if (!rev && irow == start_row) {
             int v = 0;
 #pragma unroll
@@ -874,11 +995,12 @@ __global__ __launch_bounds__(64) void k_trace(TraceArgs a) {
     uint8_t* ops = a.ops + (long long)rd * a.ops_stride;
     int nops = 0;
     const bool recomb = (a.mode == RG_MODE_RECOMBINATION || a.mode == RG_MODE_RECOMBINATION_SEMI) && rs->fwd_path != rs->rev_path;
-    const int dw = WAVE * (C <= 16 ? 1 : 2);
+    const int dww = WAVE * (C <= 16 ? 1 : 2);          // words of one stripe per layer row
+    const int dw = dww * a.nwv;                          // (a.nwv > 1: striped long reads, see k_sweep)
     // decision of layer row idx at (mirrored) column c
     auto move = [&](const uint32_t* td, int idx, int c) -> uint32_t {
-        const int q = c % C;
-        return (td[(long long)idx * dw + (q / 16) * WAVE + c / C] >> (2 * (q % 16))) & 3u;
+        const int q = c % C, gl = c / C;                 // global lane that owns the column
+        return (td[(long long)idx * dw + (gl / WAVE) * dww + (q / 16) * WAVE + gl % WAVE] >> (2 * (q % 16))) & 3u;
     };
     const uint32_t* fl = reinterpret_cast<const uint32_t*>(a.flayer) + (long long)rd * a.layer_stride;
     // ---- forward walk from (row, j) back to the source on path fp ----
@@ -945,6 +1067,12 @@ static void launch_sweep_c(const SweepArgs& a, int nreads, hipStream_t s) {
     else hipLaunchKernelGGL((k_sweep<C, false>), dim3(nreads), dim3(64), sct_bytes, s, a);
 }
 void launch_sweep(const SweepArgs& a, int nreads, int C, hipStream_t s) {
+    if (a.nwv > 1) {
+        // striped long reads: a.nwv waves per read, 32 columns per lane, uniform read-gap cost (checked by the driver)
+        const size_t bytes = (64 + 2 * RG_MAXP + a.nwv * (FIFO_WORDS + 2)) * sizeof(int);
+        hipLaunchKernelGGL((k_sweep<32, true, true>), dim3(nreads), dim3(64 * a.nwv), bytes, s, a);
+        return;
+    }
     switch (C) {
         case 4: launch_sweep_c<4>(a, nreads, s); break;
         case 8: launch_sweep_c<8>(a, nreads, s); break;
@@ -974,6 +1102,7 @@ void launch_search(const SearchArgs& a, int nreads, hipStream_t s) {
     hipLaunchKernelGGL(k_search, dim3(nreads), dim3(64), bytes, s, a);
 }
 void launch_layer(const LayerArgs& a, int nreads, int C, hipStream_t s) {
+    if (a.nwv > 1) { hipLaunchKernelGGL((k_layer<32, true>), dim3(nreads), dim3(64 * a.nwv), 0, s, a); return; }
     switch (C) {
         case 4: hipLaunchKernelGGL((k_layer<4>), dim3(nreads), dim3(64), 0, s, a); break;
         case 8: hipLaunchKernelGGL((k_layer<8>), dim3(nreads), dim3(64), 0, s, a); break;

@@ -118,9 +118,9 @@ def test_wide_and_long_shapes(oracle):
         texts, _ = api.align_batch(gg, rd[:10], None, mode=mode, score_matrix=sm)
         for i, r in enumerate(rd[:10]):
             assert texts[i] == og.align(om, r, name="read%d" % i, scores=table)[0]
-    # reads longer than the supported 2047 bases: status code, no abort
+    # reads longer than the supported 16383 bases: status code, no abort
     with pytest.raises(_lib.RecGraphError):
-        api.align_batch(gg, ["ACGT" * 600], None, mode=api.MODE_PATHWISE)
+        api.align_batch(gg, ["ACGT" * 4200], None, mode=api.MODE_PATHWISE)
 
 
 def test_sweep_kernel_variants_agree(oracle, monkeypatch):
@@ -226,3 +226,19 @@ def test_more_than_64_paths(oracle, monkeypatch):
             texts, _ = api.align_batch(gg, tiny, ["r%d" % i for i in range(len(tiny))], mode=api.MODE_RECOMBINATION, R=0, r=0.1, B=0.8)
             monkeypatch.delenv(var)
             assert texts == exp, (P, var)
+
+
+def test_reads_longer_than_2047_bases(oracle):
+    """Striped long reads: column stripes of 2048, one wave per stripe in one workgroup, carries through LDS FIFOs
+    (k_sweep / k_layer <32, true, true>), 2 to 4 stripes, mixed with short reads in the same batch."""
+    from recgraph_amd import api, synth
+    for plen, rows, P, nreads, seed in ((2600, 4200, 4, 5, 61), (5000, 7000, 3, 3, 62), (7000, 9000, 2, 2, 63)):
+        g = synth.haplotype_graph(rows, P, path_len=plen, seed=seed)
+        rd = synth.haplotype_reads(g, nreads, length=plen, seed=seed + 100, mosaic_frac=0.7)
+        rd += [g.path_sequence(P - 1)[:plen - 37], g.path_sequence(0)[:300], "ACGT" * 3]
+        _check(oracle, g.gfa(), rd, api.MODE_PATHWISE, oracle.M4_ABS)
+        _check(oracle, g.gfa(), rd, api.MODE_RECOMBINATION, oracle.M8_ABS)
+        _check(oracle, g.gfa(), rd[:3], api.MODE_RECOMBINATION, oracle.M8_ABS, R=1, r=0.5, B=0.7)
+        semi = [r[:len(r) * 2 // 3] for r in rd[:3]]
+        _check(oracle, g.gfa(), semi, api.MODE_PATHWISE_SEMI, oracle.M5_ABS)
+        _check(oracle, g.gfa(), semi, api.MODE_RECOMBINATION_SEMI, oracle.M9_ABS)

@@ -26,7 +26,9 @@ while time.time() < t_end and not fails:
     rng = np.random.default_rng(seed0 * 1000 + it)
     it += 1
     P = int(rng.choice([1, 2, 3, 5, 8, 16, 33, 40, 70, 130]))
-    plen = int(rng.choice([20, 60, 150, 300, 700, 1300], p=[0.2, 0.2, 0.2, 0.2, 0.15, 0.05]))
+    plen = int(rng.choice([20, 60, 150, 300, 700, 1300, 2600], p=[0.2, 0.2, 0.2, 0.2, 0.13, 0.05, 0.02]))
+    if plen > 2047:
+        P = min(P, 5)        # striped long reads: keep the oracle's L x n x P affordable
     rows = int(plen * rng.uniform(1.5, 6.0))
     sg = synth.haplotype_graph(rows, P, path_len=plen, seed=int(rng.integers(1, 10**6)), shared_frac=float(rng.uniform(0.1, 0.6)))
     gfa = sg.gfa()
