@@ -104,7 +104,8 @@ void rg_graph_destroy(rg_graph* g);
  * segment, steps against the id order, a segment on no path: pathwise_graph.rs:182) still yields the LnzGraph view, which
  * is all modes 0-3 need (main.rs:29); the reason is returned here ("" when the PathGraph view exists or the GFA has no
  * P lines) and by rg_batch_create (RG_ERR_GRAPH) when a pathwise mode is requested on such a graph.
- * Limits of the pathwise kernels: at most 256 paths; reads of at most 2047 bases. */
+ * Limits of the pathwise kernels: at most 256 paths; reads of at most 16383 bases (reads longer than 2047 bases run
+ * as column stripes of 2048 in one workgroup and need a uniform read-gap cost: every matrix the reference's CLI builds). */
 const char* rg_graph_path_error(const rg_graph* g);
 int64_t rg_graph_rows(const rg_graph* g);   /* lnz.len() of the LnzGraph (or PathGraph if only that exists) */
 int32_t rg_graph_paths(const rg_graph* g);  /* paths_number, 0 without P lines */
