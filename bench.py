@@ -38,8 +38,8 @@ DEFAULT_BATCH = {"C2": 10000, "C3": 10000, "C4": 4096, "C5": 4096}
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=25, help="timed steps (default: 25 x 4096 = 102 400 distinct reads, BASELINE.json's 100 k)")
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="C5", choices=["C2", "C3", "C4", "C5"])
     ap.add_argument("--batch", type=int, default=0, help="reads per step per GPU (default: per config)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
