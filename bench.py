@@ -6,9 +6,11 @@ alignment (R=4 r=0.1 B=1) of synthetic 1 kbp reads against a fixed synthetic ~10
 25 distinct batches of 4096 reads (102 400 distinct reads per GPU, seeded); a "step" is one pass of the hot path over ONE
 batch: upload of the batch's reads (rg_batch_set_reads: the timed region starts with the graph resident and the reads in
 host memory in the C ABI's input form, bases + offsets — 4 MB per step, PCIe-inclusive), two DP sweeps, candidate expansion, search,
-layer rebuild and traceback on the device, record fetch and GAF formatting on the host.  Consecutive steps alternate
-between two batch handles so that the device part of step i+1 overlaps the host formatting of step i.  The GAF text of
-EVERY timed step is kept and gathered to rank 0 at the end (inside the timed region), over RCCL when N > 1.
+layer rebuild and traceback on the device, record fetch and GAF formatting on the host.  Consecutive steps rotate over
+three batch handles (work-buffer sets in HBM, `--handles`) whose device parts run on three host threads / streams
+(`--device-threads`): the latency-bound small kernels of one step fill the gaps of the other steps' sweeps, and the host
+formatting and the upload of later steps overlap all of it.  The GAF text of EVERY timed step is kept and gathered to
+rank 0 at the end (inside the timed region), over RCCL when N > 1.
 
 Multi-GPU: reads shard across ranks (one process per GPU, graph replicated, no data-path collective).  Launched by
 torchrun (RANK / LOCAL_RANK / WORLD_SIZE in the environment) or directly: `python bench.py --gpus N` starts the N rank
@@ -45,8 +47,9 @@ def parse_args(argv=None):
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--cpu-reads", type=int, default=-1, help="cap on the reads of every cpu_baseline leg (0 = skip the legs)")
     ap.add_argument("--no-cpu", action="store_true", help="skip cpu_baseline and the parity gate")
-    ap.add_argument("--device-threads", type=int, default=2, choices=[1, 2],
-                    help="2: the device parts of the two batch handles run concurrently (two host threads, two streams)")
+    ap.add_argument("--handles", type=int, default=3, help="batch handles (work-buffer sets in HBM) the steps rotate over")
+    ap.add_argument("--device-threads", type=int, default=3, choices=[1, 2, 3, 4],
+                    help="host threads (and streams) that run the device parts of the handles concurrently; 1 = one after the other")
     return ap.parse_args(argv)
 
 
@@ -85,9 +88,9 @@ def spawn_ranks(args):
 
 
 class HipEngine:
-    """The product: two rg_batch handles on this rank's GPU behind the C ABI (ctypes)."""
+    """The product: `nhandles` rg_batch handles on this rank's GPU behind the C ABI (ctypes)."""
 
-    def __init__(self, dev, gfa, mode, first_reads):
+    def __init__(self, dev, gfa, mode, first_reads, nhandles=2):
         from recgraph_amd import _lib, api
         self._lib, self._api = _lib, api
         _lib.check(_lib.load().rg_set_device(dev))
@@ -96,13 +99,14 @@ class HipEngine:
         self.params = api.make_params(mode)
         self.handles = [api.Batch(self.graph, first_reads, self.params)]
         try:
-            # setup (not a timed or warm-up step): the second handle and the work buffers of both; if two sets do not fit
-            # the HBM the steps run back to back on one handle
+            # setup (not a timed or warm-up step): the other handles and the work buffers of all; handles whose buffers
+            # do not fit the HBM are dropped (with one handle the steps run back to back)
             self.handles[0].run()
-            self.handles.append(api.Batch(self.graph, first_reads, self.params))
-            self.handles[1].run()
+            for _ in range(1, nhandles):
+                self.handles.append(api.Batch(self.graph, first_reads, self.params))
+                self.handles[-1].run()
         except _lib.RecGraphError:
-            del self.handles[1:]
+            del self.handles[-1]
         self.rows, self.paths = self.graph.rows, self.graph.paths_number
         self.host_s = {}
 
@@ -145,9 +149,9 @@ class StubEngine:
         def kernel_stats(self):
             return {}
 
-    def __init__(self, dev, gfa, mode, first_reads):
+    def __init__(self, dev, gfa, mode, first_reads, nhandles=2):
         self.host_s = {}
-        self.handles = [self.H(), self.H()]
+        self.handles = [self.H() for _ in range(nhandles)]
         self.rows, self.paths = gfa.count("\n"), 0
 
     def thread_init(self):
@@ -282,7 +286,7 @@ def main():
     nreads_step = len(batches[0])
 
     dev = local_rank
-    eng = (StubEngine if stub else HipEngine)(dev, gfa, mode, warm)
+    eng = (StubEngine if stub else HipEngine)(dev, gfa, mode, warm, max(1, args.handles))
     hs = eng.handles
     batch_reads = batches                       # strings: the parity gate and the CPU legs align these
     batches = [eng.pack(b) for b in batches]    # the C ABI's input form, built once (not part of the hot path)
@@ -393,7 +397,7 @@ def main():
                     "kernel": kname, "avg_launch_ms": round(ms / launches, 3), "launches": launches,
                     "reads_per_launch": round(reads_per_launch, 1),
                     "durations_from": ("%d probe steps with the device parts serialised, after the timed region (the timed "
-                                       "steps run two handles concurrently: kernel_ms_per_step includes the other stream)" % probe_steps)
+                                       "steps run several handles concurrently: kernel_ms_per_step includes the other streams)" % probe_steps)
                     if probe else "the timed region (HIP events on the batch stream)",
                     # SURVEY §8d figure (the reference's own L x (n+1) x P matrices): NOT a fraction of anything this
                     # design moves — rows stay packed in registers / cache, so it exceeds the HBM peak by construction
