@@ -443,7 +443,11 @@ def main():
                           reads_step_all * min(args.steps, nb)),
                        "parallelism": "read-shard x%d" % world},
             "cell_updates_per_s": round(cells_all / dt, 1),
-            "kernel_ms_per_step": {k: round(v[0] / args.steps, 3) for k, v in kstats.items()},
+            # HIP-event time per kernel and step.  With several device threads the steps overlap on the GPU: the figures of
+            # the timed region include the other streams' kernels (their sum exceeds the step), the probe figures are
+            # the kernels' own durations (their sum is the GPU time one step would take alone)
+            "kernel_ms_per_step": {k: round(v[0] / probe_steps, 3) for k, v in kroof.items()},
+            "kernel_ms_per_step_in_timed_region": {k: round(v[0] / args.steps, 3) for k, v in kstats.items()} if probe else None,
             # host wall time per step: device thread = run + fetch, main thread = format + set_reads (canonicalise + upload
             # of the batch two steps ahead) + wait_for_device; the two threads overlap
             "host_ms_per_step": {k: round(v / args.steps * 1e3, 3) for k, v in eng.host_s.items()},
