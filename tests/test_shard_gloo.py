@@ -95,3 +95,13 @@ def test_bench_refuses_a_world_size_it_was_not_asked_for():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--no-cpu"], env=env, capture_output=True,
                          text=True, timeout=120)
     assert out.returncode == 2 and "WORLD_SIZE" in out.stderr
+
+
+def test_bench_step_pipeline_shapes():
+    """run_steps with one handle (steps back to back), with handles served by one device thread, and with as many device
+    threads as handles: every timed step's text arrives exactly once, in order."""
+    per_rank = 3 * sum(len("read%d\t" % i) + 16 + 1 for i in range(64))
+    for extra in (["--handles", "1", "--device-threads", "1"], ["--handles", "2", "--device-threads", "1"],
+                  ["--handles", "3", "--device-threads", "3"], ["--handles", "3", "--device-threads", "2"]):
+        d = _run_bench(extra, {})
+        assert d["n_gpus"] == 1 and d["gaf_bytes_gathered"] == per_rank, extra
