@@ -454,6 +454,21 @@ def align_batch(graph, reads, names=None, mode=MODE_GLOBAL_POA, seq_index_base=1
     return texts, status
 
 
+def align_batch_multi(graph, reads, names=None, mode=MODE_GLOBAL_POA, seq_index_base=1, device_ids=None, **kw):
+    """``align_batch`` over several GPUs behind one C call (``rg_align_batch_multi``: contiguous read shards, one host
+    thread and stream per device; ``device_ids`` None = every visible device).  Same return value; no ``-s`` retry."""
+    n = len(reads)
+    names = names or ["read%d" % i for i in range(n)]
+    m = MultiBatch(graph, reads, make_params(mode, **kw), device_ids=device_ids)
+    texts, status = [], []
+    for k, sh in enumerate(m.shards):
+        for j in range(sh.n):
+            i = m.begin[k] + j
+            texts.append(sh.gaf_text(j, names[i], seq_index_base + i))
+            status.append(sh.status(j))
+    return texts, status
+
+
 def _single(graph, read, name, mode, seq_index=1, **kw):
     p = make_params(mode, **kw)
     b = Batch(graph, [read], p)

@@ -88,9 +88,13 @@ def main(argv=None):
             1: api.MODE_LOCAL_POA_SCALAR if a.scalar else api.MODE_LOCAL_POA, 3: api.MODE_GAP_LOCAL_POA,
             4: api.MODE_PATHWISE, 5: api.MODE_PATHWISE_SEMI, 8: api.MODE_RECOMBINATION,
             9: api.MODE_RECOMBINATION_SEMI}[a.alignment_mode]
-    texts, status = api.align_batch(g, seqs, names, mode=mode, score_matrix=scores, o=-a.gap_open, e=-a.gap_extension,
-                                    b=float(a.extra_b), f=a.extra_f, R=a.base_rec_cost, r=a.multi_rec_cost,
-                                    B=a.rec_band_width, amb_strand=amb)
+    kw = dict(mode=mode, score_matrix=scores, o=-a.gap_open, e=-a.gap_extension, b=float(a.extra_b), f=a.extra_f,
+              R=a.base_rec_cost, r=a.multi_rec_cost, B=a.rec_band_width)
+    if amb:
+        texts, status = api.align_batch(g, seqs, names, amb_strand=True, **kw)
+    else:
+        # the reference's read loop has no order dependence: every visible GPU takes a contiguous shard of the reads
+        texts, status = api.align_batch_multi(g, seqs, names, device_ids=None, **kw)
     for i, st in enumerate(status):
         if st & (api.READ_WOULD_PANIC | api.READ_BAD_BASE):
             raise SystemExit("read %d (%s): the reference panics on this input" % (i, names[i]))
