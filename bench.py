@@ -3,29 +3,38 @@
 
 Workload (BASELINE.json configs[4], the configuration the north-star target is quoted on): -m 8 recombination
 alignment (R=4 r=0.1 B=1) of synthetic 1 kbp reads against a fixed synthetic ~10 k-row / 32-path graph.  The read set is
-25 distinct batches of 4096 reads (102 400 distinct reads per GPU, seeded); a "step" is one pass of the hot path over ONE
-batch: upload of the batch's reads (rg_batch_set_reads: the timed region starts with the graph resident and the reads in
-host memory in the C ABI's input form, bases + offsets — 4 MB per step, PCIe-inclusive), two DP sweeps, candidate expansion, search,
-layer rebuild and traceback on the device, record fetch and GAF formatting on the host.  Consecutive steps rotate over
-three batch handles (work-buffer sets in HBM, `--handles`) whose device parts run on three host threads / streams
-(`--device-threads`): the latency-bound small kernels of one step fill the gaps of the other steps' sweeps, and the host
-formatting and the upload of later steps overlap all of it.  The GAF text of EVERY timed step is kept and gathered to
-rank 0 at the end (inside the timed region), over RCCL when N > 1.
+25 distinct batches of 4096 reads (102 400 distinct reads per GPU, seeded).  A "step" is one pass of the hot path over ONE
+batch = one tile of the library's streaming engine (rg_stream_*, include/recgraph_hip.h): the timed region starts with
+the graph resident and the reads in host memory in the C ABI's input form (bases + offsets), pushes every step's batch
+into ONE rg_stream and takes the steps' GAF text back in input order.  Everything else happens behind that boundary:
+upload of the batch (4 MB per step, PCIe-inclusive), two DP sweeps, candidate expansion, search, layer rebuild and
+traceback on the device, record fetch and GAF formatting on the host, `--handles` batch handles (work-buffer sets in
+HBM, each with its own host thread and HIP stream) pulling tiles from one queue so that the latency-bound small kernels of
+one step fill the gaps of the other steps' sweeps.  This is the same call sequence `python -m recgraph_amd.cli` and the
+plain-C caller (tests/c/abi_smoke.c) make.  The GAF text of EVERY timed step is gathered to rank 0 inside the timed
+region (N > 1: over RCCL, step by step on a side thread while later steps run).
 
 Multi-GPU: reads shard across ranks (one process per GPU, graph replicated, no data-path collective).  Launched by
 torchrun (RANK / LOCAL_RANK / WORLD_SIZE in the environment) or directly: `python bench.py --gpus N` starts the N rank
 processes itself before anything touches the GPU.  `--scaling weak` (default): every rank aligns steps x batch reads of
-its own; `--scaling strong`: the steps x batch reads of the N=1 run are sharded over the ranks (shard_bounds).
+its own; `--scaling strong`: the steps x batch reads of the N=1 run are dealt to the ranks as WHOLE tiles (a rank's
+launches keep their size; only their number shrinks).
 
-After the timed region rank 0 compares the GAF text of reads of the last timed step byte for byte with the CPU
-restatement's (the in-run parity gate: exit status 3 and "parity_ok": false on any difference) and times the CPU legs
-of `cpu_baseline`.  Prints ONE JSON line on rank 0.
+After the timed region the ranks leave the process group; rank 0 alone then measures the kernels' own durations (probe
+steps on a one-handle stream), compares the GAF text of reads of the last timed step byte for byte with the CPU
+restatement's (the in-run parity gate: exit status 3 and "parity_ok": false on any difference) and times the CPU legs of
+`cpu_baseline` on worker PROCESSES that were forked at the very top of main(), before this process touched the GPU.
+Prints ONE JSON line on rank 0.
 """
 import argparse
+import hashlib
 import json
 import os
+import pickle
+import struct
 import subprocess
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -33,6 +42,7 @@ sys.path.insert(0, ROOT)
 
 BYTES_PER_CELL_UPDATE = {0: 12, 2: 32, 4: 8, 8: 12}   # SURVEY §8d algorithmic bytes per unit of work
 HBM_PEAK_GBS = 8000.0                                 # MI355X_MICROARCH.md: 8.0 TB/s spec
+VALU_NOMINAL_CYCLES = 2.0                             # MI355X_MICROARCH.md: one wave64 VALU instruction per SIMD every 2 cycles
 DISTINCT_BATCHES = 25                                 # 25 x 4096 = 102 400 distinct reads per GPU
 DEFAULT_BATCH = {"C2": 10000, "C3": 10000, "C4": 4096, "C5": 4096}
 
@@ -47,9 +57,9 @@ def parse_args(argv=None):
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--cpu-reads", type=int, default=-1, help="cap on the reads of every cpu_baseline leg (0 = skip the legs)")
     ap.add_argument("--no-cpu", action="store_true", help="skip cpu_baseline and the parity gate")
-    ap.add_argument("--handles", type=int, default=3, help="batch handles (work-buffer sets in HBM) the steps rotate over")
-    ap.add_argument("--device-threads", type=int, default=3, choices=[1, 2, 3, 4],
-                    help="host threads (and streams) that run the device parts of the handles concurrently; 1 = one after the other")
+    ap.add_argument("--handles", type=int, default=3, help="batch handles (work-buffer sets in HBM, host thread + HIP stream each) of the stream")
+    ap.add_argument("--no-probe", action="store_true", help="skip the probe steps (kernel durations then come from the timed region)")
+    ap.add_argument("--sweep-i32", action="store_true", help="force the i32 sweep kernel (rg_set_option sweep_i32)")
     return ap.parse_args(argv)
 
 
@@ -87,134 +97,170 @@ def spawn_ranks(args):
     return 0
 
 
-class HipEngine:
-    """The product: `nhandles` rg_batch handles on this rank's GPU behind the C ABI (ctypes)."""
-
-    def __init__(self, dev, gfa, mode, first_reads, nhandles=2):
-        from recgraph_amd import _lib, api
-        self._lib, self._api = _lib, api
-        _lib.check(_lib.load().rg_set_device(dev))
-        self.dev = dev
-        self.graph = api.Graph.from_gfa_text(gfa)
-        self.params = api.make_params(mode)
-        self.handles = [api.Batch(self.graph, first_reads, self.params)]
+# ----------------------------------------------------------------------------------------------------------------------
+# CPU legs: worker processes forked BEFORE this process imports torch or touches the GPU (one per host CPU, pinned).
+# Threads of one process share an address space: the restatement's per-read work buffers (40 MB vectors: mmap / munmap,
+# page faults, TLB shootdowns to every core running a thread of the process) stop scaling at a few dozen threads;
+# processes do not share any of that.
+class CpuPool:
+    def __init__(self, n):
+        self.workers = []
         try:
-            # setup (not a timed or warm-up step): the other handles and the work buffers of all; handles whose buffers
-            # do not fit the HBM are dropped (with one handle the steps run back to back)
-            self.handles[0].run()
-            for _ in range(1, nhandles):
-                self.handles.append(api.Batch(self.graph, first_reads, self.params))
-                self.handles[-1].run()
-        except _lib.RecGraphError:
-            del self.handles[-1]
-        self.rows, self.paths = self.graph.rows, self.graph.paths_number
-        self.host_s = {}
+            cpus = sorted(os.sched_getaffinity(0))
+        except AttributeError:
+            cpus = list(range(n))
+        for i in range(n):
+            p2c_r, p2c_w = os.pipe()
+            c2p_r, c2p_w = os.pipe()
+            pid = os.fork()
+            if pid == 0:
+                try:
+                    os.close(p2c_w)
+                    os.close(c2p_r)
+                    for w in self.workers:
+                        os.close(w[1])
+                        os.close(w[2])
+                    try:
+                        os.sched_setaffinity(0, {cpus[i % len(cpus)]})
+                    except Exception:
+                        pass
+                    _cpu_worker(p2c_r, c2p_w)
+                finally:
+                    os._exit(0)
+            os.close(p2c_r)
+            os.close(c2p_w)
+            self.workers.append((pid, p2c_w, c2p_r))
 
-    def thread_init(self):
-        self._lib.check(self._lib.load().rg_set_device(self.dev))     # hipSetDevice is per thread
+    @staticmethod
+    def _send(fd, obj):
+        b = pickle.dumps(obj)
+        os.write(fd, struct.pack("<q", len(b)))
+        off = 0
+        while off < len(b):
+            off += os.write(fd, b[off:off + (1 << 16)])
 
-    def pack(self, reads):
-        return self._api.Batch.pack_reads(reads)        # the C ABI's input form: bases blob + offsets
+    @staticmethod
+    def _recv(fd):
+        def rd(n):
+            buf = b""
+            while len(buf) < n:
+                c = os.read(fd, n - len(buf))
+                if not c:
+                    raise RuntimeError("cpu worker died")
+                buf += c
+            return buf
+        n = struct.unpack("<q", rd(8))[0]
+        return pickle.loads(rd(n))
 
-    def set_reads(self, h, packed):
-        t0 = time.perf_counter()
-        h.set_reads(packed)     # canonicalise + upload, inside the step (main thread: overlaps the other handle's kernels)
-        self.host_s["set_reads"] = self.host_s.get("set_reads", 0.0) + time.perf_counter() - t0
+    def call(self, idx, obj):
+        for i in idx:
+            self._send(self.workers[i][1], obj)
+        return [self._recv(self.workers[i][2]) for i in idx]
 
-    def device_part(self, h):
-        t1 = time.perf_counter()
-        h.run()
-        t2 = time.perf_counter()
-        h.fetch()
-        t3 = time.perf_counter()
-        for k, v in (("run", t2 - t1), ("fetch", t3 - t2)):
-            self.host_s[k] = self.host_s.get(k, 0.0) + v
-        return h
+    def scatter(self, idx, objs):
+        for i, o in zip(idx, objs):
+            self._send(self.workers[i][1], o)
+        return [self._recv(self.workers[i][2]) for i in idx]
 
-    def format(self, h, nthreads):
-        return h.format_all(None, 1, nthreads)
-
-    def sync(self):
-        import torch
-        torch.cuda.synchronize()
-
-
-class StubEngine:
-    """RG_BENCH_STUB=1: NO device work — lets the CPU test suite run this file's launcher, sharding, barrier/all-reduce
-    timing and text gather (the world > 1 code path) over gloo.  Its JSON line says so; it is not a measurement."""
-
-    class H:
-        cell_updates = 0
-
-        def kernel_stats(self):
-            return {}
-
-    def __init__(self, dev, gfa, mode, first_reads, nhandles=2):
-        self.host_s = {}
-        self.handles = [self.H() for _ in range(nhandles)]
-        self.rows, self.paths = gfa.count("\n"), 0
-
-    def thread_init(self):
-        pass
-
-    def pack(self, reads):
-        return reads
-
-    def set_reads(self, h, packed):
-        h.reads = packed
-
-    def device_part(self, h):
-        return h
-
-    def format(self, h, nthreads):
-        return "".join("read%d\t%s\n" % (i, r[:16]) for i, r in enumerate(h.reads)).encode()
-
-    def sync(self):
-        pass
+    def close(self):
+        for pid, w, r in self.workers:
+            try:
+                self._send(w, ("quit",))
+            except Exception:
+                pass
+        for pid, w, r in self.workers:
+            try:
+                os.waitpid(pid, 0)
+            except Exception:
+                pass
+            os.close(w)
+            os.close(r)
+        self.workers = []
 
 
-def cpu_legs(args, mode, gfa, reads, gpu_text_of, cores):
-    """cpu_baseline legs on the host cores (oracle = CPU restatement, kind "port") + the in-run parity gate: every read
-    a leg aligns is compared byte for byte with the GPU text of the same read.  Returns (cpu_baseline dict, checked,
-    mismatches)."""
+def _cpu_worker(rfd, wfd):
+    """Child: ("load", gfa, omode) -> graph built; ("reads", reads, name_base, idx_base) -> stored; ("go",) -> aligned
+    on ONE thread, returns (seconds, [text per read], minor page faults); ("faithful", read, stride) -> probe dict."""
+    import resource
     from oracle import oracle as O
-    og = O.Graph.from_gfa_text(gfa)
-    omode = {0: O.M0_SIMD, 2: O.M2, 4: O.M4_ABS, 8: O.M8_ABS}[mode]
+    O.use_native()            # built by the parent before the fork (see main): loading only
+    og = None
+    omode = None
+    job = None
+    while True:
+        msg = CpuPool._recv(rfd)
+        if msg[0] == "quit":
+            return
+        if msg[0] == "load":
+            og = O.Graph.from_gfa_text(msg[1])
+            omode = getattr(O, msg[2])
+            CpuPool._send(wfd, "ok")
+        elif msg[0] == "reads":
+            job = msg[1:]
+            CpuPool._send(wfd, "ok")
+        elif msg[0] == "go":
+            reads, name_base, idx_base = job
+            f0 = resource.getrusage(resource.RUSAGE_SELF).ru_minflt
+            secs, _, texts = og.bench_text(omode, reads, nthreads=1, name_prefix="read", name_base=name_base, idx_base=idx_base)
+            CpuPool._send(wfd, (secs, texts, resource.getrusage(resource.RUSAGE_SELF).ru_minflt - f0))
+        elif msg[0] == "faithful":
+            CpuPool._send(wfd, og.bench_faithful([msg[1]], nthreads=1, col_stride=msg[2]))
+
+
+def cpu_legs(args, mode, gfa, reads, first, gpu_text_of, cores, pool):
+    """cpu_baseline legs on the host cores (oracle = CPU restatement, kind "port") + the in-run parity gate: every read a
+    leg aligns is compared byte for byte with the GPU text of the same read.  `first`: stream index of reads[0] (the
+    stream names read i "read<i>").  Returns (cpu_baseline dict, checked, mismatches)."""
+    omode = {0: "M0_SIMD", 2: "M2", 4: "M4_ABS", 8: "M8_ABS"}[mode]
     what = {0: "oracle m0 (AVX2 semantics, scalar code)", 2: "oracle m2", 4: "oracle absolute-form m4",
             8: "oracle absolute-form m8 with the exact pruned search"}[mode]
     cap = args.cpu_reads if args.cpu_reads > 0 else 1 << 30
     checked, bad = 0, []
     pos = 0
+    nw = len(pool.workers)
+    pool.call(range(nw), ("load", gfa, omode))
 
-    def leg(nreads, nthreads):
+    def leg(per_worker, T):
+        """T worker processes, `per_worker` reads each, started together; wall time from the first 'go' to the last result."""
         nonlocal pos, checked
-        nreads = max(1, min(nreads, cap, len(reads)))
-        if pos + nreads > len(reads):
+        per_worker = max(1, min(per_worker, cap // T if cap >= T else 1, len(reads) // T))
+        need = per_worker * T
+        if pos + need > len(reads):
             pos = 0
         lo = pos
-        pos += nreads
-        secs, _, texts = og.bench_text(omode, reads[lo:lo + nreads], nthreads=nthreads, name_prefix="read", idx_base=1 + lo)
-        # oracle names are read<k> with k relative to the slice: rebuild the GPU names the same way
-        for k, t in enumerate(texts):
-            exp = gpu_text_of(lo + k, "read%d" % k, 1 + lo + k)
-            checked += 1
-            if t != exp and len(bad) < 5:
-                bad.append({"read": lo + k, "cpu": t[-120:].decode(errors="replace"), "gpu": exp[-120:].decode(errors="replace")})
-        return nreads / secs, nreads, secs
+        pos += need
+        idx = list(range(T))
+        pool.scatter(idx, [("reads", reads[lo + k * per_worker:lo + (k + 1) * per_worker], first + lo + k * per_worker,
+                            1 + first + lo + k * per_worker) for k in range(T)])
+        t0 = time.perf_counter()
+        res = pool.call(idx, ("go",))
+        wall = time.perf_counter() - t0
+        faults = 0
+        for k, (secs, texts, flt) in enumerate(res):
+            faults += flt
+            for j, t in enumerate(texts):
+                i = lo + k * per_worker + j
+                exp = gpu_text_of(i)
+                checked += 1
+                if t != exp and len(bad) < 5:
+                    bad.append({"read": i, "cpu": t[-120:].decode(errors="replace"), "gpu": exp[-120:].decode(errors="replace")})
+        return need / wall, need, wall, max(r[0] for r in res), faults / need
 
-    per_read = {0: 0.002, 2: 0.01, 4: 0.25, 8: 0.8}[mode]           # rough single-thread seconds per read (sizing only)
-    v1, n1, s1 = leg(max(4, int(6.0 / per_read)), 1)
-    sweep = []
-    tried = sorted({max(1, cores // 8), max(1, cores // 4), max(1, cores // 2), cores})
-    for T in tried:
-        if T == 1:
-            sweep.append({"threads": 1, "reads_per_s": round(v1, 3), "reads": n1, "secs": round(s1, 2)})
+    per_read = {0: 0.002, 2: 0.01, 4: 0.12, 8: 0.35}[mode]           # rough single-thread seconds per read (sizing only)
+    v1, n1, s1, _, f1 = leg(max(4, int(5.0 / per_read)), 1)
+    sweep = [{"threads": 1, "reads_per_s": round(v1, 3), "reads": n1, "secs": round(s1, 2), "per_thread_efficiency": 1.0,
+              "minor_faults_per_read": round(f1)}]
+    for T in sorted({max(1, cores // 8), max(1, cores // 4), max(1, cores // 2), cores}):
+        if T == 1 or T > nw:
             continue
-        v, n, s = leg(T * max(2, int(2.0 / per_read) if per_read < 0.1 else 2), T)
-        sweep.append({"threads": T, "reads_per_s": round(v, 3), "reads": n, "secs": round(s, 2)})
+        v, n, s, slowest, flt = leg(max(2, int(3.0 / per_read)), T)
+        sweep.append({"threads": T, "reads_per_s": round(v, 3), "reads": n, "secs": round(s, 2),
+                      "per_thread_efficiency": round(v / T / v1, 3), "slowest_worker_secs": round(slowest, 2),
+                      "minor_faults_per_read": round(flt)})
     best = max(sweep, key=lambda e: e["reads_per_s"])
     cpu = {"value": best["reads_per_s"], "unit": "reads/s", "cores": best["threads"], "kind": "port",
-           "sample": "%s; reads of the last timed step; best of a thread-count sweep %s on %d host cores (%d reads, %.1f s)"
+           "sample": "%s; reads of the last timed step; best of a sweep over %s single-threaded worker processes (forked before "
+                     "the GPU was touched, one per CPU, pinned) on %d host CPUs (%d reads, %.1f s)"
                      % (what, [e["threads"] for e in sweep], cores, best["reads"], best["secs"]),
            "single_thread": {"value": round(v1, 4), "unit": "reads/s", "reads": n1, "secs": round(s1, 2)},
            "all_cores": {"value": best["reads_per_s"], "unit": "reads/s", "threads": best["threads"]},
@@ -223,17 +269,156 @@ def cpu_legs(args, mode, gfa, reads, gpu_text_of, cores):
         # FAITHFUL figure: literal transliteration with the UNPRUNED O(L^2 n) best_alignment scan
         # (pathwise_alignment_recombination.rs:808-864).  DP timed in full, the scan on every `stride`-th column and
         # scaled to all columns — an extrapolation, said so here.
-        T = max(1, min(8, cores, cap))
+        T = max(1, min(8, nw, cap))
         stride = 100
-        f = og.bench_faithful(reads[:T], nthreads=T, col_stride=stride)
-        per = (f["dp_secs"] + f["scan_secs"] * f["cols_total"] / max(1, f["cols_visited"])) / T
+        fs = pool.scatter(list(range(T)), [("faithful", reads[k], stride) for k in range(T)])
+        dp = sum(f["dp_secs"] for f in fs)
+        scan = sum(f["scan_secs"] for f in fs)
+        cv, ct = sum(f["cols_visited"] for f in fs), sum(f["cols_total"] for f in fs)
+        per = (dp + scan * ct / max(1, cv)) / T
         cpu["faithful_extrapolated"] = {
             "value": round(1.0 / per, 5), "unit": "reads/s per thread", "all_cores_if_linear": round(cores / per, 3),
-            "reads": T, "threads": T, "dp_secs_per_read": round(f["dp_secs"] / T, 2),
-            "scan_secs_per_read_extrapolated": round(f["scan_secs"] * f["cols_total"] / max(1, f["cols_visited"]) / T, 2),
-            "note": "literal DP timed in full; unpruned scan timed on %d of %d columns per read and scaled"
-                    % (f["cols_visited"] // T, f["cols_total"] // T)}
+            "reads": T, "threads": T, "dp_secs_per_read": round(dp / T, 2),
+            "scan_secs_per_read_extrapolated": round(scan * ct / max(1, cv) / T, 2),
+            "note": "literal DP timed in full; unpruned scan timed on %d of %d columns per read and scaled" % (cv // T, ct // T)}
     return cpu, checked, bad
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+class StubStream:
+    """RG_BENCH_STUB=1: NO device work — lets the CPU test suite run this file's launcher, sharding, barrier/all-reduce
+    timing and per-step text gather (the world > 1 code path) over gloo.  Its JSON line says so; it is not a measurement."""
+    handles = 0
+
+    def __init__(self):
+        self.q = []
+        self.pos = 0
+
+    def push(self, reads):
+        self.q.append((self.pos, reads))
+        self.pos += len(reads)
+
+    def next_text(self):
+        first, reads = self.q.pop(0)
+        return first, len(reads), "".join("read%d\t%s\n" % (i, r[:16]) for i, r in enumerate(reads)).encode(), None, 0
+
+    def kernel_stats(self):
+        return {}
+
+    def close(self):
+        pass
+
+
+class HipStream:
+    """The product: one rg_stream on this rank's GPU behind the C ABI (ctypes)."""
+
+    def __init__(self, api, graph, params, dev, handles, tile, fmt_threads):
+        self.api = api
+        self.st = api.Stream(graph, params, device_ids=[dev], handles_per_device=handles, tile_reads=tile, format_threads=fmt_threads)
+
+    def push(self, packed):
+        self.st.push(packed)
+
+    def next_text(self):
+        t = self.st.next()
+        return t.first, t.n, t.text, t, t.cell_updates
+
+    def kernel_stats(self):
+        return self.st.kernel_stats()
+
+    @property
+    def handles(self):
+        return self.st.handles
+
+    def close(self):
+        self.st.close()
+
+
+class StepGather:
+    """Gather of every step's GAF text to rank 0, one step at a time on a side thread, while the main thread takes the next
+    steps out of the stream (RCCL over xGMI on the GPU box, gloo in the CPU tests).  Steps are gathered in the same order
+    on every rank; nothing else issues collectives while the thread runs."""
+
+    def __init__(self, rank, world, device):
+        self.rank, self.world, self.device = rank, world, device
+        self.parts = []                # rank 0: per step, the list of per-rank payloads
+        self.bytes = 0
+        self.busy_s = 0.0
+        self.items = []
+        self.cv = threading.Condition()
+        self.done = False
+        self.err = None
+        self.th = None
+        if world > 1:
+            self.th = threading.Thread(target=self._run, daemon=True)
+            self.th.start()
+
+    def submit(self, data):
+        if self.world == 1:
+            self.parts.append([data])
+            self.bytes += len(data)
+            return
+        with self.cv:
+            self.items.append(data)
+            self.cv.notify()
+
+    def finish(self):
+        """Blocks until every submitted step has been gathered; returns the seconds spent waiting here."""
+        t0 = time.perf_counter()
+        if self.th is not None:
+            with self.cv:
+                self.done = True
+                self.cv.notify()
+            self.th.join()
+            if self.err is not None:
+                raise self.err
+        return time.perf_counter() - t0
+
+    def _run(self):
+        import numpy as np
+        import torch
+        import torch.distributed as dist
+        try:
+            if self.device != "cpu":
+                torch.cuda.set_device(self.device)
+            while True:
+                with self.cv:
+                    while not self.items and not self.done:
+                        self.cv.wait()
+                    if not self.items:
+                        return
+                    data = self.items.pop(0)
+                t0 = time.perf_counter()
+                n = len(data)
+                ln = torch.tensor([n], dtype=torch.int64, device=self.device)
+                lens = [torch.zeros_like(ln) for _ in range(self.world)]
+                dist.all_gather(lens, ln)
+                sizes = [int(x.item()) for x in lens]
+                mx = max(1, max(sizes))
+                pad = torch.zeros(mx, dtype=torch.uint8)
+                if n:
+                    pad[:n] = torch.from_numpy(np.frombuffer(data, dtype=np.uint8).copy())
+                pad = pad.to(self.device)
+                outs = [torch.empty_like(pad) for _ in range(self.world)] if self.rank == 0 else None
+                dist.gather(pad, outs, dst=0)
+                if self.rank == 0:
+                    got = [o[:s].cpu() for o, s in zip(outs, sizes)]     # kept as tensors: no per-part bytes objects
+                    self.parts.append(got)
+                    self.bytes += sum(sizes)
+                self.busy_s += time.perf_counter() - t0
+        except Exception as ex:      # surfaced by finish()
+            self.err = ex
+
+
+def code_hash():
+    """sha256 over the kernel sources: profiles/counters_*.json carry the hash of the tree they were measured on."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "recgraph_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".hpp", ".cpp")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def main():
@@ -247,6 +432,19 @@ def main():
         sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d\n" % (args.gpus, world))
         sys.exit(2)
     stub = os.environ.get("RG_BENCH_STUB") == "1"
+    cores = os.cpu_count() or 1
+    # the CPU legs' worker processes: forked NOW, before torch / HIP are imported into this process
+    pool = None
+    want_cpu = rank == 0 and not args.no_cpu and not stub
+    oracle_build = None
+    if want_cpu:
+        from oracle import oracle as O        # (ctypes only: nothing here touches the GPU)
+        O.build()
+        oracle_build = O.use_native() or "portable liboracle.so (g++ -O2): the native build failed"
+    if want_cpu and world == 1 and args.cpu_reads != 0:
+        pool = CpuPool(cores)
+    elif want_cpu:
+        pool = CpuPool(max(1, min(8, cores // max(1, world))))      # parity gate only
     import torch
     import torch.distributed as dist
     dist_on = world > 1
@@ -261,7 +459,7 @@ def main():
             torch.cuda.set_device(local_rank)
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     from recgraph_amd import synth
-    from recgraph_amd.shard import gather_text, shard_bounds
+    from recgraph_amd.shard import shard_bounds
 
     cfg = synth.CONFIGS[args.config]
     mode = cfg["mode"]
@@ -275,213 +473,243 @@ def main():
             return synth.substring_reads(sg, n, cfg["n"], seed=seed)
         return synth.haplotype_reads(sg, n, cfg["n"], seed=seed, mosaic_frac=0.5 if args.config == "C5" else 0.0)
 
-    # read set: `nb` distinct batches.  weak: seeded per rank.  strong: the N=1 read set, this rank's shard of every batch.
+    # Read set = `steps` tiles of `batch` reads (distinct for the first DISTINCT_BATCHES, cycled after).
+    #   weak: every rank aligns `steps` tiles of its own (seeded per rank);
+    #   strong: the `steps` tiles of the N=1 run are dealt to the ranks WHOLE (shard_bounds over tiles): a rank's launches
+    #           keep their size, BASELINE.json's "100 k reads sharded across the GPUs".
     nb = min(args.steps, DISTINCT_BATCHES)
     if args.scaling == "weak":
-        batches = [make_reads(batch, 5678 + num + 1000 * rank + 100000 * (i + 1)) for i in range(nb)]
+        my_steps = list(range(args.steps))
+        seed_of = lambda i: 5678 + num + 1000 * rank + 100000 * (i % nb + 1)
     else:
-        lo, hi = shard_bounds(batch, rank, world)
-        batches = [make_reads(batch, 5678 + num + 100000 * (i + 1))[lo:hi] for i in range(nb)]
-    warm = make_reads(len(batches[0]), 5678 + num + 1000 * rank)
-    nreads_step = len(batches[0])
+        lo, hi = shard_bounds(args.steps, rank, world)
+        my_steps = list(range(lo, hi))
+        seed_of = lambda i: 5678 + num + 100000 * (i % nb + 1)
+    max_steps = max(b - a for a, b in (shard_bounds(args.steps, r, world) for r in range(world))) if args.scaling == "strong" else args.steps
+    distinct = sorted({i % nb for i in my_steps})
+    batch_reads = {i: make_reads(batch, seed_of(i)) for i in distinct}          # strings: the parity gate / CPU legs align these
+    warm = make_reads(batch, 5678 + num + 1000 * rank)
 
     dev = local_rank
-    eng = (StubEngine if stub else HipEngine)(dev, gfa, mode, warm, max(1, args.handles))
-    hs = eng.handles
-    batch_reads = batches                       # strings: the parity gate and the CPU legs align these
-    batches = [eng.pack(b) for b in batches]    # the C ABI's input form, built once (not part of the hot path)
-    warm_packed = eng.pack(warm)
-    from concurrent.futures import ThreadPoolExecutor
-    pool = ThreadPoolExecutor(args.device_threads, initializer=eng.thread_init)
-    cores = os.cpu_count() or 1
-    nthreads = max(1, min(16, cores // max(1, min(world, 8))))
-    kstats = {}
-    cells_total = 0
+    fmt_threads = max(1, min(16, cores // max(1, min(world, 8)) // max(1, args.handles)))
+    if stub:
+        main_stream = StubStream()
+        packed = batch_reads
+        warm_packed = warm
+        rows, paths = gfa.count("\n"), 0
+        api = None
+    else:
+        from recgraph_amd import _lib, api
+        _lib.check(_lib.load().rg_set_device(dev))
+        if args.sweep_i32:
+            api.set_option("sweep_i32", 1)
+        graph = api.Graph.from_gfa_text(gfa)
+        params = api.make_params(mode)
+        rows, paths = graph.rows, graph.paths_number
+        main_stream = HipStream(api, graph, params, dev, max(1, args.handles), batch, fmt_threads)
+        packed = {i: api.Batch.pack_reads(r) for i, r in batch_reads.items()}    # the C ABI's input form, built once (not part of the hot path)
+        warm_packed = api.Batch.pack_reads(warm)
 
-    def run_steps(k, read_sets, record, conc=None, stats=None):
-        """k steps over `read_sets` (cycled).  Per step and handle: set_reads (host canonicalisation + H2D) -> device part
-        (kernels + record fetch, a device thread) -> format (host threads).  With two handles the device part of step
-        i+1 overlaps the formatting of step i and the set_reads of step i+2 (both on the main thread); with
-        --device-threads 2 the device parts of the two handles are also submitted concurrently (two streams): the
-        latency-bound small kernels of one handle then run beside the sweeps of the other."""
-        nonlocal cells_total
-        conc = (args.device_threads > 1) if conc is None else conc
-        stats = kstats if stats is None else stats
-        texts = []
+    def run_steps(stream, sets, gather=None):
+        """Push every step's tile, then take them back in input order (each goes to the gather as it arrives)."""
+        for s in sets:
+            stream.push(s)
         last = None
-        nh = len(hs)
-        futs = {}
-        for j in range(min(nh, k)):
-            eng.set_reads(hs[j], read_sets[j % len(read_sets)])
-            if j == 0 or conc:
-                futs[j] = pool.submit(eng.device_part, hs[j])
-        for i in range(k):
-            tw = time.perf_counter()
-            cur = futs.pop(i).result()
-            eng.host_s["wait_for_device"] = eng.host_s.get("wait_for_device", 0.0) + time.perf_counter() - tw
-            if i + 1 < k and nh > 1 and (i + 1) not in futs:
-                futs[i + 1] = pool.submit(eng.device_part, hs[(i + 1) % nh])
-            if record:
-                for kk, (ms, nl) in cur.kernel_stats().items():      # before the handle is reused
-                    acc = stats.setdefault(kk, [0.0, 0])
-                    acc[0] += ms
-                    acc[1] += nl
-                if stats is kstats:
-                    cells_total += cur.cell_updates
-            tf = time.perf_counter()
-            texts.append(eng.format(cur, nthreads))
-            eng.host_s["format"] = eng.host_s.get("format", 0.0) + time.perf_counter() - tf
-            last = (cur, i % len(read_sets))
-            if i + nh < k:
-                eng.set_reads(cur, read_sets[(i + nh) % len(read_sets)])
-                if conc or nh == 1:
-                    futs[i + nh] = pool.submit(eng.device_part, cur)
-        return texts, last
+        cells = 0
+        for _ in sets:
+            first, n, text, tile, c = stream.next_text()
+            cells += c
+            if gather is not None:
+                gather.submit(text)
+            last = (first, n, text, tile)
+        return last, cells
 
+    # setup (neither timed nor warm-up): one tile per handle, so that every handle exists and owns its work buffers
+    run_steps(main_stream, [warm_packed] * max(1, args.handles))
     if args.warmup:
-        run_steps(args.warmup, [warm_packed], False)
+        run_steps(main_stream, [warm_packed] * args.warmup)
 
     def sync():
-        eng.sync()
+        if not stub:
+            torch.cuda.synchronize()
         if dist_on:
             dist.barrier()
-            eng.sync()
+            if not stub:
+                torch.cuda.synchronize()
 
+    k0 = main_stream.kernel_stats()
+    gather = StepGather(rank, world, "cpu" if (stub or not dist_on) else torch.device("cuda", local_rank))
     sync()
-    eng.host_s.clear()
     t0 = time.perf_counter()
-    texts, (last_h, last_set) = run_steps(args.steps, batches, True)
-    # final gather of ALL the GAF records of the timed steps to rank 0 (RCCL over xGMI when N > 1)
-    parts = gather_text(b"".join(texts), rank, world, device="cpu" if (stub or not dist_on) else "cuda")
-    gathered_bytes = sum(len(x) for x in parts) if parts is not None else 0
+    last, cells_total = run_steps(main_stream, [packed[i % nb] for i in my_steps], gather)
+    for _ in range(max_steps - len(my_steps)):
+        gather.submit(b"")                 # strong scaling: every rank takes part in the same number of step gathers
+    gather_wait = gather.finish()          # final gather of ALL the GAF records of the timed steps to rank 0 is complete here
     sync()
     dt = time.perf_counter() - t0
+    k1 = main_stream.kernel_stats()
+    kstats = {k: (v[0] - k0.get(k, (0, 0))[0], v[1] - k0.get(k, (0, 0))[1]) for k, v in k1.items()}
+    nreads_mine = batch * len(my_steps)
     if dist_on:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if stub else "cuda")
+        cdev = "cpu" if stub else "cuda"
+        tt = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-        ct = torch.tensor([float(cells_total), float(nreads_step)], dtype=torch.float64,
-                          device="cpu" if stub else "cuda")
+        ct = torch.tensor([float(cells_total), float(nreads_mine), gather.busy_s + gather_wait], dtype=torch.float64, device=cdev)
         dist.all_reduce(ct, op=dist.ReduceOp.SUM)
-        cells_all, reads_step_all = float(ct[0].item()), int(ct[1].item())
-    else:
-        cells_all, reads_step_all = float(cells_total), nreads_step
-    # Per-kernel durations for the roofline: with two device threads the kernels of the two handles share the GPU, so a
-    # kernel's HIP-event time in the timed region includes the other stream's kernels.  Two probe steps with the device
-    # parts serialised (after the timed region, same read sets) give the kernel's own duration.
-    probe = {}
-    if args.device_threads > 1 and len(hs) > 1 and rank == 0:
-        saved = dict(eng.host_s)
-        _, (last_h, last_set) = run_steps(min(2, args.steps), batches, True, conc=False, stats=probe)   # (the parity gate then checks the probe's last step)
-        eng.host_s.clear()
-        eng.host_s.update(saved)
-    rc = 0
-    if rank == 0:
-        total_reads = reads_step_all * args.steps
-        kroof = probe if probe else kstats
-        probe_steps = min(2, args.steps) if probe else args.steps
-        sweeps = {k: v for k, v in kroof.items() if k.startswith(("k_sweep", "k_m0", "k_m2"))}
-        roof = None
-        use16 = any(k.startswith("k_sweep16") for k in kstats)
-        if sweeps:
-            # dominant kernel family: the DP sweep.  One launch sweeps the whole graph once for one chunk of the batch.
-            ms = sum(v[0] for v in sweeps.values())
-            launches = sum(v[1] for v in sweeps.values())
-            counting = sum(v[1] for k, v in sweeps.items() if not k.endswith("_colmax")) or launches
-            reads_per_launch = nreads_step * probe_steps * (2 if mode == 8 else 1) / counting if mode in (4, 8) else nreads_step * probe_steps / counting
-            per_launch_units = cells_total / args.steps * probe_steps / counting   # cell-updates one sweep launch processes (this rank)
-            avg_s = ms / launches / 1e3
-            algo = per_launch_units * BYTES_PER_CELL_UPDATE[mode] / avg_s / 1e9
-            kname = {0: "k_m0_simd", 2: "k_poa_banded<true>", 4: "k_sweep", 8: "k_sweep"}[mode] + ("16" if use16 else "")
-            roof = {"bound": None, "achieved": None, "peak": None, "unit": None, "frac": None, "traffic": None,
-                    "kernel": kname, "avg_launch_ms": round(ms / launches, 3), "launches": launches,
-                    "reads_per_launch": round(reads_per_launch, 1),
-                    "durations_from": ("%d probe steps with the device parts serialised, after the timed region (the timed "
-                                       "steps run several handles concurrently: kernel_ms_per_step includes the other streams)" % probe_steps)
-                    if probe else "the timed region (HIP events on the batch stream)",
-                    # SURVEY §8d figure (the reference's own L x (n+1) x P matrices): NOT a fraction of anything this
-                    # design moves — rows stay packed in registers / cache, so it exceeds the HBM peak by construction
-                    "algorithmic_equiv_GBps": round(algo, 1)}
-            cj = os.path.join(ROOT, "profiles", "counters_%s.json" % args.config)
-            vj = os.path.join(ROOT, "profiles", "valu_calib.json")
-            if os.path.exists(cj):
-                try:
-                    c = json.load(open(cj))
-                    roof["counters_from"] = c.get("source")
-                    if c.get("kernel_base") != kname:
-                        roof["counters_stale"] = "profiled kernel %s, running %s" % (c.get("kernel_base"), kname)
-                    # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, calibrated units: see the file), per read
-                    # per launch, scaled to this run's reads per launch; fabric-side bytes (Infinity-Cache hits included)
-                    traffic = c["hbm_bytes_per_read_per_launch"] * reads_per_launch
-                    hbm = {"achieved": round(traffic / avg_s / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": round(traffic / avg_s / 1e9 / HBM_PEAK_GBS, 4)}
-                    roof["traffic"] = round(traffic)
-                    roof["hbm"] = hbm
-                    cand = [("hbm", hbm)]
-                    if os.path.exists(vj) and c.get("valu_winstr_per_read_per_launch"):
-                        peak = json.load(open(vj))["peak_winstr_per_s"]
-                        rate = c["valu_winstr_per_read_per_launch"] * reads_per_launch / avg_s
-                        valu = {"achieved": round(rate / 1e9, 2), "peak": round(peak / 1e9, 2), "unit": "G wave-instr/s",
-                                "frac": round(rate / peak, 4)}
-                        roof["valu"] = valu
-                        cand.append(("valu", valu))
-                    b, top = max(cand, key=lambda kv: kv[1]["frac"])
-                    roof.update(bound=b, achieved=top["achieved"], peak=top["peak"], unit=top["unit"], frac=top["frac"])
-                except Exception as ex:      # a broken counters file must not invalidate the throughput line
-                    roof["counters_error"] = repr(ex)
-        out = {
-            "metric": "aligned reads/sec (-m 8 recombination, 1 kbp reads, 10k-row/32-path graph)" if args.config == "C5"
-            else "aligned reads/sec (%s)" % args.config,
-            "value": round(total_reads / dt, 2), "unit": "reads/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": args.scaling, "vs_baseline": None,
-            # arithmetic type of the DP cells: packed 16-bit integers when the batch's scores provably fit, else int32
-            "dtype": "int16" if use16 else "int32", "data": "synthetic" if not stub else "STUB: no device work (RG_BENCH_STUB=1)",
-            "config": {"workload": "BASELINE.json configs[%d] (%s): -m %d, %d bp reads, graph rows=%d paths=%d, "
-                                   "%d reads/step over all GPUs, %d distinct reads timed, reads uploaded inside every step"
-                       % (num - 1, args.config, mode, cfg["n"], eng.rows, eng.paths, reads_step_all,
-                          reads_step_all * min(args.steps, nb)),
-                       "parallelism": "read-shard x%d" % world},
-            "cell_updates_per_s": round(cells_all / dt, 1),
-            # HIP-event time per kernel and step.  With several device threads the steps overlap on the GPU: the figures of
-            # the timed region include the other streams' kernels (their sum exceeds the step), the probe figures are
-            # the kernels' own durations (their sum is the GPU time one step would take alone)
-            "kernel_ms_per_step": {k: round(v[0] / probe_steps, 3) for k, v in kroof.items()},
-            "kernel_ms_per_step_in_timed_region": {k: round(v[0] / args.steps, 3) for k, v in kstats.items()} if probe else None,
-            # host wall time per step: device thread = run + fetch, main thread = format + set_reads (canonicalise + upload
-            # of the batch two steps ahead) + wait_for_device; the two threads overlap
-            "host_ms_per_step": {k: round(v / args.steps * 1e3, 3) for k, v in eng.host_s.items()},
-            "gaf_bytes_gathered": gathered_bytes,
-            "roofline": roof,
-        }
-        cpu = None
-        if not args.no_cpu and not stub:
-            reads_last = batch_reads[last_set]
-            gpu_cores = cores if world == 1 else max(1, cores // world)
-            if world == 1 and args.cpu_reads != 0:
-                cpu, checked, bad = cpu_legs(args, mode, gfa, reads_last, lambda i, nm, idx: last_h.gaf_text(i, nm, idx).encode(), gpu_cores)
-            else:
-                # N > 1 (or --cpu-reads 0): parity gate only, on a small sample
-                from oracle import oracle as O
-                og = O.Graph.from_gfa_text(gfa)
-                omode = {0: O.M0_SIMD, 2: O.M2, 4: O.M4_ABS, 8: O.M8_ABS}[mode]
-                n = min(len(reads_last), max(8, min(64, gpu_cores * 2)))
-                _, _, ts = og.bench_text(omode, reads_last[:n], nthreads=min(gpu_cores, n))
-                checked, bad = n, []
-                for k, t in enumerate(ts):
-                    exp = last_h.gaf_text(k, "read%d" % k, 1 + k).encode()
-                    if t != exp and len(bad) < 5:
-                        bad.append({"read": k, "cpu": t[-120:].decode(errors="replace"), "gpu": exp[-120:].decode(errors="replace")})
-            out["parity_checked"] = checked
-            out["parity_ok"] = not bad
-            if bad:
-                out["parity_mismatches"] = bad
-                rc = 3
-        out["cpu_baseline"] = cpu
-        print(json.dumps(out), flush=True)
-    if dist_on:
+        cells_all, total_reads = float(ct[0].item()), int(ct[1].item())
+        # the ranks part here: rank 0's probe steps and CPU legs do not hold the other GPUs
         dist.barrier()
         dist.destroy_process_group()
+        if rank != 0:
+            main_stream.close()
+            sys.exit(0)
+    else:
+        cells_all, total_reads = float(cells_total), nreads_mine
+    gathered_bytes = gather.bytes
+    handles_used = main_stream.handles
+    main_stream.close()
+
+    # Per-kernel durations for the roofline: with several handles the kernels of concurrent tiles share the GPU, so a
+    # kernel's HIP-event time in the timed region includes the other streams' kernels.  Probe steps on a ONE-handle stream
+    # (after the timed region, same read sets) give the kernels' own durations.
+    probe, probe_steps = {}, 0
+    if not stub and not args.no_probe and args.handles > 1 and my_steps:
+        ps = HipStream(api, graph, params, dev, 1, batch, fmt_threads)
+        run_steps(ps, [warm_packed])
+        p0 = ps.kernel_stats()
+        probe_steps = min(2, len(my_steps))
+        run_steps(ps, [packed[i % nb] for i in my_steps[:probe_steps]])
+        p1 = ps.kernel_stats()
+        probe = {k: (v[0] - p0.get(k, (0, 0))[0], v[1] - p0.get(k, (0, 0))[1]) for k, v in p1.items()}
+        ps.close()
+
+    rc = 0
+    steps_here = max(1, len(my_steps))
+    kroof = probe if probe else kstats
+    ksteps = probe_steps if probe else steps_here
+    kern = {k: v for k, v in kroof.items() if not k.startswith("host:")}
+    sweeps = {k: v for k, v in kern.items() if k.startswith(("k_sweep", "k_m0", "k_m2"))}
+    roof = None
+    use16 = any(k.startswith("k_sweep16") for k in kstats)
+    if sweeps:
+        # dominant kernel family: the DP sweep.  One launch sweeps the whole graph once for one chunk of the batch.
+        ms = sum(v[0] for v in sweeps.values())
+        launches = sum(v[1] for v in sweeps.values())
+        counting = sum(v[1] for k, v in sweeps.items() if not k.endswith("_colmax")) or launches
+        reads_per_launch = batch * ksteps * (2 if mode == 8 else 1) / counting if mode in (4, 8) else batch * ksteps / counting
+        per_launch_units = cells_total / steps_here * ksteps / counting   # cell-updates one sweep launch processes (this rank)
+        avg_s = ms / launches / 1e3
+        algo = per_launch_units * BYTES_PER_CELL_UPDATE[mode] / avg_s / 1e9
+        kname = {0: "k_m0_simd", 2: "k_poa_banded<true>", 4: "k_sweep", 8: "k_sweep"}[mode] + ("16" if use16 else "")
+        roof = {"bound": None, "achieved": None, "peak": None, "unit": None, "frac": None, "traffic": None,
+                "kernel": kname, "avg_launch_ms": round(ms / launches, 3), "launches": launches,
+                "reads_per_launch": round(reads_per_launch, 1),
+                "durations_from": ("%d probe steps on a one-handle stream after the timed region (the timed steps run %d handles "
+                                   "concurrently: their HIP-event times include the other streams' kernels)" % (probe_steps, handles_used))
+                if probe else "the timed region (HIP events on the batch stream)",
+                # SURVEY §8d figure (the reference's own L x (n+1) x P matrices): NOT a fraction of anything this
+                # design moves — rows stay packed in registers / cache, so it exceeds the HBM peak by construction
+                "algorithmic_equiv_GBps": round(algo, 1),
+                "code_hash": code_hash()}        # of recgraph_amd/csrc: counters collected on another tree are flagged stale
+        cj = os.path.join(ROOT, "profiles", "counters_%s.json" % args.config)
+        vj = os.path.join(ROOT, "profiles", "valu_calib.json")
+        if os.path.exists(cj):
+            try:
+                c = json.load(open(cj))
+                roof["counters_from"] = c.get("source")
+                if c.get("kernel_base") != kname:
+                    roof["counters_stale"] = "profiled kernel %s, running %s" % (c.get("kernel_base"), kname)
+                elif c.get("code_hash") != roof["code_hash"]:
+                    roof["counters_stale"] = "kernel sources changed since the counters were collected (%s -> %s)" % (c.get("code_hash"), roof["code_hash"])
+                # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, calibrated units: see the file), per read
+                # per launch, scaled to this run's reads per launch; fabric-side bytes (Infinity-Cache hits included)
+                traffic = c["hbm_bytes_per_read_per_launch"] * reads_per_launch
+                hbm = {"achieved": round(traffic / avg_s / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                       "frac": round(traffic / avg_s / 1e9 / HBM_PEAK_GBS, 4)}
+                roof["traffic"] = round(traffic)
+                roof["hbm"] = hbm
+                cand = [("hbm", hbm)]
+                if os.path.exists(vj) and c.get("valu_winstr_per_read_per_launch"):
+                    vc = json.load(open(vj))
+                    peak = vc["peak_winstr_per_s"]
+                    rate = c["valu_winstr_per_read_per_launch"] * reads_per_launch / avg_s
+                    valu = {"achieved": round(rate / 1e9, 2), "peak": round(peak / 1e9, 2), "unit": "G wave-instr/s",
+                            "frac": round(rate / peak, 4), "winstr_per_read_per_launch": round(c["valu_winstr_per_read_per_launch"])}
+                    raw = vc.get("raw", {})
+                    if raw.get("compute_units") and raw.get("clock_mhz"):
+                        # the guide's nominal issue rate (one wave64 VALU instruction per SIMD every 2 cycles) beside the
+                        # calibrated peak of this kernel's instruction mix
+                        nominal = raw["compute_units"] * 4 * raw["clock_mhz"] * 1e6 / VALU_NOMINAL_CYCLES
+                        valu["peak_nominal"] = round(nominal / 1e9, 2)
+                        valu["frac_of_nominal"] = round(rate / nominal, 4)
+                    roof["valu"] = valu
+                    cand.append(("valu", valu))
+                b, top = max(cand, key=lambda kv: kv[1]["frac"])
+                roof.update(bound=b, achieved=top["achieved"], peak=top["peak"], unit=top["unit"], frac=top["frac"])
+            except Exception as ex:      # a broken counters file must not invalidate the throughput line
+                roof["counters_error"] = repr(ex)
+    out = {
+        "metric": "aligned reads/sec (-m 8 recombination, 1 kbp reads, 10k-row/32-path graph)" if args.config == "C5"
+        else "aligned reads/sec (%s)" % args.config,
+        "value": round(total_reads / dt, 2), "unit": "reads/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(dt / max(1, args.steps) * 1e3, 3), "higher_is_better": True,
+        "scaling": args.scaling, "vs_baseline": None,
+        # arithmetic type of the DP cells: packed 16-bit integers when the batch's scores provably fit, else int32
+        "dtype": "int16" if use16 else "int32", "data": "synthetic" if not stub else "STUB: no device work (RG_BENCH_STUB=1)",
+        "config": {"workload": "BASELINE.json configs[%d] (%s): -m %d, %d bp reads, graph rows=%d paths=%d, "
+                               "%d reads/step over all GPUs, %d distinct reads timed, reads uploaded inside every step; "
+                               "one rg_stream per GPU (%d handles), %d-read tiles"
+                   % (num - 1, args.config, mode, cfg["n"], rows, paths,
+                      batch * (world if args.scaling == "weak" else 1),
+                      batch * min(args.steps, nb) * (world if args.scaling == "weak" else 1), handles_used, batch),
+                   "parallelism": "read-shard x%d" % world},
+        "cell_updates_per_s": round(cells_all / dt, 1),
+        # HIP-event time per kernel and step.  With several handles the steps overlap on the GPU: the figures of the timed
+        # region include the other streams' kernels (their sum exceeds the step), the probe figures are the kernels' own
+        # durations (their sum is the GPU time one step would take alone)
+        "kernel_ms_per_step": {k: round(v[0] / max(1, ksteps), 3) for k, v in kern.items()},
+        "kernel_ms_per_step_in_timed_region": {k: round(v[0] / steps_here, 3) for k, v in kstats.items() if not k.startswith("host:")} if probe else None,
+        # host wall time per step, summed over the stream's worker threads (they overlap each other and the device):
+        # set_reads = canonicalise + upload, run = kernels (waiting for the device), fetch = records D2H, format = GAF text
+        "host_ms_per_step": {k[5:]: round(v[0] / steps_here, 3) for k, v in kstats.items() if k.startswith("host:")},
+        "gather_ms_per_step": round((gather.busy_s if dist_on else 0.0) / steps_here * 1e3, 3),
+        "gather_wait_ms": round(gather_wait * 1e3, 3),
+        "gaf_bytes_gathered": gathered_bytes,
+        "roofline": roof,
+    }
+    cpu = None
+    if pool is not None:
+        first, n_last, text_last, tile = last
+        reads_last = batch_reads[my_steps[-1] % nb]
+        gpu_text_of = lambda i: tile.text_of(i)
+        if world == 1 and args.cpu_reads != 0:
+            cpu, checked, bad = cpu_legs(args, mode, gfa, reads_last, first, gpu_text_of, cores, pool)
+        else:
+            # N > 1 (or --cpu-reads 0): parity gate only, on a small sample
+            omode = {0: "M0_SIMD", 2: "M2", 4: "M4_ABS", 8: "M8_ABS"}[mode]
+            nw = len(pool.workers)
+            pool.call(range(nw), ("load", gfa, omode))
+            per = max(1, min(8, len(reads_last) // nw))
+            pool.scatter(list(range(nw)), [("reads", reads_last[k * per:(k + 1) * per], first + k * per, 1 + first + k * per) for k in range(nw)])
+            res = pool.call(list(range(nw)), ("go",))
+            checked, bad = 0, []
+            for k, (_, texts, _) in enumerate(res):
+                for j, t in enumerate(texts):
+                    exp = gpu_text_of(k * per + j)
+                    checked += 1
+                    if t != exp and len(bad) < 5:
+                        bad.append({"read": k * per + j, "cpu": t[-120:].decode(errors="replace"), "gpu": exp[-120:].decode(errors="replace")})
+        pool.close()
+        out["parity_checked"] = checked
+        out["parity_ok"] = not bad
+        if bad:
+            out["parity_mismatches"] = bad
+            rc = 3
+    if cpu is not None:
+        cpu["build"] = oracle_build
+    out["cpu_baseline"] = cpu
+    print(json.dumps(out), flush=True)
     sys.exit(rc)
 
 

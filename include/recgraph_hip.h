@@ -178,12 +178,13 @@ int32_t rg_align_batch(const rg_graph* g, const rg_params* p, const char* reads,
 
 /*
  * The same read loop over several GPUs behind ONE call (the reference loop main.rs:56,174,257,297 has no order
- * dependence between reads): the reads are cut into contiguous shards, one per entry of device_ids (NULL: every visible
- * device), each shard runs create + run + fetch on its device from its own host thread and stream; the graph tables are
- * uploaded once per device; nothing is exchanged between devices.  Shard k holds reads [begin_k, begin_{k+1}) and is an
- * ordinary rg_batch, owned by the rg_multi, for the rg_result_* accessors; rg_multi_format_all concatenates the text of
- * all shards in input order (names[i], seq_index_base + i index the whole read set).  With names == NULL the default
- * name of read i is "read<j>", j = its index inside its shard (as rg_batch_format_all): pass names for global numbering.
+ * dependence between reads): the reads go through the streaming engine below (tiles pulled from one queue by the
+ * batch handles of every device in device_ids, NULL: every visible device; the graph tables are uploaded once per
+ * device; nothing is exchanged between devices) and the call returns when the last tile is done.  Shard k is one tile:
+ * it holds reads [begin_k, begin_{k+1}) as a results-only rg_batch, owned by the rg_multi, for the rg_result_* accessors
+ * (rg_batch_run / rg_batch_set_reads refuse it); rg_multi_format_all concatenates the text of all shards in input
+ * order (names[i], seq_index_base + i index the whole read set).  With names == NULL the default name of read i is
+ * "read<j>", j = its index inside its shard (as rg_batch_format_all): pass names for global numbering.
  */
 typedef struct rg_multi rg_multi;
 int32_t rg_align_batch_multi(const rg_graph* g, const rg_params* p, const char* reads, const int64_t* read_off,
@@ -194,6 +195,95 @@ int64_t rg_multi_shard_begin(const rg_multi* m, int32_t k);      /* k == shards:
 int64_t rg_multi_format_all(const rg_multi* m, const char* const* names, int64_t seq_index_base, char* buf, int64_t cap,
                             int32_t nthreads);
 void rg_multi_destroy(rg_multi* m);
+
+/*
+ * FASTA ingestion.  Replaces sequences::get_sequences (sequences.rs:5-45) with the same rules: a line that starts with
+ * '>' names a read (everything after the '>') and closes the read before it when that one has bases; every other
+ * non-empty line is appended to the current read, upper-cased, '-' -> 'N'; lines end at '\n' with one '\r' before it
+ * dropped (BufRead::lines); the reads are paired with the names BY INDEX, and a file whose counts differ is refused
+ * (RG_ERR_ARG, "wrong fasta file format": the reference panics, :41-43).  The '$' the reference puts in front of
+ * every read is added inside the library.  bases / offsets / names are the input form of rg_batch_create,
+ * rg_stream_push and rg_align_batch_multi and stay valid until rg_reads_destroy.
+ */
+typedef struct rg_reads rg_reads;
+int32_t rg_reads_from_fasta(const char* fasta_text, int64_t len, rg_reads** out);
+int64_t rg_reads_count(const rg_reads* r);
+const char* rg_reads_bases(const rg_reads* r);            /* concatenated bases of all reads */
+const int64_t* rg_reads_offsets(const rg_reads* r);       /* count + 1 offsets into bases */
+const char* const* rg_reads_names(const rg_reads* r);     /* count NUL-terminated names */
+void rg_reads_destroy(rg_reads* r);
+
+/*
+ * Streaming engine: the reference's read loop (main.rs:56,174,257,297-312) as a pipeline hidden behind the boundary.
+ * Reads pushed into a stream are cut into tiles; per device `handles_per_device` batch handles (each with its own HIP
+ * stream, HBM work buffers and host thread) pull tiles from ONE queue shared by all devices of the stream (a tile goes
+ * to whichever handle is free first: load balance across devices without a static split), upload, align, fetch and
+ * format them; the latency-bound small kernels of one tile run beside the sweeps of the others and the host work
+ * (canonicalisation, upload, record fetch, GAF formatting on `format_threads` threads) overlaps the device work of
+ * the other handles.  Results come back in input order, one tile per rg_stream_next call, as exactly the bytes the
+ * reference prints on stdout for those reads.  Nothing is exchanged between devices.
+ *
+ *   rg_stream_create   starts the worker threads (the device buffers are allocated by the first tiles)
+ *   rg_stream_push     copies the reads (and names) and queues their tiles; returns at once; any thread, any time
+ *                      before rg_stream_finish.  names == NULL: read i of the stream is called "read<i>"
+ *   rg_stream_finish   no more pushes: rg_stream_next returns RG_STREAM_END after the last tile
+ *   rg_stream_next     blocks until the next tile (in input order) is done.  A tile whose device work failed returns
+ *                      that error (rg_last_error has the text) and the stream moves on to the next tile
+ *
+ * seq_index of read i is seq_index_base + i (main.rs passes i + 1 in modes 0-3 and i in modes 4, 5, 8, 9; 0 means
+ * "score only", global_abpoa.rs:241).  One thread at a time may call rg_stream_next on a stream.
+ */
+typedef struct rg_stream rg_stream;
+typedef struct rg_stream_opts {
+    int32_t handles_per_device;   /* 0: default (3)                                                            */
+    int32_t tile_reads;           /* 0: default (4096 in the pathwise modes, 8192 in the POA modes)            */
+    int32_t format_threads;       /* host threads that format one tile; 0: default (hardware threads / workers, 1..16) */
+    int32_t keep_records;         /* 1: every tile also keeps its records (rg_stream_result.records)           */
+    int64_t seq_index_base;       /* seq_index of the first read pushed                                        */
+    int32_t no_text;              /* 1: skip the GAF text (records only)                                       */
+    int32_t reserved;
+} rg_stream_opts;
+typedef struct rg_stream_result {
+    int64_t first_read;           /* index (push order) of the tile's first read                               */
+    int64_t nreads;
+    const char* text;             /* GAF text of the tile's reads in input order, NUL-terminated               */
+    int64_t text_len;
+    const int64_t* text_off;      /* nreads + 1: the text of read i is text[text_off[i] .. text_off[i + 1])      */
+    const uint32_t* status;       /* nreads: RG_READ_* bits                                                    */
+    const int32_t* score;         /* nreads: rg_result_score                                                   */
+    int32_t device;               /* HIP device that aligned the tile                                          */
+    int32_t reserved;
+    uint64_t cell_updates;        /* DP cell updates of the tile (SURVEY 8d unit of work)                       */
+    rg_batch* records;            /* keep_records: results-only handle for the rg_result_* accessors, owned by the
+                                     stream (valid until rg_stream_destroy), else NULL                         */
+} rg_stream_result;
+#define RG_STREAM_END 1
+void rg_stream_opts_default(rg_stream_opts* o);
+int32_t rg_stream_create(const rg_graph* g, const rg_params* p, const int32_t* device_ids, int32_t ndev,
+                         const rg_stream_opts* opts, rg_stream** out);
+int32_t rg_stream_push(rg_stream* s, const char* reads, const int64_t* read_off, int64_t nreads, const char* const* names);
+int32_t rg_stream_finish(rg_stream* s);
+/* RG_OK: *out describes the next tile (pointers valid until the next rg_stream_next / rg_stream_destroy on this stream);
+ * RG_STREAM_END: finished and everything delivered; negative: that tile failed. */
+int32_t rg_stream_next(rg_stream* s, rg_stream_result* out);
+void rg_stream_destroy(rg_stream* s);
+/* Measurement hooks (bench.py): per-kernel device time summed over every tile so far (HIP events on the handles' own
+ * streams; with several handles per device a kernel's time includes the other streams' kernels), the host phases
+ * ("host:set_reads", "host:run", "host:fetch", "host:format": wall seconds summed over the worker threads) listed
+ * after the kernels, tiles done, handles running per device. */
+int32_t rg_stream_kernel_count(rg_stream* s);
+const char* rg_stream_kernel_name(rg_stream* s, int32_t k);
+double rg_stream_kernel_ms(rg_stream* s, int32_t k);
+int64_t rg_stream_kernel_launches(rg_stream* s, int32_t k);
+int64_t rg_stream_tiles_done(rg_stream* s);
+int32_t rg_stream_handles(rg_stream* s);      /* batch handles that aligned at least one tile */
+
+/* Process-wide diagnostic switches, also settable through the environment (read once when the library is loaded):
+ * "sweep_i32" (RG_SWEEP_I32: i32 sweep kernel even when the packed 16-bit one is admissible), "three_sweeps"
+ * (RG_THREE_SWEEPS), "no_frec" (RG_NO_FREC: Cand-list forward emission), "debug" (RG_DEBUG: list statistics on stderr).
+ * The variants compute the same records byte for byte (tests/test_gpu_pathwise.py). */
+int32_t rg_set_option(const char* name, int64_t value);
+int64_t rg_get_option(const char* name);      /* -1: unknown option */
 
 const char* rg_last_error(void);
 int32_t rg_device_count(void);

@@ -25,13 +25,46 @@ def build(force=False):
 
 
 _lib = None
+_native = None        # (path, description) once use_native() succeeded
+
+
+def use_native():
+    """Timing build for bench.py's cpu_baseline legs: the same sources compiled ``-O3 -march=native`` ON THE MACHINE THAT
+    RUNS THEM (oracle/_native/liboracle-<cpu tag>.so; the portable liboracle.so travels between machines, native code
+    must not).  Call before the first ``lib()``.  Returns a description, or None when the build failed (the portable
+    library is used then)."""
+    global _native
+    import hashlib
+    try:
+        info = open("/proc/cpuinfo").read()
+        model = [ln for ln in info.splitlines() if ln.startswith("model name")][:1]
+        flags = [ln for ln in info.splitlines() if ln.startswith("flags")][:1]
+        tag = hashlib.sha256(("".join(model) + "".join(flags)).encode()).hexdigest()[:12]
+    except OSError:
+        return None
+    d = os.path.join(_HERE, "_native")
+    so = os.path.join(d, "liboracle-%s.so" % tag)
+    srcs = sorted(os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith(".cpp"))
+    hdrs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith(".hpp")]
+    flagsv = ["-O3", "-march=native", "-std=c++17", "-fPIC", "-Wno-sign-compare", "-ffp-contract=off", "-pthread"]
+    try:
+        if not os.path.exists(so) or any(os.path.getmtime(x) > os.path.getmtime(so) for x in srcs + hdrs):
+            os.makedirs(d, exist_ok=True)
+            tmp = so + ".%d.tmp" % os.getpid()
+            subprocess.check_call(["g++"] + flagsv + ["-shared", "-o", tmp] + srcs, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            os.replace(tmp, so)
+    except (OSError, subprocess.CalledProcessError):
+        return None
+    _native = (so, "g++ " + " ".join(flagsv[:2]) + " on " + ("".join(model).split(":")[-1].strip() or "this host"))
+    return _native[1]
 
 
 def lib():
     global _lib
     if _lib is None:
-        build()
-        l = C.CDLL(_LIB)
+        if _native is None:
+            build()
+        l = C.CDLL(_native[0] if _native else _LIB)
         l.orc_graph_new.restype = C.c_void_p
         l.orc_graph_new.argtypes = [C.c_char_p, C.c_int]
         l.orc_lnz_literal.restype = C.c_void_p
@@ -56,7 +89,7 @@ def lib():
         l.orc_bench_text.restype = C.c_double
         l.orc_bench_text.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.POINTER(C.c_longlong), C.c_longlong,
                                      C.POINTER(C.c_int), C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_float,
-                                     C.c_float, C.c_int, C.c_char_p, C.c_longlong, C.c_char_p, C.c_longlong,
+                                     C.c_float, C.c_int, C.c_char_p, C.c_longlong, C.c_longlong, C.c_char_p, C.c_longlong,
                                      C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(C.c_ulonglong)]
         l.orc_bench_faithful.restype = C.c_double
         l.orc_bench_faithful.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_longlong), C.c_longlong, C.POINTER(C.c_int),
@@ -227,9 +260,10 @@ class Graph:
         return secs, cells.value, chk.value
 
     def bench_text(self, mode, reads, scores=None, o=-4, e=-2, b=1.0, f=0.01, R=4, r=0.1, B=1.0, nthreads=1,
-                   name_prefix="read", idx_base=1):
+                   name_prefix="read", idx_base=1, name_base=0):
         """Like ``bench`` but returns (seconds, cells, [stdout text per read]); read i is named
-        ``name_prefix + str(i)`` with seq index ``idx_base + i`` (what ``rg_batch_format_all`` uses by default)."""
+        ``name_prefix + str(name_base + i)`` with seq index ``idx_base + i`` (what ``rg_batch_format_all`` uses by default;
+        a stream names its reads by their position in the whole stream)."""
         if scores is None:
             scores = scores_match_mis(2, -4)
         blob = "".join(reads).encode()
@@ -244,7 +278,7 @@ class Graph:
         buf = C.create_string_buffer(cap)
         toff = (C.c_longlong * (len(reads) + 1))()
         secs = lib().orc_bench_text(self.h, mode, blob, offa, len(reads), sc, o, e, b, f, R, r, B, nthreads,
-                                    name_prefix.encode(), idx_base, buf, cap, toff, C.byref(need), C.byref(cells))
+                                    name_prefix.encode(), name_base, idx_base, buf, cap, toff, C.byref(need), C.byref(cells))
         if need.value > cap:
             raise RuntimeError("orc_bench_text: output larger than the buffer (%d > %d)" % (need.value, cap))
         raw = buf.raw

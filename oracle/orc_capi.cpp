@@ -247,8 +247,8 @@ double orc_bench(void* h, int mode, const char* reads_concat, const long long* o
 // Returns wall seconds; *need = bytes required (nothing is written past `cap`).
 double orc_bench_text(void* h, int mode, const char* reads_concat, const long long* offsets, long long nreads,
                       const int* scores36, int o, int e, float b, float f, int brc, float mrc, float rbw, int nthreads,
-                      const char* name_prefix, long long idx_base, char* text_out, long long cap, long long* text_off,
-                      long long* need, unsigned long long* cells_out) {
+                      const char* name_prefix, long long name_base, long long idx_base, char* text_out, long long cap,
+                      long long* text_off, long long* need, unsigned long long* cells_out) {
     tune_malloc_once();
     auto* g = (OrcGraph*)h;
     Scores sc0 = scores_from(scores36);
@@ -266,7 +266,7 @@ double orc_bench_text(void* h, int mode, const char* reads_concat, const long lo
                 rd += (*p == '-') ? 'N' : (char)std::toupper(*p);
             size_t bta = (size_t)(b + f * (float)rd.size());  // main.rs:57
             uint64_t c = 0;
-            Result res = run_one(g, mode, rd, std::string(name_prefix) + std::to_string(r), (size_t)(idx_base + r), sc, o, e, bta,
+            Result res = run_one(g, mode, rd, std::string(name_prefix) + std::to_string(name_base + r), (size_t)(idx_base + r), sc, o, e, bta,
                                  brc, mrc, rbw, &c);
             cells += c;
             outs[(size_t)r] = res.would_panic ? std::string("<would panic>\n") : res.out;

@@ -20,6 +20,17 @@ class GafFields(C.Structure):
                 ("residue_matches_number", C.c_uint64), ("n_path_ids", C.c_int64), ("comments_len", C.c_int64)]
 
 
+class StreamOpts(C.Structure):
+    _fields_ = [("handles_per_device", C.c_int32), ("tile_reads", C.c_int32), ("format_threads", C.c_int32),
+                ("keep_records", C.c_int32), ("seq_index_base", C.c_int64), ("no_text", C.c_int32), ("reserved", C.c_int32)]
+
+
+class StreamResult(C.Structure):
+    _fields_ = [("first_read", C.c_int64), ("nreads", C.c_int64), ("text", C.c_void_p), ("text_len", C.c_int64),
+                ("text_off", C.POINTER(C.c_int64)), ("status", C.POINTER(C.c_uint32)), ("score", C.POINTER(C.c_int32)),
+                ("device", C.c_int32), ("reserved", C.c_int32), ("cell_updates", C.c_uint64), ("records", C.c_void_p)]
+
+
 class Params(C.Structure):
     _fields_ = [("mode", C.c_int32), ("scores", C.c_int32 * 36), ("gap_open", C.c_int32), ("gap_ext", C.c_int32),
                 ("band_b", C.c_float), ("band_f", C.c_float), ("bta_override", C.c_int64),
@@ -47,7 +58,11 @@ SYMBOLS = ["rg_params_default", "rg_scores_match_mis", "rg_graph_from_gfa", "rg_
            "rg_result_status", "rg_result_score", "rg_result_gaf", "rg_result_fields", "rg_batch_format_all", "rg_batch_cell_updates", "rg_batch_kernel_count",
            "rg_batch_kernel_name", "rg_batch_kernel_ms", "rg_batch_kernel_launches", "rg_align_batch", "rg_align_batch_multi", "rg_multi_shards", "rg_multi_batch", "rg_multi_shard_begin",
            "rg_multi_format_all", "rg_multi_destroy", "rg_last_error",
-           "rg_device_count", "rg_set_device"]
+           "rg_device_count", "rg_set_device",
+           "rg_reads_from_fasta", "rg_reads_count", "rg_reads_bases", "rg_reads_offsets", "rg_reads_names", "rg_reads_destroy",
+           "rg_stream_opts_default", "rg_stream_create", "rg_stream_push", "rg_stream_finish", "rg_stream_next",
+           "rg_stream_destroy", "rg_stream_kernel_count", "rg_stream_kernel_name", "rg_stream_kernel_ms",
+           "rg_stream_kernel_launches", "rg_stream_tiles_done", "rg_stream_handles", "rg_set_option", "rg_get_option"]
 
 _lib = None
 
@@ -112,6 +127,35 @@ def load():
     l.rg_batch_kernel_launches.restype = i64
     l.rg_last_error.restype = C.c_char_p
     l.rg_set_device.argtypes = [i32]
+    l.rg_reads_from_fasta.argtypes = [C.c_char_p, i64, P(vp)]
+    l.rg_reads_count.argtypes = [vp]
+    l.rg_reads_count.restype = i64
+    l.rg_reads_bases.argtypes = [vp]
+    l.rg_reads_bases.restype = vp
+    l.rg_reads_offsets.argtypes = [vp]
+    l.rg_reads_offsets.restype = P(i64)
+    l.rg_reads_names.argtypes = [vp]
+    l.rg_reads_names.restype = P(C.c_char_p)
+    l.rg_reads_destroy.argtypes = [vp]
+    l.rg_stream_opts_default.argtypes = [P(StreamOpts)]
+    l.rg_stream_create.argtypes = [vp, P(Params), P(i32), i32, P(StreamOpts), P(vp)]
+    l.rg_stream_push.argtypes = [vp, vp, P(i64), i64, P(C.c_char_p)]
+    l.rg_stream_finish.argtypes = [vp]
+    l.rg_stream_next.argtypes = [vp, P(StreamResult)]
+    l.rg_stream_destroy.argtypes = [vp]
+    l.rg_stream_kernel_count.argtypes = [vp]
+    l.rg_stream_kernel_name.argtypes = [vp, i32]
+    l.rg_stream_kernel_name.restype = C.c_char_p
+    l.rg_stream_kernel_ms.argtypes = [vp, i32]
+    l.rg_stream_kernel_ms.restype = C.c_double
+    l.rg_stream_kernel_launches.argtypes = [vp, i32]
+    l.rg_stream_kernel_launches.restype = i64
+    l.rg_stream_tiles_done.argtypes = [vp]
+    l.rg_stream_tiles_done.restype = i64
+    l.rg_stream_handles.argtypes = [vp]
+    l.rg_set_option.argtypes = [C.c_char_p, i64]
+    l.rg_get_option.argtypes = [C.c_char_p]
+    l.rg_get_option.restype = i64
     _lib = l
     return l
 

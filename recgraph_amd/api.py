@@ -355,8 +355,8 @@ class _ShardView(Batch):
 
 
 class MultiBatch:
-    """rg_align_batch_multi: the read loop over several GPUs behind one call (contiguous read shards, one host thread
-    and one stream per device, results in input order)."""
+    """rg_align_batch_multi: the read loop over several GPUs behind one call (the streaming engine inside: tiles of
+    reads pulled by the batch handles of every device, one results-only shard per tile, results in input order)."""
 
     def __init__(self, graph, reads, params, device_ids=None):
         lib = _lib.load()
@@ -397,6 +397,161 @@ class MultiBatch:
             if need + 1 <= cap:
                 return buf.raw[:need]
             cap = need + 4096
+
+
+class Reads:
+    """sequences::get_sequences (sequences.rs:5-45) behind the C ABI (rg_reads_from_fasta): the bases of all reads in one
+    blob + offsets + names, in the input form of ``Batch`` / ``Stream.push`` (no per-character Python)."""
+
+    def __init__(self, handle):
+        lib = _lib.load()
+        self._h = handle
+        self.n = lib.rg_reads_count(handle)
+        self._bases = lib.rg_reads_bases(handle)
+        self._off = lib.rg_reads_offsets(handle)
+        self._names = lib.rg_reads_names(handle)
+
+    @classmethod
+    def from_fasta_text(cls, text):
+        b = text if isinstance(text, bytes) else text.encode()
+        h = C.c_void_p()
+        check(_lib.load().rg_reads_from_fasta(b, len(b), C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def from_fasta(cls, path):
+        with open(path, "rb") as f:
+            return cls.from_fasta_text(f.read())
+
+    def __del__(self):
+        try:
+            _lib.load().rg_reads_destroy(self._h)
+        except Exception:
+            pass
+
+    def __len__(self):
+        return self.n
+
+    @property
+    def offsets(self):
+        return np.ctypeslib.as_array(self._off, shape=(self.n + 1,))
+
+    @property
+    def names(self):
+        return [self._names[i].decode() for i in range(self.n)]
+
+    def sequences(self):
+        """The reads as strings (tests / the ``-s true`` path)."""
+        off = self.offsets
+        blob = C.string_at(self._bases, int(off[-1]))
+        return [blob[off[i]:off[i + 1]].decode() for i in range(self.n)]
+
+
+class StreamTile:
+    """One rg_stream_result, copied out of the library's buffers."""
+    __slots__ = ("first", "n", "text", "text_off", "status", "score", "device", "cell_updates", "records")
+
+    def text_of(self, i):
+        return self.text[self.text_off[i]:self.text_off[i + 1]]
+
+
+class Stream:
+    """rg_stream: the reference's read loop (main.rs:56,174,257,297-312) as the pipeline hidden behind the C ABI: tiles of
+    reads pulled by ``handles_per_device`` batch handles per device from one queue, results in input order."""
+
+    def __init__(self, graph, params, device_ids=None, handles_per_device=0, tile_reads=0, format_threads=0,
+                 seq_index_base=1, keep_records=False, no_text=False):
+        lib = _lib.load()
+        self.graph = graph
+        o = _lib.StreamOpts()
+        lib.rg_stream_opts_default(C.byref(o))
+        o.handles_per_device, o.tile_reads, o.format_threads = handles_per_device, tile_reads, format_threads
+        o.seq_index_base, o.keep_records, o.no_text = seq_index_base, int(keep_records), int(no_text)
+        devs = (C.c_int32 * len(device_ids))(*device_ids) if device_ids is not None else None
+        self._h = C.c_void_p()
+        check(lib.rg_stream_create(graph._h, C.byref(params), devs, len(device_ids) if device_ids is not None else 0,
+                                   C.byref(o), C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            _lib.load().rg_stream_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def push(self, reads, names=None):
+        """``reads``: list of strings, a packed ``(bytes, int64 offsets)`` pair (``Batch.pack_reads``) or a ``Reads``
+        (its names are used).  The library copies everything before the call returns."""
+        lib = _lib.load()
+        if isinstance(reads, Reads):
+            check(lib.rg_stream_push(self._h, reads._bases, reads._off, reads.n, reads._names))
+            return reads.n
+        blob, offs = reads if isinstance(reads, tuple) else Batch.pack_reads(reads)
+        n = len(offs) - 1
+        arr = (C.c_char_p * n)(*[x.encode() for x in names]) if names is not None else None
+        check(lib.rg_stream_push(self._h, blob, offs.ctypes.data_as(C.POINTER(C.c_int64)), n, arr))
+        return n
+
+    def finish(self):
+        check(_lib.load().rg_stream_finish(self._h))
+
+    def next(self, copy_text=True):
+        """The next tile in input order (blocks), or None after ``finish`` when everything was delivered."""
+        lib = _lib.load()
+        r = _lib.StreamResult()
+        rc = lib.rg_stream_next(self._h, C.byref(r))
+        if rc == 1:
+            return None
+        check(rc)
+        t = StreamTile()
+        t.first, t.n, t.device, t.cell_updates, t.records = r.first_read, r.nreads, r.device, r.cell_updates, r.records
+        t.text = C.string_at(r.text, r.text_len) if copy_text else (r.text, r.text_len)
+        t.text_off = np.ctypeslib.as_array(r.text_off, shape=(r.nreads + 1,)).copy()
+        t.status = np.ctypeslib.as_array(r.status, shape=(r.nreads,)).copy()
+        t.score = np.ctypeslib.as_array(r.score, shape=(r.nreads,)).copy()
+        return t
+
+    def __iter__(self):
+        while True:
+            t = self.next()
+            if t is None:
+                return
+            yield t
+
+    def kernel_stats(self):
+        """{name: (ms summed over the tiles so far, launches)}; the host phases are listed as ``host:*``."""
+        lib = _lib.load()
+        return {lib.rg_stream_kernel_name(self._h, k).decode(): (lib.rg_stream_kernel_ms(self._h, k), lib.rg_stream_kernel_launches(self._h, k))
+                for k in range(lib.rg_stream_kernel_count(self._h))}
+
+    @property
+    def handles(self):
+        return _lib.load().rg_stream_handles(self._h)
+
+
+def set_option(name, value):
+    """rg_set_option: process-wide diagnostic switches ("sweep_i32", "three_sweeps", "no_frec", "debug")."""
+    check(_lib.load().rg_set_option(name.encode(), int(value)))
+
+
+def align_stream(graph, reads, names=None, mode=MODE_GLOBAL_POA, seq_index_base=1, device_ids=None, handles_per_device=0,
+                 tile_reads=0, **kw):
+    """``align_batch`` through the streaming engine (every visible GPU unless ``device_ids`` says otherwise): returns the
+    per-read texts and status bits in input order.  No ``-s`` retry."""
+    st = Stream(graph, make_params(mode, **kw), device_ids=device_ids, handles_per_device=handles_per_device,
+                tile_reads=tile_reads, seq_index_base=seq_index_base)
+    st.push(reads, names)
+    st.finish()
+    texts, status = [], []
+    for t in st:
+        texts += [t.text_of(i).decode() for i in range(t.n)]
+        status += [int(x) for x in t.status]
+    st.close()
+    return texts, status
 
 
 _COMPLEMENT = {"A": "T", "C": "G", "G": "C", "T": "A", "N": "N"}
@@ -455,8 +610,8 @@ def align_batch(graph, reads, names=None, mode=MODE_GLOBAL_POA, seq_index_base=1
 
 
 def align_batch_multi(graph, reads, names=None, mode=MODE_GLOBAL_POA, seq_index_base=1, device_ids=None, **kw):
-    """``align_batch`` over several GPUs behind one C call (``rg_align_batch_multi``: contiguous read shards, one host
-    thread and stream per device; ``device_ids`` None = every visible device).  Same return value; no ``-s`` retry."""
+    """``align_batch`` over several GPUs behind one C call (``rg_align_batch_multi``: the streaming engine, one
+    results-only shard per tile; ``device_ids`` None = every visible device).  Same return value; no ``-s`` retry."""
     n = len(reads)
     names = names or ["read%d" % i for i in range(n)]
     m = MultiBatch(graph, reads, make_params(mode, **kw), device_ids=device_ids)

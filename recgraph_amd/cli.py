@@ -10,24 +10,13 @@ import time
 
 
 def get_sequences(path):
-    """sequences::get_sequences (sequences.rs:5-45): names = header minus '>', bases upper-cased, '-' -> 'N'
-    (the '$' prefix is added inside the library)."""
-    seqs, names, cur = [], [], []
-    with open(path) as f:
-        for line in f:
-            line = line.rstrip("\n").rstrip("\r")
-            if line.startswith(">"):
-                names.append(line[1:])
-                if cur:
-                    seqs.append("".join(cur))
-                cur = []
-            elif line:
-                cur.append("".join("N" if c == "-" else c.upper() for c in line))
-    if cur:
-        seqs.append("".join(cur))
-    if len(seqs) != len(names):
-        raise SystemExit("wrong fasta file format")      # sequences.rs:41-43
-    return seqs, names
+    """sequences::get_sequences (sequences.rs:5-45) through the library (rg_reads_from_fasta): (sequences, names)."""
+    from . import api
+    try:
+        r = api.Reads.from_fasta(path)
+    except api._lib.RecGraphError as ex:
+        raise SystemExit(str(ex).split(": ", 1)[-1])     # "wrong fasta file format" (sequences.rs:41-43)
+    return r.sequences(), r.names
 
 
 def write_gaf_records(out_file, records, numbers):
@@ -68,6 +57,9 @@ def build_parser():
     p.add_argument("-b", "--extra-b", type=int, default=1)
     p.add_argument("-f", "--extra-f", type=float, default=0.01)
     p.add_argument("--scalar", action="store_true", help="-m 0 / -m 1 with the non-AVX2 path of the reference")
+    p.add_argument("--devices", default="", help="comma-separated HIP device ids (default: every visible device)")
+    p.add_argument("--handles", type=int, default=0, help="batch handles per device (default 3)")
+    p.add_argument("--tile", type=int, default=0, help="reads per tile (default 4096 pathwise / 8192 POA)")
     return p
 
 
@@ -82,34 +74,63 @@ def main(argv=None):
         scores = api.create_score_matrix_i32(a.match_score, -a.mismatch_score)   # args_parser.rs:155
     else:
         scores = api.create_score_matrix_i32(matrix_file_path=a.matrix if a.matrix.endswith(".mtx") else a.matrix + ".mtx")
-    seqs, names = get_sequences(a.sequence_path)
+    try:
+        reads = api.Reads.from_fasta(a.sequence_path)        # sequences.rs:5-45 inside the library
+    except api._lib.RecGraphError as ex:
+        raise SystemExit(str(ex).split(": ", 1)[-1])
     g = api.Graph.from_gfa(a.graph_path)
     mode = {0: api.MODE_GLOBAL_POA_SCALAR if a.scalar else api.MODE_GLOBAL_POA, 2: api.MODE_GAP_POA,
             1: api.MODE_LOCAL_POA_SCALAR if a.scalar else api.MODE_LOCAL_POA, 3: api.MODE_GAP_LOCAL_POA,
             4: api.MODE_PATHWISE, 5: api.MODE_PATHWISE_SEMI, 8: api.MODE_RECOMBINATION,
             9: api.MODE_RECOMBINATION_SEMI}[a.alignment_mode]
-    kw = dict(mode=mode, score_matrix=scores, o=-a.gap_open, e=-a.gap_extension, b=float(a.extra_b), f=a.extra_f,
+    kw = dict(score_matrix=scores, o=-a.gap_open, e=-a.gap_extension, b=float(a.extra_b), f=a.extra_f,
               R=a.base_rec_cost, r=a.multi_rec_cost, B=a.rec_band_width)
-    if amb:
-        texts, status = api.align_batch(g, seqs, names, amb_strand=True, **kw)
-    else:
-        # the reference's read loop has no order dependence: every visible GPU takes a contiguous shard of the reads
-        texts, status = api.align_batch_multi(g, seqs, names, device_ids=None, **kw)
-    for i, st in enumerate(status):
-        if st & (api.READ_WOULD_PANIC | api.READ_BAD_BASE):
-            raise SystemExit("read %d (%s): the reference panics on this input" % (i, names[i]))
-    if a.out_file == "standard output":
-        sys.stdout.write("".join(texts))
-    else:
+    to_file = a.out_file != "standard output"
+    records, numbers = [], []
+
+    def emit(first, texts):
+        """texts: the stdout text of consecutive reads starting at read `first`."""
+        if not to_file:
+            sys.stdout.write("".join(texts))
+            return
         # warning lines are println!'d by the exec functions whatever -o says; only the record goes through write_gaf
-        records, numbers = [], []
-        for i, t in enumerate(texts):
+        for k, t in enumerate(texts):
             lines = t.split("\n")[:-1]
             sys.stdout.write("".join(ln + "\n" for ln in lines[:-1]))
             records.append(lines[-1])
             # main.rs passes i + 1 in modes 0-3 (:98-103, :161-166, :206-211, :246-251) and the 0-based i in modes
             # 4, 5, 8, 9 (:260, :268, :311)
-            numbers.append(i + 1 if a.alignment_mode in (0, 1, 2, 3) else i)
+            numbers.append(first + k + 1 if a.alignment_mode in (0, 1, 2, 3) else first + k)
+
+    def panics(first, status, names):
+        bad = [i for i, st in enumerate(status) if st & (api.READ_WOULD_PANIC | api.READ_BAD_BASE)]
+        if bad:
+            raise SystemExit("read %d (%s): the reference panics on this input" % (first + bad[0], names[first + bad[0]]))
+
+    if amb:
+        names = reads.names
+        texts, status = api.align_batch(g, reads.sequences(), names, mode=mode, amb_strand=True, **kw)
+        panics(0, status, names)
+        emit(0, texts)
+    else:
+        # the reference's read loop (main.rs:56,174,257,297) has no order dependence: the streaming engine cuts the reads
+        # into tiles that the batch handles of every visible GPU (or --devices) pull from one queue; text in input order
+        devs = [int(x) for x in a.devices.split(",")] if a.devices else None
+        st = api.Stream(g, api.make_params(mode, **kw), device_ids=devs, handles_per_device=a.handles, tile_reads=a.tile)
+        st.push(reads)
+        st.finish()
+        names = None
+        for t in st:
+            if (t.status & (api.READ_WOULD_PANIC | api.READ_BAD_BASE)).any():
+                names = names or reads.names
+                panics(t.first, [int(x) for x in t.status], names)
+            if to_file:
+                emit(t.first, [t.text_of(i).decode() for i in range(t.n)])
+            else:
+                sys.stdout.buffer.write(t.text)
+        st.close()
+    sys.stdout.flush()
+    if to_file:
         write_gaf_records(a.out_file, records, numbers)
     sys.stderr.write("Done in %d.\n" % int(time.time() - t0))    # main.rs:319-323
 

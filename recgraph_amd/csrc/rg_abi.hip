@@ -12,208 +12,30 @@
 #include <mutex>
 #include <thread>
 
-#include "rg_host.hpp"
-#include "rg_path_args.hpp"
-#include "rg_poa_args.hpp"
+#include <cstdlib>
 
-using namespace rg;
+#include "rg_batch_impl.hpp"
 
-#define HIPCHK(x)                                                                                       \
-    do {                                                                                                \
-        hipError_t e_ = (x);                                                                            \
-        if (e_ != hipSuccess) {                                                                         \
-            (void)hipGetLastError(); /* clears the sticky error: the handle stays usable after a failed call */ \
-            return fail(e_ == hipErrorNoDevice || e_ == hipErrorInvalidDevice ? RG_ERR_NO_DEVICE : RG_ERR_HIP, \
-                        std::string(#x) + ": " + hipGetErrorString(e_));                                \
-        }                                                                                               \
-    } while (0)
-
-template <typename T>
-struct DevBuf {
-    T* p = nullptr;
-    size_t n = 0;
-    ~DevBuf() { if (p) (void)hipFree(p); }
-    size_t bytes() const { return p ? n * sizeof(T) : 0; }
-    int alloc(size_t count) {
-        if (count <= n && p) return RG_OK;
-        if (p) { (void)hipFree(p); p = nullptr; n = 0; }
-        if (count == 0) count = 1;
-        HIPCHK(hipMalloc((void**)&p, count * sizeof(T)));
-        n = count;
-        return RG_OK;
-    }
-    int upload(const std::vector<T>& v) {
-        int rc = alloc(v.size());
-        if (rc) return rc;
-        if (!v.empty()) HIPCHK(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
-        return RG_OK;
-    }
-};
-
-// Device copy of the flattened graph: one per HIP device that has a batch on this graph (built on first use, under the
-// graph's mutex; the host arrays are immutable after creation, so a graph handle is shareable across threads and devices).
-struct GraphTables {
-    int dev = 0;
-    // LnzGraph view
-    DevBuf<uint8_t> d_lnz;
-    DevBuf<int> d_pred_off, d_pred_rows, d_r_values, d_min_pred;
-    // PathGraph view
-    DevBuf<uint64_t> d_row_mask;
-    DevBuf<int> d_knm, d_dfs, d_dfe, d_fgoff, d_rgoff, d_segfirst, d_seglast;
-    DevBuf<GroupDesc> d_fgroups, d_rgroups;
-    DevBuf<unsigned long long> d_node_id;
-    DevBuf<int> d_eoff, d_epred, d_roff, d_rsucc;
-    DevBuf<uint64_t> d_emask, d_rmask;
-    DevBuf<uint8_t> d_pnwp, d_rnwp;
-};
-
-struct rg_graph {
-    HostGraph h;
-    std::mutex mu;
-    std::map<int, std::unique_ptr<GraphTables>> tables;   // by device id
-    ~rg_graph() {
-        int cur = 0;
-        (void)hipGetDevice(&cur);
-        for (auto& kv : tables) { (void)hipSetDevice(kv.first); kv.second.reset(); }
-        (void)hipSetDevice(cur);
-    }
-};
-
-static int base_code(char c) {
-    switch (c) {
-        case 'A': return 0; case 'C': return 1; case 'G': return 2; case 'T': return 3; case 'N': return 4;
-        default: return -1;
-    }
-}
-
-// tables of `g` on the CURRENT device (uploaded once per device)
-static int upload_graph(rg_graph* gr, GraphTables** out) {
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(RG_ERR_NO_DEVICE, "no HIP device");
-    int dev = 0;
-    HIPCHK(hipGetDevice(&dev));
-    std::lock_guard<std::mutex> lock(gr->mu);
-    auto it = gr->tables.find(dev);
-    if (it != gr->tables.end()) { *out = it->second.get(); return RG_OK; }
-    auto g = std::make_unique<GraphTables>();
-    g->dev = dev;
-    const HostGraph& h = gr->h;
-    std::vector<uint8_t> codes(h.L, 0);
-    for (int i = 1; i + 1 < h.L; ++i) {
-        int c = base_code(h.lnz[i]);
-        if (c < 0) return fail(RG_ERR_GRAPH, "graph base outside ACGTN (the reference panics on the score lookup)");
-        codes[i] = (uint8_t)c;
-    }
-    int rc;
-    if ((rc = g->d_lnz.upload(codes))) return rc;
-    if (h.has_lnz) {
-        if ((rc = g->d_pred_off.upload(h.pred_off)) || (rc = g->d_pred_rows.upload(h.pred_rows)) ||
-            (rc = g->d_r_values.upload(h.r_values)) || (rc = g->d_min_pred.upload(h.min_pred)))
-            return rc;
-    }
-    if (h.has_path) {
-        std::vector<unsigned long long> ids(h.node_id.begin(), h.node_id.end());
-        std::vector<int> segfirst(h.L), seglast(h.L);
-        for (int i = 0; i < h.L; ++i) {
-            // "first row of its segment" / "last row of its segment" flags of the recombination tie rule
-            // (pathwise_alignment_recombination.rs:847-851)
-            segfirst[i] = i >= 1 && h.node_id[i] != h.node_id[i - 1];
-            seglast[i] = (i + 1 == h.L) || h.node_id[i] != h.node_id[i + 1];
-        }
-        // path masks as RG_PW words per row / edge
-        auto flat = [](const std::vector<PMask>& v) {
-            std::vector<uint64_t> o(v.size() * RG_PW);
-            for (size_t i = 0; i < v.size(); ++i) for (int w = 0; w < RG_PW; ++w) o[i * RG_PW + w] = v[i].w[w];
-            return o;
-        };
-        if ((rc = g->d_row_mask.upload(flat(h.row_mask))) || (rc = g->d_knm.upload(h.knm)) || (rc = g->d_dfs.upload(h.dfs)) ||
-            (rc = g->d_dfe.upload(h.dfe)) || (rc = g->d_fgoff.upload(h.fgoff)) || (rc = g->d_rgoff.upload(h.rgoff)) ||
-            (rc = g->d_fgroups.upload(h.fgroups)) || (rc = g->d_rgroups.upload(h.rgroups)) ||
-            (rc = g->d_node_id.upload(ids)) || (rc = g->d_segfirst.upload(segfirst)) ||
-            (rc = g->d_seglast.upload(seglast)) || (rc = g->d_eoff.upload(h.eoff)) || (rc = g->d_epred.upload(h.epred)) ||
-            (rc = g->d_emask.upload(flat(h.emask))) || (rc = g->d_roff.upload(h.roff)) || (rc = g->d_rsucc.upload(h.rsucc)) ||
-            (rc = g->d_rmask.upload(flat(h.rmask))) || (rc = g->d_pnwp.upload(h.pnwp)) || (rc = g->d_rnwp.upload(h.rnwp)))
-            return rc;
-    }
-    *out = g.get();
-    gr->tables[dev] = std::move(g);
-    return RG_OK;
-}
-
-// page-locked host staging buffer (H2D / D2H by DMA, no pageable bounce copy)
-template <typename T>
-struct PinBuf {
-    T* p = nullptr;
-    size_t n = 0;
-    ~PinBuf() { if (p) (void)hipHostFree(p); }
-    int alloc(size_t count) {
-        if (count <= n && p) return RG_OK;
-        if (p) { (void)hipHostFree(p); p = nullptr; n = 0; }
-        if (count == 0) count = 1;
-        count += count / 4;           // head-room: read sets of a stream differ a little in size
-        HIPCHK(hipHostMalloc((void**)&p, count * sizeof(T), hipHostMallocDefault));
-        n = count;
-        return RG_OK;
-    }
-};
-
-struct KernelStat {
-    std::string name;
-    double ms = 0;
-    long long launches = 0;
-};
-
-struct rg_batch {
-    const rg_graph* g = nullptr;
-    GraphTables* gt = nullptr;         // the graph's tables on this batch's device
-    rg_params p;
-    int64_t nreads = 0;
-    const uint8_t* codes = nullptr;    // base codes 0..4 per base (inside `stage`); the canonical text of a read (upper
-                                       // case, '-' -> 'N': sequences.rs:13-22) is "ACGTN"[code]
-    std::vector<long long> off;
-    std::vector<uint8_t> bad;
-    std::vector<int> bta;
-    int max_n = 0;
-    hipStream_t stream = nullptr;
-    int dev = 0;                       // device the handle was created on (graph tables are bound to it too)
-    // device inputs
-    // one device block [off | bta | codes | bad] filled by ONE DMA from the pinned block `stage` (same layout)
-    DevBuf<uint8_t> d_in;
-    PinBuf<uint8_t> stage;
-    struct InView { const uint8_t* reads; const long long* off; const uint8_t* bad; const int* bta; } in{};
-    DevBuf<int> d_col0;
-    // work + outputs
-    DevBuf<int> d_arena_m;
-    DevBuf<uint32_t> d_arena_pw;
-    DevBuf<int4> d_rinfo;
-    DevBuf<DevRecord> d_rec;
-    DevBuf<uint8_t> d_ops;
-    DevBuf<int32_t> d_oprows;
-    DevBuf<unsigned long long> d_cells;
-    long long cap_cells = 0, ops_stride = 0;
-    PathWork pw;                       // m4/m8 buffers
-    // host results
-    std::vector<DevRecord> rec;
-    std::vector<uint8_t> ops;
-    std::vector<int32_t> oprows;
-    bool fetched = false;
-    uint64_t cells = 0;
-    std::vector<KernelStat> stats;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
-    ~rg_batch() {
-        for (auto& e : ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
-        if (stream) (void)hipStreamDestroy(stream);
-    }
-};
-
-static void rg_batch_destroy_impl(rg_batch* b) {
+void rg_batch_destroy_impl(rg_batch* b) {
     if (!b) return;
-    int cur = 0;
-    (void)hipGetDevice(&cur);
-    (void)hipSetDevice(b->dev);     // buffers and stream are freed on the device that owns them
+    DevGuard dg(b->dev);            // buffers and stream are freed on the device that owns them
     delete b;
-    (void)hipSetDevice(cur);
 }
+
+namespace rg {
+Options& options() {
+    static Options o;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        auto env = [](const char* k) { const char* v = getenv(k); return v && *v && strcmp(v, "0") != 0 ? 1 : 0; };
+        o.sweep_i32 = env("RG_SWEEP_I32");
+        o.three_sweeps = env("RG_THREE_SWEEPS");
+        o.no_frec = env("RG_NO_FREC");
+        o.debug = env("RG_DEBUG");
+    });
+    return o;
+}
+}  // namespace rg
 
 namespace {
 
@@ -278,7 +100,7 @@ int run_local(rg_batch* b) {
     size_t free_b = 0, total_b = 0;
     HIPCHK(hipMemGetInfo(&free_b, &total_b));
     free_b += b->d_arena_m.bytes() + b->d_arena_pw.bytes();   // arenas of a previous run are reused
-    const size_t budget = free_b / 4 * 3;
+    const size_t budget = b->mem_budget ? std::min(b->mem_budget, free_b / 10 * 9) : free_b / 4 * 3;
     if (per_read > budget) return fail(RG_ERR_CAPACITY, "local POA: one read's L x W matrices exceed the free HBM");
     const long long chunk = (long long)std::min<size_t>((size_t)b->nreads, budget / per_read);
     int rc;
@@ -315,22 +137,26 @@ int run_poa(rg_batch* b) {
     const int planes = mode == RG_MODE_GAP_POA ? 2 : 1;   // m2: m | y score planes, w0 | w1 path planes
     Timed T(b);
     for (auto& s : b->stats) { s.ms = 0; s.launches = 0; }
-    for (int attempt = 0; attempt < 12; ++attempt) {
+    int oom_shift = 0;      // the budget is halved every time an arena allocation fails (other handles / threads took the memory)
+    for (int attempt = 0; attempt < 24; ++attempt) {
         int rc;
         // Reads per launch: the band arenas of one launch take at most 45 % of the HBM that is free (plus what this
-        // handle already holds), so that a second handle of a streaming caller fits beside this one.
+        // handle already holds), so that a second handle of a streaming caller fits beside this one; a handle of the
+        // streaming engine has its own share of the device instead (mem_budget).
         const size_t per_read = (size_t)b->cap_cells * planes * (sizeof(int) + sizeof(uint32_t)) + (size_t)h.L * sizeof(int4);
         size_t free_b = 0, total_b = 0;
         HIPCHK(hipMemGetInfo(&free_b, &total_b));
         free_b += b->d_arena_m.bytes() + b->d_arena_pw.bytes() + b->d_rinfo.bytes();
-        const size_t budget = free_b / 100 * 45;
+        const size_t budget = (b->mem_budget ? std::min(b->mem_budget, free_b / 10 * 9) : free_b / 100 * 45) >> oom_shift;
         if (per_read > budget) return fail(RG_ERR_CAPACITY, "band arena of one read exceeds the free HBM");
         const long long maxchunk = (long long)std::min<size_t>((size_t)b->nreads, budget / per_read);
         const long long nchunks = (b->nreads + maxchunk - 1) / maxchunk;
         const long long chunk = (b->nreads + nchunks - 1) / nchunks;      // even launches
         if ((rc = b->d_arena_m.alloc((size_t)chunk * b->cap_cells * planes)) ||
-            (rc = b->d_arena_pw.alloc((size_t)chunk * b->cap_cells * planes)) || (rc = b->d_rinfo.alloc((size_t)chunk * h.L)))
+            (rc = b->d_arena_pw.alloc((size_t)chunk * b->cap_cells * planes)) || (rc = b->d_rinfo.alloc((size_t)chunk * h.L))) {
+            if (rc == RG_ERR_HIP && chunk > 1 && oom_shift < 8) { ++oom_shift; continue; }   // out of memory: smaller launches
             return rc;
+        }
         HIPCHK(hipMemsetAsync(b->d_cells.p, 0, sizeof(unsigned long long), b->stream));
         PoaArgs a;
         a.g = DevLnz{h.L, g->d_lnz.p, g->d_pred_off.p, g->d_pred_rows.p, g->d_r_values.p, g->d_min_pred.p};
@@ -374,19 +200,109 @@ int rg_run_pathwise(rg_batch* b);
 namespace rg {
 int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params& p, PathWork& w, const uint8_t* d_reads,
                     const long long* d_off, const uint8_t* d_bad, int nreads, int max_n, DevRecord* d_rec, uint8_t* d_ops,
-                    long long ops_stride, unsigned long long* d_cells, hipStream_t stream,
+                    long long ops_stride, unsigned long long* d_cells, hipStream_t stream, size_t mem_budget,
+                    unsigned long long* cells_out,
                     std::vector<std::pair<std::string, std::pair<double, long long>>>& stats);
+}
+
+// Text of read i exactly as the reference prints it (warning lines + GAFStruct::to_string), appended to `out`.
+extern "C" {
+static bool build_fields(const rg_batch* b, int64_t i, const char* name, GafFields& out);
+}
+static void append_gaf(const rg_batch* b, int64_t i, const char* name, int64_t seq_index, std::string& out) {
+    const DevRecord& d = b->rec[i];
+    GafFields f;
+    if (seq_index != 0 && build_fields(b, i, name, f)) out += f.text();
+    else if ((d.status & (ST_BAD_BASE | ST_WOULD_PANIC)) == 0 && (d.status & ST_BAND_WARNING))
+        out += "Band length probably too short, maybe try with larger b and f\n";
+}
+
+// All GAF text of a fetched batch in input order, formatted by `nthreads` host threads (contiguous blocks of reads per
+// thread, concatenated).  Name of read i: names[i], or "read<name_base + i>".  offs (optional): nreads + 1 offsets of the
+// reads' texts inside `out`.
+void format_batch(const rg_batch* b, const char* const* names, int64_t name_base, int64_t seq_index_base, int nthreads,
+                  std::string& out, std::vector<int64_t>* offs) {
+    const int64_t n = b->nreads;
+    if (nthreads < 1) nthreads = 1;
+    if (nthreads > n) nthreads = (int)std::max<int64_t>(1, n);
+    std::vector<std::string> parts((size_t)nthreads);
+    std::vector<int64_t> lens((size_t)n);
+    auto work = [&](int t) {
+        const int64_t lo = n * t / nthreads, hi = n * (t + 1) / nthreads;
+        std::string& o = parts[(size_t)t];
+        o.reserve((size_t)(hi - lo) * 2304);
+        std::string nm;
+        for (int64_t i = lo; i < hi; ++i) {
+            const size_t before = o.size();
+            const char* name;
+            if (names) name = names[i];
+            else { nm = "read" + std::to_string(name_base + i); name = nm.c_str(); }
+            append_gaf(b, i, name, seq_index_base + i, o);
+            lens[(size_t)i] = (int64_t)(o.size() - before);
+        }
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < nthreads; ++t) th.emplace_back(work, t);
+    work(0);
+    for (auto& t : th) t.join();
+    size_t total = 0;
+    for (auto& s : parts) total += s.size();
+    out.clear();
+    out.reserve(total + 1);
+    for (auto& s : parts) out += s;
+    if (offs) {
+        offs->resize((size_t)n + 1);
+        int64_t acc = 0;
+        for (int64_t i = 0; i < n; ++i) { (*offs)[(size_t)i] = acc; acc += lens[(size_t)i]; }
+        (*offs)[(size_t)n] = acc;
+    }
+}
+
+// Results of a fetched batch as a handle of their own (host records only): the device handle is free for the next
+// read set while a caller still reads this one through the rg_result_* accessors.
+rg_batch* rg_batch_detach_results(rg_batch* b) {
+    auto r = std::make_unique<rg_batch>();
+    r->g = b->g;
+    r->p = b->p;
+    r->nreads = b->nreads;
+    r->dev = -1;
+    r->off = b->off;
+    r->codes_own.assign(b->codes, b->codes + (size_t)b->off[(size_t)b->nreads]);
+    r->codes = r->codes_own.data();
+    r->rec = std::move(b->rec);
+    r->ops = std::move(b->ops);
+    r->oprows = std::move(b->oprows);
+    r->ops_stride = b->ops_stride;
+    r->cells = b->cells;
+    r->stats = b->stats;
+    r->fetched = true;
+    b->fetched = false;
+    return r.release();
 }
 
 extern "C" {
 
-struct rg_multi {
-    std::vector<rg_batch*> shards;
-    std::vector<int64_t> begin;    // shards.size() + 1
-    ~rg_multi() { for (rg_batch* b : shards) rg_batch_destroy_impl(b); }
-};
-
 const char* rg_last_error(void) { return g_last_error.c_str(); }
+
+static std::atomic<int>* option_slot(const char* name) {
+    if (!name) return nullptr;
+    Options& o = options();
+    if (!strcmp(name, "sweep_i32")) return &o.sweep_i32;
+    if (!strcmp(name, "three_sweeps")) return &o.three_sweeps;
+    if (!strcmp(name, "no_frec")) return &o.no_frec;
+    if (!strcmp(name, "debug")) return &o.debug;
+    return nullptr;
+}
+int32_t rg_set_option(const char* name, int64_t value) {
+    std::atomic<int>* s = option_slot(name);
+    if (!s) return fail(RG_ERR_ARG, std::string("unknown option ") + (name ? name : "(null)"));
+    *s = value ? 1 : 0;
+    return RG_OK;
+}
+int64_t rg_get_option(const char* name) {
+    std::atomic<int>* s = option_slot(name);
+    return s ? (int64_t)s->load() : -1;
+}
 
 int32_t rg_device_count(void) {
     int n = 0;
@@ -466,10 +382,27 @@ static int load_reads(rg_batch* b, const char* reads, const int64_t* read_off, i
     const rg_graph* g = b->g;
     const rg_params* p = &b->p;
     const int mode = p->mode;
+    // validation first: a rejected read set leaves the handle exactly as it was
+    for (int64_t r = 0; r < nreads; ++r)
+        if (read_off[r + 1] - read_off[r] < 1) return fail(RG_ERR_ARG, "empty read");
+    if (read_off[nreads] - read_off[0] >= (1ll << 40)) return fail(RG_ERR_ARG, "read set too large");
+    // From here on the handle describes no read set until every buffer is sized and uploaded (`valid`): rg_batch_run and
+    // rg_batch_fetch refuse it after a failed allocation instead of launching the new reads against the old buffers.
+    b->valid = false;
     b->fetched = false;
+    const long long base = read_off[0];
+    const size_t total = (size_t)(read_off[nreads] - base);
+    // staging layout (8-byte aligned pieces): offsets (int64), bta (int32), codes (u8), bad (u8)
+    const size_t o_off = 0, o_bta = o_off + sizeof(long long) * (size_t)(nreads + 1);
+    const size_t o_codes = (o_bta + sizeof(int) * (size_t)nreads + 7) & ~(size_t)7;
+    const size_t o_bad = (o_codes + total + 7) & ~(size_t)7;
+    const size_t in_bytes = o_bad + (size_t)nreads;
+    int rc;
+    if ((rc = b->stage.alloc(in_bytes)) || (rc = b->d_in.alloc(in_bytes + in_bytes / 4)) || (rc = b->d_rec.alloc(nreads)) ||
+        (rc = b->d_cells.alloc(1)))
+        return rc;
     b->nreads = nreads;
     b->off.resize(nreads + 1);
-    const long long base = read_off[0];
     for (int64_t i = 0; i <= nreads; ++i) b->off[i] = read_off[i] - base;
     // sequences.rs:13-22 as two 256-entry tables: canonical character ('-' -> 'N', upper case) and base code (0xff = none)
     static const struct Canon {
@@ -484,14 +417,6 @@ static int load_reads(rg_batch* b, const char* reads, const int64_t* read_off, i
             }
         }
     } canon;
-    const size_t total = (size_t)(read_off[nreads] - base);
-    // staging layout (8-byte aligned pieces): offsets (int64), bta (int32), codes (u8), bad (u8)
-    const size_t o_off = 0, o_bta = o_off + sizeof(long long) * (size_t)(nreads + 1);
-    const size_t o_codes = (o_bta + sizeof(int) * (size_t)nreads + 7) & ~(size_t)7;
-    const size_t o_bad = (o_codes + total + 7) & ~(size_t)7;
-    const size_t in_bytes = o_bad + (size_t)nreads;
-    int rc;
-    if ((rc = b->stage.alloc(in_bytes))) return rc;
     b->bad.assign(nreads, 0);
     b->bta.resize(nreads);
     b->max_n = 0;
@@ -501,8 +426,7 @@ static int load_reads(rg_batch* b, const char* reads, const int64_t* read_off, i
     for (size_t k = 0; k < total; ++k) codes[k] = canon.code[src[k]];       // one table pass over the whole blob
     for (int64_t r = 0; r < nreads; ++r) {
         const long long n = b->off[r + 1] - b->off[r];
-        if (n < 1) return fail(RG_ERR_ARG, "empty read");
-        b->max_n = std::max<int>(b->max_n, (int)n);
+        b->max_n = std::max<int>(b->max_n, (int)std::min<long long>(n, INT32_MAX));
         // a character outside ACGTN (after canonicalisation): the reference panics on the score lookup
         if (memchr(codes + b->off[r], 0xff, (size_t)n)) {
             b->bad[r] = 1;
@@ -516,16 +440,6 @@ static int load_reads(rg_batch* b, const char* reads, const int64_t* read_off, i
     memcpy(b->stage.p + o_off, b->off.data(), sizeof(long long) * (size_t)(nreads + 1));
     memcpy(b->stage.p + o_bta, b->bta.data(), sizeof(int) * (size_t)nreads);
     memcpy(b->stage.p + o_bad, b->bad.data(), (size_t)nreads);
-    if ((rc = b->d_in.alloc(in_bytes + in_bytes / 4))) return rc;
-    // ONE DMA from the pinned block on the batch's stream (no blit kernel that would queue behind a running sweep of
-    // another handle), ordered before the kernels of the next run
-    HIPCHK(hipMemcpyAsync(b->d_in.p, b->stage.p, in_bytes, hipMemcpyHostToDevice, b->stream));
-    HIPCHK(hipStreamSynchronize(b->stream));
-    b->in.off = reinterpret_cast<const long long*>(b->d_in.p + o_off);
-    b->in.bta = reinterpret_cast<const int*>(b->d_in.p + o_bta);
-    b->in.reads = b->d_in.p + o_codes;
-    b->in.bad = b->d_in.p + o_bad;
-    if ((rc = b->d_rec.alloc(nreads)) || (rc = b->d_cells.alloc(1))) return rc;
     const HostGraph& h = g->h;
     // traceback ops per read: POA walks at most L rows + n columns; a pathwise walk stays on the rows of one path per
     // half (forward to the source, reverse to the sink): <= 2 * (rows of the longest path + n)
@@ -539,6 +453,15 @@ static int load_reads(rg_batch* b, const char* reads, const int64_t* read_off, i
         const long long per_row = std::min<long long>(b->max_n + 1, 2 * maxbta + 40);
         b->cap_cells = std::max(b->cap_cells, (long long)h.L * per_row);   // keeps an arena regrown by an earlier run
     }
+    // ONE DMA from the pinned block on the batch's stream (no blit kernel that would queue behind a running sweep of
+    // another handle), ordered before the kernels of the next run
+    HIPCHK(hipMemcpyAsync(b->d_in.p, b->stage.p, in_bytes, hipMemcpyHostToDevice, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    b->in.off = reinterpret_cast<const long long*>(b->d_in.p + o_off);
+    b->in.bta = reinterpret_cast<const int*>(b->d_in.p + o_bta);
+    b->in.reads = b->d_in.p + o_codes;
+    b->in.bad = b->d_in.p + o_bad;
+    b->valid = true;
     return RG_OK;
 }
 
@@ -589,23 +512,34 @@ int32_t rg_batch_create(const rg_graph* gc, const rg_params* p, const char* read
     return RG_OK;
 }
 
+static const char* kNoDevBuffers = "results-only handle (a tile of a stream / rg_multi): it has no device buffers";
+static const char* kNoReads = "the handle holds no read set (a previous rg_batch_set_reads failed)";
+
 int32_t rg_batch_set_reads(rg_batch* b, const char* reads, const int64_t* read_off, int64_t nreads) {
     if (!b || !reads || !read_off || nreads < 1) return fail(RG_ERR_ARG, "null/empty argument");
-    HIPCHK(hipSetDevice(b->dev));
+    if (b->dev < 0) return fail(RG_ERR_ARG, kNoDevBuffers);
+    DevGuard dg(b->dev);            // the handle is bound to the device it was created on; the caller's device is restored
+    HIPCHK(dg.err);
     return load_reads(b, reads, read_off, nreads);
 }
 
 int32_t rg_batch_run(rg_batch* b) {
     if (!b) return fail(RG_ERR_ARG, "null batch");
+    if (b->dev < 0) return fail(RG_ERR_ARG, kNoDevBuffers);
+    if (!b->valid) return fail(RG_ERR_ARG, kNoReads);
     b->fetched = false;
-    HIPCHK(hipSetDevice(b->dev));   // the handle is bound to the device it was created on
+    DevGuard dg(b->dev);
+    HIPCHK(dg.err);
     if (is_poa(b->p.mode)) return run_poa(b);
     return rg_run_pathwise(b);
 }
 
 int32_t rg_batch_fetch(rg_batch* b) {
     if (!b) return fail(RG_ERR_ARG, "null batch");
-    HIPCHK(hipSetDevice(b->dev));
+    if (b->dev < 0) return fail(RG_ERR_ARG, kNoDevBuffers);
+    if (!b->valid) return fail(RG_ERR_ARG, kNoReads);
+    DevGuard dg(b->dev);
+    HIPCHK(dg.err);
     b->rec.resize(b->nreads);
     HIPCHK(hipMemcpy(b->rec.data(), b->d_rec.p, sizeof(DevRecord) * b->nreads, hipMemcpyDeviceToHost));
     b->ops.resize((size_t)b->nreads * b->ops_stride);
@@ -659,12 +593,8 @@ static bool build_fields(const rg_batch* b, int64_t i, const char* name, GafFiel
 
 int64_t rg_result_gaf(const rg_batch* b, int64_t i, const char* name, int64_t seq_index, char* buf, int64_t cap) {
     if (!b || !b->fetched || i < 0 || i >= b->nreads) return fail(RG_ERR_ARG, "result not available");
-    const DevRecord& d = b->rec[i];
     std::string out;
-    GafFields f;
-    if (seq_index != 0 && build_fields(b, i, name, f)) out = f.text();
-    else if ((d.status & (ST_BAD_BASE | ST_WOULD_PANIC)) == 0 && (d.status & ST_BAND_WARNING))
-        out = "Band length probably too short, maybe try with larger b and f\n";
+    append_gaf(b, i, name, seq_index, out);
     if (buf && (int64_t)out.size() + 1 <= cap) memcpy(buf, out.c_str(), out.size() + 1);
     return (int64_t)out.size();
 }
@@ -692,32 +622,10 @@ int32_t rg_result_fields(const rg_batch* b, int64_t i, rg_gaf_fields* out, uint6
 int64_t rg_batch_format_all(const rg_batch* b, const char* const* names, int64_t seq_index_base, char* buf, int64_t cap,
                             int32_t nthreads) {
     if (!b || !b->fetched) return fail(RG_ERR_ARG, "result not available");
-    const int64_t n = b->nreads;
-    std::vector<std::string> parts((size_t)n);
-    if (nthreads < 1) nthreads = 1;
-    auto work = [&](int t) {
-        std::vector<char> tmp(1 << 16);
-        for (int64_t i = t; i < n; i += nthreads) {
-            std::string nm = names ? std::string(names[i]) : "read" + std::to_string(i);
-            int64_t need = rg_result_gaf(b, i, nm.c_str(), seq_index_base + i, tmp.data(), (int64_t)tmp.size());
-            if (need + 1 > (int64_t)tmp.size()) {
-                tmp.resize((size_t)need + 16);
-                rg_result_gaf(b, i, nm.c_str(), seq_index_base + i, tmp.data(), (int64_t)tmp.size());
-            }
-            parts[(size_t)i].assign(tmp.data(), (size_t)need);
-        }
-    };
-    std::vector<std::thread> th;
-    for (int t = 1; t < nthreads; ++t) th.emplace_back(work, t);
-    work(0);
-    for (auto& t : th) t.join();
-    int64_t total = 0;
-    for (auto& s : parts) total += (int64_t)s.size();
-    if (buf && total + 1 <= cap) {
-        char* o = buf;
-        for (auto& s : parts) { memcpy(o, s.data(), s.size()); o += s.size(); }
-        *o = 0;
-    }
+    std::string out;
+    format_batch(b, names, 0, seq_index_base, nthreads, out, nullptr);
+    const int64_t total = (int64_t)out.size();
+    if (buf && total + 1 <= cap) memcpy(buf, out.c_str(), out.size() + 1);
     return total;
 }
 
@@ -737,63 +645,6 @@ int32_t rg_align_batch(const rg_graph* g, const rg_params* p, const char* reads,
     return RG_OK;
 }
 
-// ---- all visible GPUs behind one call ("one call may use all visible GPUs") ----
-int32_t rg_align_batch_multi(const rg_graph* g, const rg_params* p, const char* reads, const int64_t* read_off, int64_t nreads,
-                             const int32_t* device_ids, int32_t ndev, rg_multi** out) {
-    if (!g || !p || !reads || !read_off || !out || nreads < 1) return fail(RG_ERR_ARG, "null/empty argument");
-    std::vector<int> devs;
-    if (device_ids) {
-        if (ndev < 1) return fail(RG_ERR_ARG, "empty device list");
-        devs.assign(device_ids, device_ids + ndev);
-    } else {
-        const int n = rg_device_count();
-        if (n < 1) return fail(RG_ERR_NO_DEVICE, "no HIP device");
-        for (int d = 0; d < n; ++d) devs.push_back(d);
-    }
-    if ((int64_t)devs.size() > nreads) devs.resize((size_t)nreads);
-    const int S = (int)devs.size();
-    auto m = std::make_unique<rg_multi>();
-    m->shards.assign(S, nullptr);
-    m->begin.resize(S + 1);
-    for (int k = 0; k <= S; ++k) m->begin[k] = nreads / S * k + std::min<int64_t>(k, nreads % S);   // contiguous, sizes differ by <= 1
-    std::vector<int> rcs(S, RG_OK);
-    std::vector<std::string> errs(S);
-    auto work = [&](int k) {
-        // the reference's read loop (main.rs:56,174,257,297) on this shard: one host thread, one device, one stream
-        if (hipSetDevice(devs[k]) != hipSuccess) { (void)hipGetLastError(); rcs[k] = RG_ERR_NO_DEVICE; errs[k] = "hipSetDevice(" + std::to_string(devs[k]) + ") failed"; return; }
-        rcs[k] = rg_align_batch(g, p, reads, read_off + m->begin[k], m->begin[k + 1] - m->begin[k], &m->shards[k]);
-        if (rcs[k]) errs[k] = g_last_error;     // thread-local: carry it to the caller's thread
-    };
-    std::vector<std::thread> th;
-    for (int k = 1; k < S; ++k) th.emplace_back(work, k);
-    int cur = 0;
-    (void)hipGetDevice(&cur);
-    work(0);
-    (void)hipSetDevice(cur);
-    for (auto& t : th) t.join();
-    for (int k = 0; k < S; ++k)
-        if (rcs[k]) return fail(rcs[k], "device " + std::to_string(devs[k]) + ": " + errs[k]);
-    *out = m.release();
-    return RG_OK;
-}
-int32_t rg_multi_shards(const rg_multi* m) { return m ? (int32_t)m->shards.size() : 0; }
-rg_batch* rg_multi_batch(const rg_multi* m, int32_t k) { return m && k >= 0 && k < (int32_t)m->shards.size() ? m->shards[k] : nullptr; }
-int64_t rg_multi_shard_begin(const rg_multi* m, int32_t k) { return m && k >= 0 && k <= (int32_t)m->shards.size() ? m->begin[k] : -1; }
-int64_t rg_multi_format_all(const rg_multi* m, const char* const* names, int64_t seq_index_base, char* buf, int64_t cap,
-                            int32_t nthreads) {
-    if (!m) return fail(RG_ERR_ARG, "null handle");
-    int64_t total = 0;
-    for (size_t k = 0; k < m->shards.size(); ++k) {
-        const int64_t left = buf && cap > total ? cap - total : 0;
-        const int64_t need = rg_batch_format_all(m->shards[k], names ? names + m->begin[k] : nullptr, seq_index_base + m->begin[k],
-                                                 left ? buf + total : nullptr, left, nthreads);
-        if (need < 0) return need;
-        total += need;
-    }
-    return total;
-}
-void rg_multi_destroy(rg_multi* m) { delete m; }
-
 }  // extern "C"
 
 // ---- pathwise modes: buffers are owned by PathWork, kernels by rg_path_driver.hip ----
@@ -808,13 +659,13 @@ int rg_run_pathwise(rg_batch* b) {
     gd.eoff = g->d_eoff.p; gd.epred = g->d_epred.p; gd.emask = g->d_emask.p; gd.roff = g->d_roff.p; gd.rsucc = g->d_rsucc.p;
     gd.rmask = g->d_rmask.p; gd.pnwp = g->d_pnwp.p; gd.rnwp = g->d_rnwp.p;
     std::vector<std::pair<std::string, std::pair<double, long long>>> st;
+    // what this handle already holds counts towards its share of the device
+    unsigned long long c = 0;
     int rc = path_driver_run(h, gd, b->p, b->pw, b->in.reads, b->in.off, b->in.bad, (int)b->nreads, b->max_n, b->d_rec.p,
-                             b->d_ops.p, b->ops_stride, b->d_cells.p, b->stream, st);
+                             b->d_ops.p, b->ops_stride, b->d_cells.p, b->stream, b->mem_budget, &c, st);
     b->stats.clear();
     for (auto& s : st) b->stats.push_back(KernelStat{s.first, s.second.first, s.second.second});
     if (rc) return rc;
-    unsigned long long c = 0;
-    HIPCHK(hipMemcpy(&c, b->d_cells.p, sizeof c, hipMemcpyDeviceToHost));
     b->cells = c;
     return RG_OK;
 }

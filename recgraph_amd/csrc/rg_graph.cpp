@@ -257,6 +257,8 @@ int build_from_gfa(const char* text, int64_t len, HostGraph& g) {
     }
     if (segs.empty()) return fail(RG_ERR_GFA, "no segments");
     std::stable_sort(segs.begin(), segs.end(), [](const Segment& a, const Segment& b) { return a.id < b.id; });
+    for (size_t k = 1; k < segs.size(); ++k)
+        if (segs[k].id == segs[k - 1].id) return fail(RG_ERR_GFA, "duplicate segment id " + std::to_string(segs[k].id));
     std::unordered_map<uint64_t, int32_t> idx;
     int32_t row = 1;
     for (size_t s = 0; s < segs.size(); ++s) {

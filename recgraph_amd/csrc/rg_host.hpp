@@ -4,6 +4,7 @@
 // reference's HashMap/BitVec containers (graph.rs:23-27, pathwise_graph.rs:10-18,75-78) have no
 // counterpart here.
 #pragma once
+#include <atomic>
 #include <cstdint>
 #include <string>
 #include <vector>
@@ -13,6 +14,17 @@
 namespace rg {
 
 extern thread_local std::string g_last_error;
+
+// Process-wide diagnostic switches (rg_set_option; defaults from the environment variables of the same meaning, read
+// once when the library is loaded): no getenv on the run path.
+struct Options {
+    std::atomic<int> sweep_i32{0};      // RG_SWEEP_I32: force the i32 sweep kernel
+    std::atomic<int> three_sweeps{0};   // RG_THREE_SWEEPS: force the three-sweep -m 8 pipeline
+    std::atomic<int> no_frec{0};        // RG_NO_FREC: Cand-list forward emission instead of records
+    std::atomic<int> debug{0};          // RG_DEBUG: candidate / record statistics on stderr
+};
+Options& options();
+
 int fail(int code, const std::string& msg);
 
 // Path sets: the reference uses BitVec(paths_number) (pathwise_graph.rs:10-18); here a fixed 256-bit mask (4 words),

@@ -55,7 +55,12 @@ struct PathWorkImpl {
     int nfsteps = 0, nrsteps = 0;
     unsigned fcap = 0, rcap = 0;
     std::vector<hipEvent_t> ev;
-    ~PathWorkImpl() { for (auto e : ev) (void)hipEventDestroy(e); }
+    Buf<unsigned> need;                 // [4] per chunk: largest nf, nr, forward / reverse record count of a read (k_need)
+    unsigned long long* h_sum = nullptr;  // pinned: {cell updates of the chunk, need[0..3]} read back once per chunk
+    ~PathWorkImpl() {
+        for (auto e : ev) (void)hipEventDestroy(e);
+        if (h_sum) (void)hipHostFree(h_sum);
+    }
 };
 PathWork::~PathWork() { delete impl; }
 
@@ -112,10 +117,13 @@ struct Timer {
 
 int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params& p, PathWork& pw, const uint8_t* d_reads,
                     const long long* d_off, const uint8_t* d_bad, int nreads, int max_n, DevRecord* d_rec, uint8_t* d_ops,
-                    long long ops_stride, unsigned long long* d_cells, hipStream_t stream,
+                    long long ops_stride, unsigned long long* d_cells, hipStream_t stream, size_t mem_budget,
+                    unsigned long long* cells_out,
                     std::vector<std::pair<std::string, std::pair<double, long long>>>& stats) {
     if (!pw.impl) pw.impl = new PathWorkImpl();
     PathWorkImpl& w = *pw.impl;
+    const Options& opt = options();
+    const bool debug = opt.debug != 0;
     const int pmode = p.mode;
     const bool semi = pmode == RG_MODE_PATHWISE_SEMI || pmode == RG_MODE_RECOMBINATION_SEMI;
     // pipeline selector: the semiglobal modes run the same kernels with the `semi` switches
@@ -136,14 +144,27 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
     // kernel (test hook: the two must agree byte for byte)
     DevScores dsc;
     for (int i = 0; i < 36; ++i) dsc.t[i] = p.scores[i];
-    const bool use16 = nwv == 1 && !getenv("RG_SWEEP_I32") && sweep16_admissible(dsc, h.max_path_rows, max_n, C);
+    const bool use16 = nwv == 1 && !opt.sweep_i32 && sweep16_admissible(dsc, h.max_path_rows, max_n, C);
+    if (!use16) {
+        // the i32 sweep packs (value, path) keys as value * 256 + path in 32 bits: |value| must stay below 2^23
+        long long maxabs = 0;
+        for (int i = 0; i < 36; ++i) if (i != 35 && p.scores[i] != RG_SCORE_MISSING) maxabs = std::max<long long>(maxabs, std::llabs((long long)p.scores[i]));
+        if ((long long)(h.max_path_rows + max_n + 2) * maxabs >= (1ll << 23))
+            return fail(RG_ERR_CAPACITY, "scores of this batch can reach 2^23 in magnitude: outside the 32-bit (value, path) keys of the pathwise kernels");
+    }
+    hipError_t memset_err = hipSuccess;
     auto sweep = [&](const SweepArgs& sa_, int nr) {
         // (striped sweeps advance the candidate counter of a read atomically from several waves: start it at zero)
-        if (nwv > 1 && sa_.cand && sa_.ncand_out) (void)hipMemsetAsync(sa_.ncand_out, 0, sizeof(unsigned) * nr, stream);
+        if (nwv > 1 && sa_.cand && sa_.ncand_out) {
+            const hipError_t e = hipMemsetAsync(sa_.ncand_out, 0, sizeof(unsigned) * nr, stream);
+            if (e != hipSuccess) memset_err = e;
+        }
         if (use16) launch_sweep16(sa_, nr, C, stream);
         else launch_sweep(sa_, nr, C, stream);
     };
     int rc;
+    if (!w.h_sum) HIPCHK(hipHostMalloc((void**)&w.h_sum, 8 * sizeof(unsigned long long), hipHostMallocDefault));
+    if ((rc = w.need.alloc(4))) return rc;
     if (!w.tables) {
         // rows of every path in program order, with the direction-word slot of the group holding the path
         auto build = [&](const std::vector<int32_t>& goff, const std::vector<GroupDesc>& groups, bool fwd,
@@ -215,6 +236,8 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
     {
         size_t fr = 0, tot = 0;
         if (hipMemGetInfo(&fr, &tot) == hipSuccess) budget = fr / 4 * 3;
+        // a handle of the streaming engine has its own share of the device (what it already holds counts towards it)
+        if (mem_budget) budget = mem_budget;
     }
     // -m 8 pipeline: two sweeps (forward with a loose threshold from the exact path-0 score, then reverse) when
     // every gap entry is <= 0 (then w[.][j] <= (n - j) * max match); three sweeps otherwise / on request
@@ -224,18 +247,19 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
         gaps_nonpos = gaps_nonpos && p.scores[x * 6 + 5] <= 0 && p.scores[5 * 6 + x] <= 0;
         for (int y = 0; y < 5; ++y) maxmatch = std::max(maxmatch, p.scores[x * 6 + y]);
     }
-    const bool two_sweep = mode == RG_MODE_RECOMBINATION && gaps_nonpos && nwv == 1 && !getenv("RG_THREE_SWEEPS");
+    const bool two_sweep = mode == RG_MODE_RECOMBINATION && gaps_nonpos && nwv == 1 && !opt.three_sweeps;
     // forward emissions of the two-sweep pipeline are loose (threshold from the path-0 score): k_sweep16 writes them as
     // (row, lane) records that k_expand filters with the final bound; k_sweep writes plain Cand entries
-    const bool use_rec = two_sweep && use16 && !getenv("RG_NO_FREC");
+    const bool use_rec = two_sweep && use16 && !opt.no_frec;
     const int recw = 4 + C;
     if (w.fcap == 0) { w.fcap = (two_sweep && !use_rec) ? 1u << 20 : 1u << 15; w.rcap = use_rec ? 1u << 16 : 1u << 19; w.frec_cap = 1u << 16; w.rrec_cap = 1u << 14; }
     stats.clear();
-    HIPCHK(hipMemsetAsync(d_cells, 0, sizeof(unsigned long long), stream));
     Timer T{&w, stream};
     int done = 0;
     unsigned long long cells_done = 0;
     while (done < nreads) {
+        HIPCHK(hipMemsetAsync(d_cells, 0, sizeof(unsigned long long), stream));      // cell updates of this chunk attempt
+        HIPCHK(hipMemsetAsync(w.need.p, 0, 4 * sizeof(unsigned), stream));
         const size_t per_read_all = per_read + (mode == RG_MODE_RECOMBINATION ? ((size_t)w.fcap * sizeof(Cand) + (size_t)w.rcap * (sizeof(Cand) + 4) +
                                                                                      (use_rec ? (size_t)(w.frec_cap + w.rrec_cap) * recw * 4 : 0)) : 0);
         int maxchunk = (int)std::min<size_t>(8192, std::max<size_t>(1, budget / per_read_all));
@@ -332,54 +356,8 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
             SearchArgs sr{gd, w.state.p, w.fcand.p, w.rcand.p, w.nf.p, w.nr.p, w.ridx.p, w.fcap, w.rcap, w.wr.p, wpad, p.base_rec_cost,
                           p.multi_rec_cost};
             TIMED(T, "k_search", launch_search(sr, chunk, stream));
-            // candidate-list overflow: regrow and redo this chunk
-            if ((rc = T.collect(stats))) return rc;
-            std::vector<unsigned> hn(chunk), hr(chunk);
-            HIPCHK(hipMemcpy(hn.data(), w.nf.p, sizeof(unsigned) * chunk, hipMemcpyDeviceToHost));
-            HIPCHK(hipMemcpy(hr.data(), w.nr.p, sizeof(unsigned) * chunk, hipMemcpyDeviceToHost));
-            unsigned needf = 0, needr = 0, needrec = 0;
-            for (int i = 0; i < chunk; ++i) { needf = std::max(needf, hn[i]); needr = std::max(needr, hr[i]); }
-            if (use_rec) {
-                std::vector<unsigned> hc(chunk);
-                HIPCHK(hipMemcpy(hc.data(), w.nrec.p, sizeof(unsigned) * chunk, hipMemcpyDeviceToHost));
-                unsigned long long sc = 0;
-                for (int i = 0; i < chunk; ++i) { needrec = std::max(needrec, hc[i]); sc += hc[i]; }
-                if (getenv("RG_DEBUG")) fprintf(stderr, "[rg] forward records mean %.1f max %u (cap %u)\n", (double)sc / chunk, needrec, w.frec_cap);
-                HIPCHK(hipMemcpy(hc.data(), w.nrrec.p, sizeof(unsigned) * chunk, hipMemcpyDeviceToHost));
-                unsigned needrrec = 0;
-                sc = 0;
-                for (int i = 0; i < chunk; ++i) { needrrec = std::max(needrrec, hc[i]); sc += hc[i]; }
-                if (getenv("RG_DEBUG")) fprintf(stderr, "[rg] reverse records mean %.1f max %u (cap %u)\n", (double)sc / chunk, needrrec, w.rrec_cap);
-                if (needrrec > w.rrec_cap) {
-                    const unsigned long long fullrec = (unsigned long long)L * WAVE;
-                    if (w.rrec_cap >= fullrec) return fail(RG_ERR_CAPACITY, "reverse record list overflow at full size");
-                    while (w.rrec_cap < needrrec) w.rrec_cap = (unsigned)std::min<unsigned long long>(2ull * w.rrec_cap, fullrec);
-                    HIPCHK(hipMemcpy(d_cells, &cells_done, sizeof cells_done, hipMemcpyHostToDevice));
-                    continue;
-                }
-                if (needrec > w.frec_cap) {
-                    const unsigned long long fullrec = (unsigned long long)L * WAVE;
-                    if (w.frec_cap >= fullrec) return fail(RG_ERR_CAPACITY, "forward record list overflow at full size");
-                    while (w.frec_cap < needrec) w.frec_cap = (unsigned)std::min<unsigned long long>(2ull * w.frec_cap, fullrec);
-                    HIPCHK(hipMemcpy(d_cells, &cells_done, sizeof cells_done, hipMemcpyHostToDevice));
-                    continue;
-                }
-            }
-            if (getenv("RG_DEBUG")) {
-                unsigned long long sf = 0, sr = 0;
-                for (int i = 0; i < chunk; ++i) { sf += hn[i]; sr += hr[i]; }
-                fprintf(stderr, "[rg] chunk %d reads: fwd cand mean %.1f max %u, rev cand mean %.1f max %u\n", chunk,
-                        (double)sf / chunk, needf, (double)sr / chunk, needr);
-            }
-            if (needf > w.fcap || needr > w.rcap) {
-                const unsigned long long full = (unsigned long long)L * wpad;
-                if ((needf > w.fcap && w.fcap >= full) || (needr > w.rcap && w.rcap >= full) || needf > full || needr > full)
-                    return fail(RG_ERR_CAPACITY, "candidate list overflow at full size");
-                while (w.fcap < needf) w.fcap = (unsigned)std::min<unsigned long long>(2ull * w.fcap, full);
-                while (w.rcap < needr) w.rcap = (unsigned)std::min<unsigned long long>(2ull * w.rcap, full);
-                HIPCHK(hipMemcpy(d_cells, &cells_done, sizeof cells_done, hipMemcpyHostToDevice));
-                continue;
-            }
+            // largest list / record counts of the chunk, read back once after the traceback (no host round trip here)
+            launch_need(w.state.p, w.nf.p, w.nr.p, use_rec ? w.nrec.p : nullptr, use_rec ? w.nrrec.p : nullptr, w.need.p, chunk, stream);
         }
         LayerArgs la;
         memset(&la, 0, sizeof la);
@@ -401,10 +379,55 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
         ta.rlayer = w.rlayer.p; ta.layer_stride = layer_stride; ta.fpoff = w.fpoff.p; ta.fprow = w.fprow.p;
         ta.rpoff = w.rpoff.p; ta.rprow = w.rprow.p; ta.nreads = chunk; ta.mode = pmode; ta.semi = semi ? 1 : 0; ta.nwv = nwv;
         TIMED(T, "k_trace", launch_trace(ta, C, stream));
+        // ONE read-back per chunk: cell updates + overflow summary, through pinned memory on the batch's stream
+        HIPCHK(hipMemcpyAsync(w.h_sum, d_cells, sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipMemcpyAsync(w.h_sum + 1, w.need.p, 4 * sizeof(unsigned), hipMemcpyDeviceToHost, stream));
         if ((rc = T.collect(stats))) return rc;
-        HIPCHK(hipMemcpy(&cells_done, d_cells, sizeof cells_done, hipMemcpyDeviceToHost));
+        if (memset_err != hipSuccess) return fail(RG_ERR_HIP, std::string("hipMemsetAsync: ") + hipGetErrorString(memset_err));
+        if (mode == RG_MODE_RECOMBINATION) {
+            // candidate-list / record-list overflow: regrow and redo this chunk (k_layer / k_trace skipped its reads)
+            const unsigned* nd = reinterpret_cast<const unsigned*>(w.h_sum + 1);
+            const unsigned needf = nd[0], needr = nd[1], needrec = nd[2], needrrec = nd[3];
+            if (debug) {
+                std::vector<unsigned> hn(chunk), hr(chunk);
+                HIPCHK(hipMemcpy(hn.data(), w.nf.p, sizeof(unsigned) * chunk, hipMemcpyDeviceToHost));
+                HIPCHK(hipMemcpy(hr.data(), w.nr.p, sizeof(unsigned) * chunk, hipMemcpyDeviceToHost));
+                unsigned long long sf = 0, sr = 0;
+                for (int i = 0; i < chunk; ++i) { sf += hn[i]; sr += hr[i]; }
+                fprintf(stderr, "[rg] chunk %d reads: fwd cand mean %.1f max %u (cap %u), rev cand mean %.1f max %u (cap %u)\n", chunk,
+                        (double)sf / chunk, needf, w.fcap, (double)sr / chunk, needr, w.rcap);
+                if (use_rec) {
+                    HIPCHK(hipMemcpy(hn.data(), w.nrec.p, sizeof(unsigned) * chunk, hipMemcpyDeviceToHost));
+                    HIPCHK(hipMemcpy(hr.data(), w.nrrec.p, sizeof(unsigned) * chunk, hipMemcpyDeviceToHost));
+                    sf = sr = 0;
+                    for (int i = 0; i < chunk; ++i) { sf += hn[i]; sr += hr[i]; }
+                    fprintf(stderr, "[rg] records: forward mean %.1f max %u (cap %u), reverse mean %.1f max %u (cap %u)\n",
+                            (double)sf / chunk, needrec, w.frec_cap, (double)sr / chunk, needrrec, w.rrec_cap);
+                }
+            }
+            bool redo = false;
+            if (use_rec && (needrrec > w.rrec_cap || needrec > w.frec_cap)) {
+                const unsigned long long fullrec = (unsigned long long)L * WAVE;
+                if ((needrrec > w.rrec_cap && w.rrec_cap >= fullrec) || (needrec > w.frec_cap && w.frec_cap >= fullrec))
+                    return fail(RG_ERR_CAPACITY, "record list overflow at full size");
+                while (w.rrec_cap < needrrec) w.rrec_cap = (unsigned)std::min<unsigned long long>(2ull * w.rrec_cap, fullrec);
+                while (w.frec_cap < needrec) w.frec_cap = (unsigned)std::min<unsigned long long>(2ull * w.frec_cap, fullrec);
+                redo = true;
+            }
+            if (needf > w.fcap || needr > w.rcap) {
+                const unsigned long long full = (unsigned long long)L * wpad;
+                if ((needf > w.fcap && w.fcap >= full) || (needr > w.rcap && w.rcap >= full) || needf > full || needr > full)
+                    return fail(RG_ERR_CAPACITY, "candidate list overflow at full size");
+                while (w.fcap < needf) w.fcap = (unsigned)std::min<unsigned long long>(2ull * w.fcap, full);
+                while (w.rcap < needr) w.rcap = (unsigned)std::min<unsigned long long>(2ull * w.rcap, full);
+                redo = true;
+            }
+            if (redo) continue;
+        }
+        cells_done += w.h_sum[0];
         done += chunk;
     }
+    if (cells_out) *cells_out = cells_done;
     return RG_OK;
 }
 

@@ -187,6 +187,8 @@ void launch_opt0(const Opt0Args& a, int nreads, int C, hipStream_t s);
 void launch_threshold(const ThrArgs& a, int nreads, hipStream_t s);
 void launch_bound(const BoundArgs& a, int nreads, hipStream_t s);
 void launch_search(const SearchArgs& a, int nreads, hipStream_t s);
+void launch_need(const ReadState* st, const unsigned* nf, const unsigned* nr, const unsigned* nrec, const unsigned* nrrec,
+                 unsigned* need, int nreads, hipStream_t s);
 void launch_layer(const LayerArgs& a, int nreads, int C, hipStream_t s);
 void launch_trace(const TraceArgs& a, int C, hipStream_t s);
 

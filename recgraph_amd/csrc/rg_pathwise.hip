@@ -1056,6 +1056,29 @@ __global__ __launch_bounds__(64) void k_trace(TraceArgs a) {
 }
 
 // ---------------------------------------------------------------------------------
+// Largest candidate-list / record-list length any read of the chunk asked for: the driver reads these four words back
+// once per chunk (with the cell-update counter) instead of copying the per-read counters in the middle of the pipeline.
+__global__ __launch_bounds__(256) void k_need(const ReadState* st, const unsigned* nf, const unsigned* nr, const unsigned* nrec,
+                                              const unsigned* nrrec, unsigned* need, int nreads) {
+    const int rd = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned v[4] = {0, 0, 0, 0};
+    if (rd < nreads && !(st[rd].status & (ST_BAD_BASE | ST_WOULD_PANIC))) {
+        v[0] = nf[rd]; v[1] = nr[rd];
+        if (nrec) v[2] = nrec[rd];
+        if (nrrec) v[3] = nrrec[rd];
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        for (int d = WAVE / 2; d >= 1; d >>= 1) v[e] = max(v[e], (unsigned)__shfl_xor((int)v[e], d, WAVE));
+        if ((threadIdx.x & (WAVE - 1)) == 0 && v[e]) atomicMax(&need[e], v[e]);
+    }
+}
+void launch_need(const ReadState* st, const unsigned* nf, const unsigned* nr, const unsigned* nrec, const unsigned* nrrec,
+                 unsigned* need, int nreads, hipStream_t s) {
+    hipLaunchKernelGGL(k_need, dim3((nreads + 255) / 256), dim3(256), 0, s, st, nf, nr, nrec, nrrec, need, nreads);
+}
+
+// ---------------------------------------------------------------------------------
 // launchers
 template <int C>
 static void launch_sweep_c(const SweepArgs& a, int nreads, hipStream_t s) {

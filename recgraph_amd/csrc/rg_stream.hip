@@ -1,0 +1,451 @@
+// Streaming engine of librecgraph_hip (rg_stream_*, rg_reads_*, rg_align_batch_multi in include/recgraph_hip.h): the
+// reference's read loop (main.rs:56,174,257,297-312) as a pipeline hidden behind the C ABI.
+//
+//   caller thread(s)   rg_stream_push: copy reads + names, cut into tiles, append to ONE queue
+//   worker threads     `handles_per_device` per device, each owns one rg_batch handle (HIP stream + HBM work buffers):
+//                      pop a tile -> canonicalise + upload (rg_batch_set_reads) -> kernels (rg_batch_run) -> record
+//                      fetch -> GAF text on `format_threads` host threads -> publish
+//   caller thread      rg_stream_next: tiles in input order
+//
+// The queue is shared by every handle of every device (a tile goes to whichever handle is free first), so devices
+// balance without a static split; the small latency-bound kernels of one tile run beside the sweeps of the other
+// handles' tiles, and all host work of a tile overlaps the device work of the others.  There is no CPU fallback:
+// rg_stream_create fails with RG_ERR_NO_DEVICE when no HIP device is usable.
+#include <algorithm>
+#include <chrono>
+#include <condition_variable>
+#include <cstring>
+#include <deque>
+#include <thread>
+
+#include "rg_batch_impl.hpp"
+
+// ---------------------------------------------------------------------------------------------------------------------
+// FASTA (sequences::get_sequences, sequences.rs:5-45)
+struct rg_reads {
+    std::string bases;
+    std::vector<int64_t> off;           // count + 1
+    std::vector<std::string> names;
+    std::vector<const char*> name_ptrs;
+};
+
+extern "C" {
+
+int32_t rg_reads_from_fasta(const char* text, int64_t len, rg_reads** out) {
+    if (!text || !out || len < 0) return fail(RG_ERR_ARG, "null argument");
+    auto r = std::make_unique<rg_reads>();
+    r->bases.reserve((size_t)len);
+    r->off.push_back(0);
+    // the reference pushes a name at every header and a sequence whenever the one being collected is non-empty at the
+    // next header / at the end of the file; the two lists are paired by index afterwards (:41-43 panics when the counts differ)
+    size_t cur_begin = 0;               // start of the sequence being collected inside r->bases
+    const char* p = text;
+    const char* end = text + len;
+    while (p < end) {
+        const char* nl = (const char*)memchr(p, '\n', (size_t)(end - p));
+        const char* le = nl ? nl : end;
+        const char* q = le;
+        if (nl && q > p && q[-1] == '\r') --q;              // BufRead::lines drops "\n" or "\r\n" (a '\r' at the very end stays)
+        if (q > p) {                                        // empty lines are skipped (:14)
+            if (*p == '>') {
+                r->names.emplace_back(p + 1, q);
+                if (r->bases.size() > cur_begin) { r->off.push_back((int64_t)r->bases.size()); cur_begin = r->bases.size(); }
+            } else {
+                for (const char* c = p; c < q; ++c) {
+                    const unsigned char ch = (unsigned char)*c;
+                    // '-' -> 'N', ASCII upper-casing (char::to_ascii_uppercase leaves everything else alone)
+                    r->bases.push_back(ch == '-' ? 'N' : (ch >= 'a' && ch <= 'z') ? (char)(ch - 32) : (char)ch);
+                }
+            }
+        }
+        p = nl ? nl + 1 : end;
+    }
+    if (r->bases.size() > cur_begin) r->off.push_back((int64_t)r->bases.size());
+    if (r->off.size() - 1 != r->names.size()) return fail(RG_ERR_ARG, "wrong fasta file format");
+    r->name_ptrs.reserve(r->names.size());
+    for (auto& n : r->names) r->name_ptrs.push_back(n.c_str());
+    *out = r.release();
+    return RG_OK;
+}
+int64_t rg_reads_count(const rg_reads* r) { return r ? (int64_t)r->names.size() : 0; }
+const char* rg_reads_bases(const rg_reads* r) { return r ? r->bases.c_str() : nullptr; }
+const int64_t* rg_reads_offsets(const rg_reads* r) { return r ? r->off.data() : nullptr; }
+const char* const* rg_reads_names(const rg_reads* r) { return r ? r->name_ptrs.data() : nullptr; }
+void rg_reads_destroy(rg_reads* r) { delete r; }
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+
+struct Tile {
+    int64_t id = 0;                     // position in the output order
+    int64_t first = 0, n = 0;           // reads [first, first + n) of the stream
+    std::string bases;
+    std::vector<int64_t> off;           // n + 1, relative to `bases`
+    std::vector<std::string> names;     // empty: "read<first + i>"
+    // results
+    int rc = RG_OK;
+    std::string err;
+    std::string text;
+    std::vector<int64_t> text_off;
+    std::vector<uint32_t> status;
+    std::vector<int32_t> score;
+    int device = -1;
+    uint64_t cells = 0;
+    rg_batch* records = nullptr;        // keep_records: owned by the stream once delivered
+    ~Tile() { if (records) rg_batch_destroy_impl(records); }
+};
+
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+bool mode_is_pathwise(int mode) {
+    return mode == RG_MODE_PATHWISE || mode == RG_MODE_RECOMBINATION || mode == RG_MODE_PATHWISE_SEMI || mode == RG_MODE_RECOMBINATION_SEMI;
+}
+
+}  // namespace
+
+struct rg_stream {
+    const rg_graph* g = nullptr;
+    rg_params p;
+    rg_stream_opts o;
+    std::vector<int> devs;                  // one entry per device slot (a device may be listed more than once)
+    std::vector<size_t> budget;             // HBM share of one handle, per slot
+    int tile_reads = 4096;
+    int format_threads = 1;
+
+    std::mutex mu;
+    std::condition_variable cv_work, cv_done;
+    std::deque<Tile*> queue;
+    std::map<int64_t, Tile*> done;
+    int64_t tiles_pushed = 0, next_out = 0, reads_pushed = 0;
+    bool finished = false, stopping = false;
+    std::vector<std::thread> workers;
+    std::unique_ptr<Tile> cur;              // the tile rg_stream_next last returned
+    std::vector<rg_batch*> kept;            // keep_records: results-only handles of the delivered tiles
+
+    std::mutex smu;                         // statistics
+    std::vector<KernelStat> kstats;
+    double host_s[4] = {0, 0, 0, 0};        // set_reads, run, fetch, format
+    int64_t tiles_done = 0;
+    int handles_used = 0;
+    std::vector<std::string> stat_names;    // storage for rg_stream_kernel_name
+
+    ~rg_stream() {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            stopping = true;
+        }
+        cv_work.notify_all();
+        for (auto& t : workers) t.join();
+        for (Tile* t : queue) delete t;
+        for (auto& kv : done) delete kv.second;
+        for (rg_batch* b : kept) rg_batch_destroy_impl(b);
+    }
+
+    void worker(int slot) {
+        const int dev = devs[(size_t)slot];
+        if (hipSetDevice(dev) != hipSuccess) (void)hipGetLastError();    // every ABI entry selects the handle's device anyway
+        rg_batch* h = nullptr;
+        bool counted = false;
+        for (;;) {
+            Tile* t = nullptr;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv_work.wait(lk, [&] { return stopping || !queue.empty(); });
+                if (stopping) break;
+                t = queue.front();
+                queue.pop_front();
+            }
+            double ts[5];
+            ts[0] = now_s();
+            int rc;
+            if (!h) {
+                // (the handle is created on the first tile: its work buffers are sized by what it actually aligns)
+                rc = rg_batch_create(g, &p, t->bases.data(), t->off.data(), t->n, &h);
+                if (rc == RG_OK) h->mem_budget = budget[(size_t)slot];
+            } else {
+                rc = rg_batch_set_reads(h, t->bases.data(), t->off.data(), t->n);
+            }
+            ts[1] = now_s();
+            if (rc == RG_OK) rc = rg_batch_run(h);
+            ts[2] = now_s();
+            if (rc == RG_OK) rc = rg_batch_fetch(h);
+            ts[3] = now_s();
+            t->device = dev;
+            if (rc == RG_OK) {
+                t->cells = h->cells;
+                t->status.resize((size_t)t->n);
+                t->score.resize((size_t)t->n);
+                for (int64_t i = 0; i < t->n; ++i) { t->status[(size_t)i] = h->rec[(size_t)i].status & 0xffu; t->score[(size_t)i] = h->rec[(size_t)i].score; }
+                if (!o.no_text) {
+                    std::vector<const char*> np;
+                    if (!t->names.empty()) { np.reserve(t->names.size()); for (auto& s : t->names) np.push_back(s.c_str()); }
+                    format_batch(h, np.empty() ? nullptr : np.data(), t->first, o.seq_index_base + t->first, format_threads, t->text, &t->text_off);
+                } else {
+                    t->text_off.assign((size_t)t->n + 1, 0);
+                }
+                if (o.keep_records) t->records = rg_batch_detach_results(h);
+            } else {
+                t->rc = rc;
+                t->err = g_last_error;
+            }
+            ts[4] = now_s();
+            {
+                std::lock_guard<std::mutex> lk(smu);
+                for (int k = 0; k < 4; ++k) host_s[k] += ts[k + 1] - ts[k];
+                ++tiles_done;
+                if (h && !counted) { ++handles_used; counted = true; }
+                if (rc == RG_OK)
+                    for (auto& s : h->stats) {
+                        bool found = false;
+                        for (auto& a : kstats) if (a.name == s.name) { a.ms += s.ms; a.launches += s.launches; found = true; break; }
+                        if (!found) kstats.push_back(s);
+                    }
+            }
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                done[t->id] = t;
+            }
+            cv_done.notify_all();
+        }
+        if (h) rg_batch_destroy_impl(h);
+    }
+};
+
+extern "C" {
+
+void rg_stream_opts_default(rg_stream_opts* o) {
+    if (o) memset(o, 0, sizeof *o);
+    if (o) o->seq_index_base = 1;
+}
+
+int32_t rg_stream_create(const rg_graph* g, const rg_params* p, const int32_t* device_ids, int32_t ndev, const rg_stream_opts* opts,
+                         rg_stream** out) {
+    if (!g || !p || !out) return fail(RG_ERR_ARG, "null argument");
+    auto s = std::make_unique<rg_stream>();
+    s->g = g;
+    s->p = *p;
+    if (opts) s->o = *opts; else rg_stream_opts_default(&s->o);
+    const int visible = rg_device_count();
+    if (visible < 1) return fail(RG_ERR_NO_DEVICE, "no HIP device (the product has no CPU path)");
+    if (device_ids) {
+        if (ndev < 1) return fail(RG_ERR_ARG, "empty device list");
+        s->devs.assign(device_ids, device_ids + ndev);
+        for (int d : s->devs) if (d < 0 || d >= visible) return fail(RG_ERR_NO_DEVICE, "no HIP device " + std::to_string(d));
+    } else {
+        for (int d = 0; d < visible; ++d) s->devs.push_back(d);
+    }
+    const int K = s->o.handles_per_device > 0 ? std::min(s->o.handles_per_device, 8) : 3;
+    s->tile_reads = s->o.tile_reads > 0 ? s->o.tile_reads : (mode_is_pathwise(p->mode) ? 4096 : 8192);
+    const int nworkers = K * (int)s->devs.size();
+    const int hw = (int)std::max(1u, std::thread::hardware_concurrency());
+    s->format_threads = s->o.format_threads > 0 ? std::min(s->o.format_threads, 64) : std::max(1, std::min(16, hw / std::max(1, nworkers)));
+    // HBM share of one handle: what is free on its device now, split over the handles the stream runs there
+    s->budget.assign(s->devs.size(), 0);
+    for (size_t k = 0; k < s->devs.size(); ++k) {
+        DevGuard dg(s->devs[k]);
+        HIPCHK(dg.err);
+        size_t fr = 0, tot = 0;
+        HIPCHK(hipMemGetInfo(&fr, &tot));
+        const size_t same = (size_t)std::count(s->devs.begin(), s->devs.end(), s->devs[k]);
+        s->budget[k] = fr / 100 * 92 / ((size_t)K * same);
+    }
+    // the graph tables of every device are uploaded before the workers race for them (rg_batch_create takes the lock too)
+    rg_stream* sp = s.get();
+    for (size_t k = 0; k < s->devs.size(); ++k)
+        for (int j = 0; j < K; ++j) s->workers.emplace_back([sp, k] { sp->worker((int)k); });
+    *out = s.release();
+    return RG_OK;
+}
+
+int32_t rg_stream_push(rg_stream* s, const char* reads, const int64_t* read_off, int64_t nreads, const char* const* names) {
+    if (!s || !reads || !read_off || nreads < 1) return fail(RG_ERR_ARG, "null/empty argument");
+    for (int64_t r = 0; r < nreads; ++r)
+        if (read_off[r + 1] - read_off[r] < 1) return fail(RG_ERR_ARG, "empty read");
+    // Tiles: at most tile_reads reads each, even sizes; at least one tile per device slot when there are enough reads,
+    // and (several devices) a multiple of the device count so that equal tiles spread evenly.
+    const int64_t T = s->tile_reads, D = (int64_t)s->devs.size();
+    int64_t nt = (nreads + T - 1) / T;
+    nt = std::max(nt, std::min<int64_t>(D, nreads));
+    if (D > 1 && nreads >= nt + D) nt = (nt + D - 1) / D * D;
+    std::vector<Tile*> tiles;
+    for (int64_t k = 0; k < nt; ++k) {
+        const int64_t lo = nreads * k / nt, hi = nreads * (k + 1) / nt;
+        if (hi == lo) continue;
+        auto t = std::make_unique<Tile>();
+        t->n = hi - lo;
+        t->bases.assign(reads + read_off[lo], reads + read_off[hi]);
+        t->off.resize((size_t)t->n + 1);
+        for (int64_t i = 0; i <= t->n; ++i) t->off[(size_t)i] = read_off[lo + i] - read_off[lo];
+        if (names) { t->names.reserve((size_t)t->n); for (int64_t i = lo; i < hi; ++i) t->names.emplace_back(names[i] ? names[i] : ""); }
+        t->first = lo;          // relative to this push: made absolute under the lock
+        tiles.push_back(t.release());
+    }
+    {
+        std::lock_guard<std::mutex> lk(s->mu);
+        if (s->finished) {
+            for (Tile* t : tiles) delete t;
+            return fail(RG_ERR_ARG, "rg_stream_push after rg_stream_finish");
+        }
+        for (Tile* t : tiles) {
+            t->id = s->tiles_pushed++;
+            t->first += s->reads_pushed;
+            s->queue.push_back(t);
+        }
+        s->reads_pushed += nreads;
+    }
+    s->cv_work.notify_all();
+    return RG_OK;
+}
+
+int32_t rg_stream_finish(rg_stream* s) {
+    if (!s) return fail(RG_ERR_ARG, "null stream");
+    {
+        std::lock_guard<std::mutex> lk(s->mu);
+        s->finished = true;
+    }
+    s->cv_done.notify_all();
+    return RG_OK;
+}
+
+int32_t rg_stream_next(rg_stream* s, rg_stream_result* out) {
+    if (!s || !out) return fail(RG_ERR_ARG, "null argument");
+    Tile* t = nullptr;
+    {
+        std::unique_lock<std::mutex> lk(s->mu);
+        s->cv_done.wait(lk, [&] { return s->done.count(s->next_out) || (s->finished && s->next_out == s->tiles_pushed); });
+        auto it = s->done.find(s->next_out);
+        if (it == s->done.end()) return RG_STREAM_END;
+        t = it->second;
+        s->done.erase(it);
+        ++s->next_out;
+    }
+    s->cur.reset(t);
+    memset(out, 0, sizeof *out);
+    out->first_read = t->first;
+    out->nreads = t->n;
+    out->device = t->device;
+    if (t->rc != RG_OK) return fail(t->rc, "tile of reads [" + std::to_string(t->first) + ", " + std::to_string(t->first + t->n) + ") on device " +
+                                               std::to_string(t->device) + ": " + t->err);
+    out->text = t->text.c_str();
+    out->text_len = (int64_t)t->text.size();
+    out->text_off = t->text_off.data();
+    out->status = t->status.data();
+    out->score = t->score.data();
+    out->cell_updates = t->cells;
+    if (t->records) {
+        s->kept.push_back(t->records);
+        out->records = t->records;
+        t->records = nullptr;
+    }
+    return RG_OK;
+}
+
+void rg_stream_destroy(rg_stream* s) { delete s; }
+
+int32_t rg_stream_kernel_count(rg_stream* s) {
+    if (!s) return 0;
+    std::lock_guard<std::mutex> lk(s->smu);
+    return (int32_t)s->kstats.size() + 4;
+}
+static bool stream_stat(rg_stream* s, int32_t k, std::string* name, double* ms, int64_t* launches) {
+    static const char* host_names[4] = {"host:set_reads", "host:run", "host:fetch", "host:format"};
+    std::lock_guard<std::mutex> lk(s->smu);
+    const int32_t nk = (int32_t)s->kstats.size();
+    if (k < 0 || k >= nk + 4) return false;
+    if (k < nk) {
+        if (name) *name = s->kstats[(size_t)k].name;
+        if (ms) *ms = s->kstats[(size_t)k].ms;
+        if (launches) *launches = s->kstats[(size_t)k].launches;
+    } else {
+        if (name) *name = host_names[k - nk];
+        if (ms) *ms = s->host_s[k - nk] * 1e3;
+        if (launches) *launches = s->tiles_done;
+    }
+    return true;
+}
+const char* rg_stream_kernel_name(rg_stream* s, int32_t k) {
+    if (!s) return "";
+    std::string nm;
+    if (!stream_stat(s, k, &nm, nullptr, nullptr)) return "";
+    std::lock_guard<std::mutex> lk(s->smu);
+    for (auto& x : s->stat_names) if (x == nm) return x.c_str();
+    s->stat_names.reserve(64);          // (pointers handed out stay valid: never more than a few dozen names)
+    s->stat_names.push_back(nm);
+    return s->stat_names.back().c_str();
+}
+double rg_stream_kernel_ms(rg_stream* s, int32_t k) {
+    double ms = 0;
+    if (s) stream_stat(s, k, nullptr, &ms, nullptr);
+    return ms;
+}
+int64_t rg_stream_kernel_launches(rg_stream* s, int32_t k) {
+    int64_t n = 0;
+    if (s) stream_stat(s, k, nullptr, nullptr, &n);
+    return n;
+}
+int64_t rg_stream_tiles_done(rg_stream* s) {
+    if (!s) return 0;
+    std::lock_guard<std::mutex> lk(s->smu);
+    return s->tiles_done;
+}
+int32_t rg_stream_handles(rg_stream* s) {
+    if (!s) return 0;
+    std::lock_guard<std::mutex> lk(s->smu);
+    return s->handles_used;
+}
+
+// ---- all visible GPUs behind one call ("one call may use all visible GPUs") ----
+struct rg_multi {
+    rg_stream* stream = nullptr;            // owns the shards (results-only handles of its tiles)
+    std::vector<rg_batch*> shards;
+    std::vector<int64_t> begin;             // shards.size() + 1
+    ~rg_multi() { delete stream; }
+};
+
+int32_t rg_align_batch_multi(const rg_graph* g, const rg_params* p, const char* reads, const int64_t* read_off, int64_t nreads,
+                             const int32_t* device_ids, int32_t ndev, rg_multi** out) {
+    if (!g || !p || !reads || !read_off || !out || nreads < 1) return fail(RG_ERR_ARG, "null/empty argument");
+    rg_stream_opts o;
+    rg_stream_opts_default(&o);
+    o.keep_records = 1;
+    o.no_text = 1;
+    auto m = std::make_unique<rg_multi>();
+    int rc = rg_stream_create(g, p, device_ids, ndev, &o, &m->stream);
+    if (rc) return rc;
+    if ((rc = rg_stream_push(m->stream, reads, read_off, nreads, nullptr)) || (rc = rg_stream_finish(m->stream))) return rc;
+    int first_err = RG_OK;
+    std::string err;
+    for (;;) {
+        rg_stream_result r;
+        rc = rg_stream_next(m->stream, &r);
+        if (rc == RG_STREAM_END) break;
+        if (rc != RG_OK) { if (first_err == RG_OK) { first_err = rc; err = g_last_error; } continue; }   // drain: the workers finish their tiles
+        m->begin.push_back(r.first_read);
+        m->shards.push_back(r.records);
+    }
+    if (first_err != RG_OK) return fail(first_err, err);
+    m->begin.push_back(nreads);
+    *out = m.release();
+    return RG_OK;
+}
+int32_t rg_multi_shards(const rg_multi* m) { return m ? (int32_t)m->shards.size() : 0; }
+rg_batch* rg_multi_batch(const rg_multi* m, int32_t k) { return m && k >= 0 && k < (int32_t)m->shards.size() ? m->shards[(size_t)k] : nullptr; }
+int64_t rg_multi_shard_begin(const rg_multi* m, int32_t k) { return m && k >= 0 && k <= (int32_t)m->shards.size() ? m->begin[(size_t)k] : -1; }
+int64_t rg_multi_format_all(const rg_multi* m, const char* const* names, int64_t seq_index_base, char* buf, int64_t cap,
+                            int32_t nthreads) {
+    if (!m) return fail(RG_ERR_ARG, "null handle");
+    int64_t total = 0;
+    for (size_t k = 0; k < m->shards.size(); ++k) {
+        const int64_t left = buf && cap > total ? cap - total : 0;
+        const int64_t need = rg_batch_format_all(m->shards[k], names ? names + m->begin[k] : nullptr, seq_index_base + m->begin[k],
+                                                 left ? buf + total : nullptr, left, nthreads);
+        if (need < 0) return need;
+        total += need;
+    }
+    return total;
+}
+void rg_multi_destroy(rg_multi* m) { delete m; }
+
+}  // extern "C"

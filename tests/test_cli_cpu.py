@@ -23,6 +23,74 @@ def test_fasta_reader(tmp_path):
     assert len(seqs) == len(names) == 52 and all(len(s) == 150 for s in seqs)
 
 
+def test_fasta_rules_of_sequences_rs():
+    """rg_reads_from_fasta against a literal Python restatement of sequences::get_sequences (sequences.rs:5-45) on
+    hand-made and random texts: CRLF, blank lines, multi-line records, lower case, '-', names with spaces, a header
+    without bases (count mismatch -> refused), bases before the first header (paired with the names by index)."""
+    import random
+    import pytest
+    from recgraph_amd import _lib, api
+
+    def literal(text):
+        seqs, names, cur = [], [], []
+        lines = text.split("\n")
+        for k, line in enumerate(lines):
+            if k == len(lines) - 1:
+                if line == "":
+                    break               # the text ended with '\n' (or is empty): no further line
+            elif line.endswith("\r"):
+                line = line[:-1]        # BufRead::lines strips "\r\n", not a '\r' at the very end of the file
+            if not line.startswith(">") and line != "":
+                cur += ["N" if c == "-" else (c.upper() if "a" <= c <= "z" else c) for c in line]
+            elif line.startswith(">"):
+                names.append(line[1:])
+                if cur:
+                    seqs.append("".join(cur))
+                cur = []
+        if cur:
+            seqs.append("".join(cur))
+        if len(seqs) != len(names):
+            raise ValueError("wrong fasta file format")
+        return seqs, names
+
+    def lib(text):
+        r = api.Reads.from_fasta_text(text)
+        assert list(r.offsets) == [sum(len(x) for x in r.sequences()[:i]) for i in range(len(r) + 1)]
+        return r.sequences(), r.names
+
+    cases = [">a\nACGT\n", ">a b c\r\nac-gt\r\nNN\r\n\r\n>b\r\nTT", "ACGT\n>a\n>b\nGG\n", ">a\nAC\n\n\nGT\n>b\nT\n", ">\nA\n",
+             ">a\nA C\n>b\n \n"]
+    for text in cases:
+        assert lib(text) == literal(text), text
+    for text in (">a\n>b\nAC\n", "ACGT\n", ">a\n", ">a\nAC\n>b\n"):
+        with pytest.raises(ValueError):
+            literal(text)
+        with pytest.raises(_lib.RecGraphError, match="wrong fasta file format"):
+            lib(text)
+    assert lib("") == ([], []) == literal("")
+    rnd = random.Random(7)
+    for _ in range(300):
+        parts = []
+        for _ in range(rnd.randint(0, 8)):
+            kind = rnd.random()
+            if kind < 0.35:
+                parts.append(">" + "".join(rnd.choice("abc 12>") for _ in range(rnd.randint(0, 5))))
+            elif kind < 0.9:
+                parts.append("".join(rnd.choice("ACGTacgtnN-x") for _ in range(rnd.randint(0, 9))))
+            else:
+                parts.append("")
+        text = "".join(p + rnd.choice(["\n", "\r\n"]) for p in parts)
+        if rnd.random() < 0.3 and text.endswith("\n"):
+            text = text[:-1]            # (may leave a trailing '\r': it then belongs to the last line)
+        try:
+            exp = literal(text)
+        except ValueError:
+            with pytest.raises(_lib.RecGraphError):
+                lib(text)
+            continue
+        assert lib(text) == exp, repr(text)
+
+
 def test_out_file_semantics_follow_write_gaf(tmp_path):
     """utils.rs:200-219 + the numbers main.rs passes: modes 0-3 create the file at the first read and append after;
     modes 4/5/8/9 pass the 0-based index, so the file is re-created at the SECOND read (main.rs:260,268,311)."""

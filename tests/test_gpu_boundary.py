@@ -43,8 +43,9 @@ def test_result_fields_rebuild_the_gaf_line(example_gfa, example_reads):
 
 
 def test_multi_device_call_equals_one_batch(oracle):
-    """rg_align_batch_multi: contiguous shards, one host thread and stream per entry of device_ids, text in input order.
-    One GPU here: the device list names it several times (the shards then share the device and its graph tables)."""
+    """rg_align_batch_multi: the streaming engine behind one call — tiles of contiguous reads (at least one per entry of
+    device_ids) pulled by the batch handles of every listed device, text in input order.  One GPU here: the device list
+    names it several times (its handles then share the device and its graph tables)."""
     from recgraph_amd import api, synth
     sg = synth.haplotype_graph(1500, 8, path_len=300, seed=11)
     reads = synth.haplotype_reads(sg, 37, length=300, seed=12, mosaic_frac=0.5)
@@ -54,7 +55,8 @@ def test_multi_device_call_equals_one_batch(oracle):
         one, _ = api.align_batch(g, reads, names, mode=mode)
         for devs in ([0], [0, 0, 0], None):
             m = api.MultiBatch(g, reads, api.make_params(mode), device_ids=devs)
-            assert m.begin[0] == 0 and m.begin[-1] == len(reads) and len(m.shards) == (len(devs) if devs else len(m.shards))
+            assert m.begin[0] == 0 and m.begin[-1] == len(reads) and len(m.shards) >= (len(devs) if devs else 1)
+            assert m.begin == sorted(m.begin) and sum(sh.n for sh in m.shards) == len(reads)
             assert m.format_all(names, 1, 4).decode() == "".join(one), (mode, devs)
             sh, j = m.locate(20)
             assert sh.gaf_text(j, names[20], 21) == one[20]

@@ -4,6 +4,15 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
+
+def _switch(var, on):
+    """The diagnostic switches of the library (rg_set_option; the environment variables of the same names only set the
+    defaults when the library is loaded)."""
+    from recgraph_amd import api
+    api.set_option({"RG_SWEEP_I32": "sweep_i32", "RG_NO_FREC": "no_frec", "RG_THREE_SWEEPS": "three_sweeps"}[var], on)
+
+
+
 DIAMOND = ("H\tVN:Z:1.0\nS\t1\tA\nS\t2\tT\nS\t3\tC\nS\t4\tG\nL\t1\t+\t2\t+\t0M\nL\t1\t+\t3\t+\t0M\nL\t2\t+\t4\t+\t0M\n"
            "L\t3\t+\t4\t+\t0M\nP\tp0\t1+,2+,4+\t*\nP\tp1\t1+,3+,4+\t*\n")
 TWO_BUBBLES = ("S\t1\tA\nS\t2\tT\nS\t3\tC\nS\t4\tG\nS\t5\tA\nS\t6\tC\nS\t7\tT\n" +
@@ -123,7 +132,7 @@ def test_wide_and_long_shapes(oracle):
         api.align_batch(gg, ["ACGT" * 4200], None, mode=api.MODE_PATHWISE)
 
 
-def test_sweep_kernel_variants_agree(oracle, monkeypatch):
+def test_sweep_kernel_variants_agree(oracle):
     """The packed 16-bit sweep (default when the scores fit), the i32 sweep (RG_SWEEP_I32) and the Cand-list forward
     emission (RG_NO_FREC) are three implementations of the same DP: byte-identical records, all equal to the oracle.
     A matrix whose scores do not fit 16 bits must take the i32 kernel by itself."""
@@ -136,18 +145,18 @@ def test_sweep_kernel_variants_agree(oracle, monkeypatch):
         reads = [r[:180] for r in rd[:cut]] if mode in (api.MODE_RECOMBINATION_SEMI, api.MODE_PATHWISE_SEMI) else rd[:cut]
         base = _check(oracle, g.gfa(), reads, mode, om)
         for var in ("RG_SWEEP_I32", "RG_NO_FREC"):
-            monkeypatch.setenv(var, "1")
+            _switch(var, 1)
             texts, _ = api.align_batch(gg, reads, ["r%d" % i for i in range(len(reads))], mode=mode)
-            monkeypatch.delenv(var)
+            _switch(var, 0)
             assert texts == base, var
     # a narrow recombination band and very short reads (thresholds of "never" columns, rows every path visits)
     tiny = ["GG", "A", "ACG", "TTTTT", rd[0][:7], rd[1][:30]] + rd[:6]
     for mode, om in ((api.MODE_RECOMBINATION, oracle.M8_ABS), (api.MODE_RECOMBINATION_SEMI, oracle.M9_ABS)):
         base = _check(oracle, g.gfa(), tiny, mode, om, R=0, r=0.1, B=0.8)
         for var in ("RG_SWEEP_I32", "RG_NO_FREC", "RG_THREE_SWEEPS"):
-            monkeypatch.setenv(var, "1")
+            _switch(var, 1)
             texts, _ = api.align_batch(gg, tiny, ["r%d" % i for i in range(len(tiny))], mode=mode, R=0, r=0.1, B=0.8)
-            monkeypatch.delenv(var)
+            _switch(var, 0)
             assert texts == base, (var, mode)
     # scores outside the 16-bit budget: (rows on a path + read length) * max |score| > 24000
     sm = api.create_score_matrix_i32(90, -120)
@@ -158,7 +167,7 @@ def test_sweep_kernel_variants_agree(oracle, monkeypatch):
         assert texts[i] == og.align(oracle.M8_ABS, r, name="read%d" % i, scores=table)[0]
 
 
-def test_three_sweep_pipeline(oracle, monkeypatch):
+def test_three_sweep_pipeline(oracle):
     """The -m 8 / -m 9 pipeline the driver takes when a gap entry is positive (no path-0 lower bound for the forward
     thresholds: forward column maxima first, reverse sweep, forward again) or on request (RG_THREE_SWEEPS), with the
     packed 16-bit sweep and with the i32 sweep.  Same records as the two-sweep pipeline, all equal to the oracle."""
@@ -169,12 +178,12 @@ def test_three_sweep_pipeline(oracle, monkeypatch):
     names = ["r%d" % i for i in range(len(rd))]
     for mode, om, reads in ((api.MODE_RECOMBINATION, oracle.M8_ABS, rd), (api.MODE_RECOMBINATION_SEMI, oracle.M9_ABS, [r[:170] for r in rd[:14]])):
         base = _check(oracle, g.gfa(), reads, mode, om)
-        monkeypatch.setenv("RG_THREE_SWEEPS", "1")
+        _switch("RG_THREE_SWEEPS", 1)
         t16, _ = api.align_batch(gg, reads, names[:len(reads)], mode=mode)
-        monkeypatch.setenv("RG_SWEEP_I32", "1")
+        _switch("RG_SWEEP_I32", 1)
         t32, _ = api.align_batch(gg, reads, names[:len(reads)], mode=mode)
-        monkeypatch.delenv("RG_SWEEP_I32")
-        monkeypatch.delenv("RG_THREE_SWEEPS")
+        _switch("RG_SWEEP_I32", 0)
+        _switch("RG_THREE_SWEEPS", 0)
         assert t16 == base and t32 == base
     # matrices with positive gap entries (reachable through api.rs-style custom matrices only): the driver must pick
     # the three-sweep pipeline and the i32 sweep by itself.  Uniform (+1 everywhere) and non-uniform gap costs.
@@ -197,7 +206,7 @@ def test_three_sweep_pipeline(oracle, monkeypatch):
             assert texts[i] == og.align(oracle.M8_PRUNED, rd[i], name="read%d" % i, scores=table)[0]
 
 
-def test_more_than_64_paths(oracle, monkeypatch):
+def test_more_than_64_paths(oracle):
     """Path sets wider than one 64-bit word (P up to 256): groups whose members span several 64-path pages run as one
     alpha entry + continuation entries; packed and i32 sweeps, global and semiglobal, two- and three-sweep pipelines."""
     from recgraph_amd import api, synth
@@ -212,19 +221,19 @@ def test_more_than_64_paths(oracle, monkeypatch):
             base[mode] = (reads, _check(oracle, g.gfa(), reads, mode, om))
         gg = api.Graph.from_gfa_text(g.gfa())
         for var in ("RG_SWEEP_I32", "RG_THREE_SWEEPS"):
-            monkeypatch.setenv(var, "1")
+            _switch(var, 1)
             for mode in (api.MODE_RECOMBINATION, api.MODE_RECOMBINATION_SEMI):
                 reads, exp = base[mode]
                 texts, _ = api.align_batch(gg, reads, ["r%d" % i for i in range(len(reads))], mode=mode)
                 assert texts == exp, (P, var, mode)
-            monkeypatch.delenv(var)
+            _switch(var, 0)
         _check(oracle, g.gfa(), rd[:3], api.MODE_RECOMBINATION, oracle.M8_PRUNED)      # the literal restatement
         tiny = ["GG", "A", "ACG", rd[0][:9]] + rd[:4]
         exp = _check(oracle, g.gfa(), tiny, api.MODE_RECOMBINATION, oracle.M8_ABS, R=0, r=0.1, B=0.8)
         for var in ("RG_SWEEP_I32", "RG_NO_FREC", "RG_THREE_SWEEPS"):
-            monkeypatch.setenv(var, "1")
+            _switch(var, 1)
             texts, _ = api.align_batch(gg, tiny, ["r%d" % i for i in range(len(tiny))], mode=api.MODE_RECOMBINATION, R=0, r=0.1, B=0.8)
-            monkeypatch.delenv(var)
+            _switch(var, 0)
             assert texts == exp, (P, var)
 
 

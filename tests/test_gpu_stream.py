@@ -1,0 +1,164 @@
+"""GPU: the streaming engine behind the C ABI (rg_stream_*, rg_reads_from_fasta) — the pipeline bench.py times and the
+CLI runs — delivers, tile by tile and in input order, exactly the bytes of the plain one-handle batch path (which the
+other GPU tests hold equal to the oracle)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _graph_reads(n=61, seed=21):
+    from recgraph_amd import api, synth
+    sg = synth.haplotype_graph(1500, 8, path_len=300, seed=seed)
+    reads = synth.haplotype_reads(sg, n, length=300, seed=seed + 1, mosaic_frac=0.5)
+    return sg, api.Graph.from_gfa_text(sg.gfa()), reads
+
+
+def test_stream_equals_batch_in_every_mode(oracle):
+    from recgraph_amd import api
+    sg, g, reads = _graph_reads()
+    names = ["q%d" % i for i in range(len(reads))]
+    og = oracle.Graph.from_gfa_text(sg.gfa())
+    for mode, om in ((api.MODE_RECOMBINATION, oracle.M8_ABS), (api.MODE_PATHWISE, oracle.M4_ABS), (api.MODE_GLOBAL_POA, oracle.M0_SIMD),
+                     (api.MODE_GAP_POA, oracle.M2), (api.MODE_RECOMBINATION_SEMI, None), (api.MODE_LOCAL_POA, None)):
+        one, st1 = api.align_batch(g, reads, names, mode=mode)
+        if om is not None:
+            assert one[7] == og.align(om, reads[7], name=names[7], idx=8)[0]
+        for handles, tile in ((3, 8), (1, 16), (2, 1000)):
+            texts, status = api.align_stream(g, reads, names, mode=mode, device_ids=[0], handles_per_device=handles, tile_reads=tile)
+            assert texts == one and status == st1, (mode, handles, tile)
+    # default names are global: read<i>
+    texts, _ = api.align_stream(g, reads, None, mode=api.MODE_PATHWISE, device_ids=[0], tile_reads=9)
+    base, _ = api.align_batch(g, reads, None, mode=api.MODE_PATHWISE)
+    assert texts == base
+
+
+def test_stream_pushes_interleaved_with_results_and_statistics():
+    from recgraph_amd import api
+    _, g, reads = _graph_reads(n=90, seed=31)
+    one, _ = api.align_batch(g, reads, None, mode=api.MODE_RECOMBINATION)
+    st = api.Stream(g, api.make_params(api.MODE_RECOMBINATION), device_ids=[0, 0], handles_per_device=2, tile_reads=7)
+    got, firsts = [], []
+    st.push(reads[:30])
+    t = st.next()
+    got.append(t)
+    st.push(api.Batch.pack_reads(reads[30:75]))          # the packed (bytes, offsets) form
+    st.push(reads[75:])
+    st.finish()
+    got += list(st)
+    assert st.next() is None                               # RG_STREAM_END is sticky
+    for t in got:
+        firsts.append(t.first)
+        assert t.n <= 7 and t.device == 0 and t.cell_updates > 0
+        assert [t.text_of(i).decode() for i in range(t.n)] == one[t.first:t.first + t.n]
+        assert t.text == "".join(one[t.first:t.first + t.n]).encode()
+    assert firsts == sorted(firsts) and sum(t.n for t in got) == len(reads)
+    ks = st.kernel_stats()
+    assert any(k.startswith("k_sweep") for k in ks) and "host:format" in ks and 1 <= st.handles <= 4
+    nt = len(got)
+    assert all(v[1] == nt for k, v in ks.items() if k.startswith("host:"))
+    st.close()
+    with pytest.raises(api._lib.RecGraphError):
+        api.Stream(g, api.make_params(api.MODE_PATHWISE), device_ids=[99])
+
+
+def test_stream_reports_bad_reads_and_keeps_going():
+    """A read with a character outside ACGTN is flagged (the reference panics on it) and the rest of its tile is aligned;
+    an empty read is refused at the push; a tile that fails on the device (reads too long for the pathwise kernels) comes
+    back as an error from rg_stream_next and the stream moves on."""
+    from recgraph_amd import api
+    _, g, reads = _graph_reads(n=12, seed=41)
+    rd = list(reads)
+    rd[5] = rd[5][:50] + "X" + rd[5][51:]
+    st = api.Stream(g, api.make_params(api.MODE_PATHWISE), device_ids=[0], tile_reads=4)
+    with pytest.raises(api._lib.RecGraphError):
+        st.push(rd[:3] + [""])
+    st.push(rd)
+    st.push(["ACGT" * 4200])            # 16 800 bases: RG_ERR_ARG from the batch run
+    st.push(rd[:2])
+    st.finish()
+    one, _ = api.align_batch(g, reads, None, mode=api.MODE_PATHWISE)
+    seen, errors = 0, 0
+    while True:
+        try:
+            t = st.next()
+        except api._lib.RecGraphError as ex:
+            errors += 1
+            assert "16383" in str(ex)
+            continue
+        if t is None:
+            break
+        for i in range(t.n):
+            k = t.first + i
+            if k == 5:
+                assert t.status[i] & api.READ_BAD_BASE and t.text_of(i) == b""
+            elif k < 12:
+                assert t.text_of(i).decode() == one[k]
+            seen += 1
+    assert errors == 1 and seen == 14
+
+
+def test_fasta_in_gaf_out_through_the_library_and_the_cli(tmp_path, oracle, example_gfa):
+    from recgraph_amd import api
+    fa = os.path.join(ROOT, "tests", "golden", "example_reads.fa")
+    gfa = os.path.join(ROOT, "tests", "golden", "example_graph.gfa")
+    rd = api.Reads.from_fasta(fa)
+    seqs, names = rd.sequences(), rd.names
+    og = oracle.Graph.from_gfa_text(example_gfa)
+    g = api.Graph.from_gfa_text(example_gfa)
+    for mode, om in ((8, oracle.M8_ABS), (0, oracle.M0_SIMD), (4, oracle.M4_ABS)):
+        exp = "".join(og.align(om, s, name=names[i], idx=i + 1)[0] for i, s in enumerate(seqs))
+        st = api.Stream(g, api.make_params(mode), device_ids=[0], tile_reads=20)
+        st.push(rd)
+        st.finish()
+        assert b"".join(t.text for t in st).decode() == exp
+        r = subprocess.run([sys.executable, "-m", "recgraph_amd.cli", fa, gfa, "-m", str(mode), "--tile", "16"], capture_output=True,
+                           text=True, cwd=ROOT, timeout=600)
+        assert r.returncode == 0 and r.stdout == exp and r.stderr.startswith("Done in"), r.stderr[-500:]
+    # -o: modes 4+ lose record 0 (utils.rs:200-219 with the 0-based numbers of main.rs:260)
+    out = tmp_path / "o.gaf"
+    r = subprocess.run([sys.executable, "-m", "recgraph_amd.cli", fa, gfa, "-m", "4", "-o", str(out)], capture_output=True, text=True,
+                       cwd=ROOT, timeout=600)
+    assert r.returncode == 0 and r.stdout == ""
+    exp = [og.align(oracle.M4_ABS, s, name=names[i], idx=i + 1)[0] for i, s in enumerate(seqs)]
+    assert out.read_text() == "".join(exp[1:])
+
+
+def test_two_distinct_devices():
+    """The shared tile queue over two different GPUs (skipped on a one-GPU box)."""
+    from recgraph_amd import _lib, api
+    if _lib.load().rg_device_count() < 2:
+        pytest.skip("one GPU visible")
+    _, g, reads = _graph_reads(n=64, seed=51)
+    one, _ = api.align_batch(g, reads, None, mode=api.MODE_RECOMBINATION)
+    st = api.Stream(g, api.make_params(api.MODE_RECOMBINATION), device_ids=[0, 1], handles_per_device=2, tile_reads=4)
+    st.push(reads)
+    st.finish()
+    tiles = list(st)
+    assert b"".join(t.text for t in tiles).decode() == "".join(one)
+    assert {t.device for t in tiles} == {0, 1}
+    m = api.MultiBatch(g, reads, api.make_params(api.MODE_PATHWISE), device_ids=[1, 0])
+    base, _ = api.align_batch(g, reads, None, mode=api.MODE_PATHWISE)
+    assert m.format_all(["read%d" % i for i in range(len(reads))], 1, 4).decode() == "".join(base)
+
+
+def test_a_failed_set_reads_leaves_no_stale_handle():
+    """a handle whose rg_batch_set_reads was refused keeps its previous read set; run/fetch never see a
+    half-loaded one."""
+    from recgraph_amd import api
+    _, g, reads = _graph_reads(n=10, seed=61)
+    b = api.Batch(g, reads, api.make_params(api.MODE_PATHWISE))
+    b.run()
+    b.fetch()
+    before = [b.gaf_text(i, "r", i + 1) for i in range(10)]
+    with pytest.raises(api._lib.RecGraphError):
+        b.set_reads(reads[:3] + [""] + reads[3:] * 40)         # refused before anything of the handle is touched
+    b.n = 10
+    b.run()
+    b.fetch()
+    assert [b.gaf_text(i, "r", i + 1) for i in range(10)] == before

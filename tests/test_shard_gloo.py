@@ -81,12 +81,19 @@ def test_bench_launcher_runs_the_world_2_path():
     # the stub formats 'read<i>\t<16 bases>\n' per read: all 3 steps of both ranks must arrive on rank 0
     per_rank = 3 * sum(len("read%d\t" % i) + 16 + 1 for i in range(64))
     assert weak["gaf_bytes_gathered"] == 2 * per_rank
+    assert "64-read tiles" in weak["config"]["workload"]
+    # strong scaling deals WHOLE tiles to the ranks (rank 0: 2 of the 3 steps, rank 1: 1): reads per launch per rank are
+    # what they are at N = 1, and all 3 steps' text arrives on rank 0
     strong = _run_bench(["--gpus", "2", "--scaling", "strong"], {})
     assert strong["n_gpus"] == 2 and strong["scaling"] == "strong"
-    assert "64 reads/step over all GPUs" in strong["config"]["workload"]
-    assert strong["gaf_bytes_gathered"] == 3 * 2 * sum(len("read%d\t" % i) + 16 + 1 for i in range(32))
+    assert "64 reads/step over all GPUs" in strong["config"]["workload"] and "64-read tiles" in strong["config"]["workload"]
+    assert strong["gaf_bytes_gathered"] == per_rank
+    assert "gather_ms_per_step" in strong and "gather_wait_ms" in strong
     one = _run_bench([], {})
     assert one["n_gpus"] == 1 and one["gaf_bytes_gathered"] == per_rank
+    # more ranks than steps: some ranks hold no tile at all
+    few = _run_bench(["--gpus", "2", "--scaling", "strong", "--steps", "1"], {})
+    assert few["gaf_bytes_gathered"] == per_rank // 3
 
 
 def test_bench_refuses_a_world_size_it_was_not_asked_for():
@@ -98,10 +105,8 @@ def test_bench_refuses_a_world_size_it_was_not_asked_for():
 
 
 def test_bench_step_pipeline_shapes():
-    """run_steps with one handle (steps back to back), with handles served by one device thread, and with as many device
-    threads as handles: every timed step's text arrives exactly once, in order."""
+    """One handle (steps back to back) or several: every timed step's text arrives exactly once, in order."""
     per_rank = 3 * sum(len("read%d\t" % i) + 16 + 1 for i in range(64))
-    for extra in (["--handles", "1", "--device-threads", "1"], ["--handles", "2", "--device-threads", "1"],
-                  ["--handles", "3", "--device-threads", "3"], ["--handles", "3", "--device-threads", "2"]):
+    for extra in (["--handles", "1"], ["--handles", "2"], ["--handles", "3"]):
         d = _run_bench(extra, {})
         assert d["n_gpus"] == 1 and d["gaf_bytes_gathered"] == per_rank, extra

@@ -82,6 +82,7 @@ for cfg in ("C2", "C3", "C4", "C5"):
             b = json.loads([ln for ln in open(bj) if ln.startswith("{")][-1])
             reads_per_launch = b["roofline"]["reads_per_launch"]
             kbase = b["roofline"]["kernel"]
+            chash = b["roofline"].get("code_hash")
         except Exception:
             pass
     if not reads_per_launch:
@@ -93,7 +94,7 @@ for cfg in ("C2", "C3", "C4", "C5"):
             tot[cn][0] += v
             tot[cn][1] += n
     out = {"source": "profiles/%s_%s_pmc.csv (rocprofv3 --pmc, separate passes, %s reads per launch)" % (TAG, c, reads_per_launch),
-           "kernel_base": kbase, "kernels": sorted(dom), "reads_per_launch": reads_per_launch,
+           "kernel_base": kbase, "code_hash": chash, "kernels": sorted(dom), "reads_per_launch": reads_per_launch,
            "fetch_bytes_per_counter_KB": fcal, "write_bytes_per_counter_KB": wcal}
     if "FETCH_SIZE" in tot and "WRITE_SIZE" in tot:
         fb = tot["FETCH_SIZE"][0] / tot["FETCH_SIZE"][1] * fcal
