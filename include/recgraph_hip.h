@@ -262,6 +262,11 @@ void rg_stream_opts_default(rg_stream_opts* o);
 int32_t rg_stream_create(const rg_graph* g, const rg_params* p, const int32_t* device_ids, int32_t ndev,
                          const rg_stream_opts* opts, rg_stream** out);
 int32_t rg_stream_push(rg_stream* s, const char* reads, const int64_t* read_off, int64_t nreads, const char* const* names);
+/* rg_reads_from_fasta + rg_stream_push in one pass: every time tile_reads more reads are complete they are pushed, so the
+ * devices start while the rest of the text is parsed.  *nreads_out: reads pushed.  A text whose name / sequence counts
+ * differ at its end returns RG_ERR_ARG ("wrong fasta file format", sequences.rs:41-43) AFTER the complete reads before
+ * that point were pushed: the caller drops the stream. */
+int32_t rg_stream_push_fasta(rg_stream* s, const char* fasta_text, int64_t len, int64_t* nreads_out);
 int32_t rg_stream_finish(rg_stream* s);
 /* RG_OK: *out describes the next tile (pointers valid until the next rg_stream_next / rg_stream_destroy on this stream);
  * RG_STREAM_END: finished and everything delivered; negative: that tile failed. */
@@ -269,8 +274,10 @@ int32_t rg_stream_next(rg_stream* s, rg_stream_result* out);
 void rg_stream_destroy(rg_stream* s);
 /* Measurement hooks (bench.py): per-kernel device time summed over every tile so far (HIP events on the handles' own
  * streams; with several handles per device a kernel's time includes the other streams' kernels), the host phases
- * ("host:set_reads", "host:run", "host:fetch", "host:format": wall seconds summed over the worker threads) listed
- * after the kernels, tiles done, handles running per device. */
+ * ("host:set_reads", "host:run", "host:fetch", "host:format": wall milliseconds summed over the worker threads and
+ * tiles; "host:first_tile_create", "host:first_tile_run": the part of them spent on each handle's first tile, where
+ * the handle is created and its HBM work buffers are allocated; "host:context_warmup": device context creation in the
+ * worker threads at rg_stream_create) listed after the kernels, tiles done, handles that aligned a tile. */
 int32_t rg_stream_kernel_count(rg_stream* s);
 const char* rg_stream_kernel_name(rg_stream* s, int32_t k);
 double rg_stream_kernel_ms(rg_stream* s, int32_t k);

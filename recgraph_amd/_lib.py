@@ -60,7 +60,7 @@ SYMBOLS = ["rg_params_default", "rg_scores_match_mis", "rg_graph_from_gfa", "rg_
            "rg_multi_format_all", "rg_multi_destroy", "rg_last_error",
            "rg_device_count", "rg_set_device",
            "rg_reads_from_fasta", "rg_reads_count", "rg_reads_bases", "rg_reads_offsets", "rg_reads_names", "rg_reads_destroy",
-           "rg_stream_opts_default", "rg_stream_create", "rg_stream_push", "rg_stream_finish", "rg_stream_next",
+           "rg_stream_opts_default", "rg_stream_create", "rg_stream_push", "rg_stream_push_fasta", "rg_stream_finish", "rg_stream_next",
            "rg_stream_destroy", "rg_stream_kernel_count", "rg_stream_kernel_name", "rg_stream_kernel_ms",
            "rg_stream_kernel_launches", "rg_stream_tiles_done", "rg_stream_handles", "rg_set_option", "rg_get_option"]
 
@@ -140,6 +140,7 @@ def load():
     l.rg_stream_opts_default.argtypes = [P(StreamOpts)]
     l.rg_stream_create.argtypes = [vp, P(Params), P(i32), i32, P(StreamOpts), P(vp)]
     l.rg_stream_push.argtypes = [vp, vp, P(i64), i64, P(C.c_char_p)]
+    l.rg_stream_push_fasta.argtypes = [vp, C.c_char_p, i64, P(i64)]
     l.rg_stream_finish.argtypes = [vp]
     l.rg_stream_next.argtypes = [vp, P(StreamResult)]
     l.rg_stream_destroy.argtypes = [vp]

@@ -15,10 +15,20 @@ Everything is computed by ``librecgraph_hip.so`` on the GPU; nothing here falls 
 import ctypes as C
 from dataclasses import dataclass, field
 
-import numpy as np
-
 from . import _lib
 from ._lib import Params, check
+
+
+
+class _LazyNumpy:
+    """numpy is imported at first use: the CLI's streaming path starts without it (200 ms of a 3 s job)."""
+
+    def __getattr__(self, name):
+        import numpy
+        return getattr(numpy, name)
+
+
+np = _LazyNumpy()
 
 ALPHABET = "ACGTN-"
 SCORE_MISSING = -536870912
@@ -495,6 +505,13 @@ class Stream:
         arr = (C.c_char_p * n)(*[x.encode() for x in names]) if names is not None else None
         check(lib.rg_stream_push(self._h, blob, offs.ctypes.data_as(C.POINTER(C.c_int64)), n, arr))
         return n
+
+    def push_fasta(self, text):
+        """rg_stream_push_fasta: FASTA text (bytes) parsed inside the library (sequences.rs:5-45), its reads pushed tile by
+        tile while the rest is parsed.  Returns the number of reads."""
+        n = C.c_int64(0)
+        check(_lib.load().rg_stream_push_fasta(self._h, text, len(text), C.byref(n)))
+        return n.value
 
     def finish(self):
         check(_lib.load().rg_stream_finish(self._h))

@@ -60,13 +60,20 @@ def build_parser():
     p.add_argument("--devices", default="", help="comma-separated HIP device ids (default: every visible device)")
     p.add_argument("--handles", type=int, default=0, help="batch handles per device (default 3)")
     p.add_argument("--tile", type=int, default=0, help="reads per tile (default 4096 pathwise / 8192 POA)")
+    p.add_argument("--timing", action="store_true", help="phase timings as one JSON line on stderr")
     return p
 
 
 def main(argv=None):
     t0 = time.time()
     a = build_parser().parse_args(argv)
+    phases = {}
+
+    def mark(name, since):
+        phases[name] = round(time.time() - since, 3)
+        return time.time()
     from . import api
+    tp = mark("import", t0)
     if a.alignment_mode not in (0, 1, 2, 3, 4, 5, 8, 9):
         raise SystemExit("Alignment mode must be in [0..5] or [8, 9]")   # main.rs:315-317
     amb = a.amb_strand == "true" and a.alignment_mode in (0, 1, 2, 3)     # modes 4+ ignore -s (main.rs:254-313)
@@ -74,11 +81,17 @@ def main(argv=None):
         scores = api.create_score_matrix_i32(a.match_score, -a.mismatch_score)   # args_parser.rs:155
     else:
         scores = api.create_score_matrix_i32(matrix_file_path=a.matrix if a.matrix.endswith(".mtx") else a.matrix + ".mtx")
-    try:
-        reads = api.Reads.from_fasta(a.sequence_path)        # sequences.rs:5-45 inside the library
-    except api._lib.RecGraphError as ex:
-        raise SystemExit(str(ex).split(": ", 1)[-1])
+    with open(a.sequence_path, "rb") as f:
+        fasta = f.read()
+    tp = mark("fasta_read", tp)
+
+    def parse_reads():
+        try:
+            return api.Reads.from_fasta_text(fasta)          # sequences.rs:5-45 inside the library
+        except api._lib.RecGraphError as ex:
+            raise SystemExit(str(ex).split(": ", 1)[-1])     # "wrong fasta file format" (:41-43)
     g = api.Graph.from_gfa(a.graph_path)
+    tp = mark("graph", tp)
     mode = {0: api.MODE_GLOBAL_POA_SCALAR if a.scalar else api.MODE_GLOBAL_POA, 2: api.MODE_GAP_POA,
             1: api.MODE_LOCAL_POA_SCALAR if a.scalar else api.MODE_LOCAL_POA, 3: api.MODE_GAP_LOCAL_POA,
             4: api.MODE_PATHWISE, 5: api.MODE_PATHWISE_SEMI, 8: api.MODE_RECOMBINATION,
@@ -108,6 +121,7 @@ def main(argv=None):
             raise SystemExit("read %d (%s): the reference panics on this input" % (first + bad[0], names[first + bad[0]]))
 
     if amb:
+        reads = parse_reads()
         names = reads.names
         texts, status = api.align_batch(g, reads.sequences(), names, mode=mode, amb_strand=True, **kw)
         panics(0, status, names)
@@ -117,21 +131,33 @@ def main(argv=None):
         # into tiles that the batch handles of every visible GPU (or --devices) pull from one queue; text in input order
         devs = [int(x) for x in a.devices.split(",")] if a.devices else None
         st = api.Stream(g, api.make_params(mode, **kw), device_ids=devs, handles_per_device=a.handles, tile_reads=a.tile)
-        st.push(reads)
+        tp = mark("stream_create", tp)
+        try:
+            st.push_fasta(fasta)       # parsed inside the library; tiles start on the devices while the rest is parsed
+        except api._lib.RecGraphError as ex:
+            raise SystemExit(str(ex).split(": ", 1)[-1])
         st.finish()
-        names = None
+        tp = mark("parse_and_push", tp)
         for t in st:
+            if "first_tile" not in phases:
+                mark("first_tile", tp)
             if (t.status & (api.READ_WOULD_PANIC | api.READ_BAD_BASE)).any():
-                names = names or reads.names
-                panics(t.first, [int(x) for x in t.status], names)
+                panics(0, [0] * t.first + [int(x) for x in t.status], parse_reads().names)
             if to_file:
                 emit(t.first, [t.text_of(i).decode() for i in range(t.n)])
             else:
                 sys.stdout.buffer.write(t.text)
+        tp = mark("all_tiles", tp)
+        phases["kernels_ms"] = {k: round(v[0], 1) for k, v in st.kernel_stats().items()}
         st.close()
+        tp = mark("stream_close", tp)
     sys.stdout.flush()
     if to_file:
         write_gaf_records(a.out_file, records, numbers)
+    if a.timing:
+        import json
+        phases["total"] = round(time.time() - t0, 3)
+        sys.stderr.write(json.dumps(phases) + "\n")
     sys.stderr.write("Done in %d.\n" % int(time.time() - t0))    # main.rs:319-323
 
 

@@ -32,6 +32,7 @@ Options& options() {
         o.three_sweeps = env("RG_THREE_SWEEPS");
         o.no_frec = env("RG_NO_FREC");
         o.debug = env("RG_DEBUG");
+        { const char* v = getenv("RG_CHUNK_READS"); o.chunk_reads = v ? atoi(v) : 0; }
     });
     return o;
 }
@@ -291,12 +292,13 @@ static std::atomic<int>* option_slot(const char* name) {
     if (!strcmp(name, "three_sweeps")) return &o.three_sweeps;
     if (!strcmp(name, "no_frec")) return &o.no_frec;
     if (!strcmp(name, "debug")) return &o.debug;
+    if (!strcmp(name, "chunk_reads")) return &o.chunk_reads;
     return nullptr;
 }
 int32_t rg_set_option(const char* name, int64_t value) {
     std::atomic<int>* s = option_slot(name);
     if (!s) return fail(RG_ERR_ARG, std::string("unknown option ") + (name ? name : "(null)"));
-    *s = value ? 1 : 0;
+    *s = s == &options().chunk_reads ? (int)std::max<int64_t>(0, std::min<int64_t>(value, 1 << 20)) : (value ? 1 : 0);
     return RG_OK;
 }
 int64_t rg_get_option(const char* name) {

@@ -22,6 +22,7 @@ struct Options {
     std::atomic<int> three_sweeps{0};   // RG_THREE_SWEEPS: force the three-sweep -m 8 pipeline
     std::atomic<int> no_frec{0};        // RG_NO_FREC: Cand-list forward emission instead of records
     std::atomic<int> debug{0};          // RG_DEBUG: candidate / record statistics on stderr
+    std::atomic<int> chunk_reads{0};    // RG_CHUNK_READS: most reads one pathwise kernel launch takes (0: what the HBM budget allows, <= 8192)
 };
 Options& options();
 

@@ -5,6 +5,7 @@
 //   -m 8:  sweep(F1: column maxima) -> seed -> thr -> sweep(R: dirs, candidates, column maxima)
 //          -> thr -> sweep(F2: dirs, candidates) -> search -> layer(F) -> layer(R) -> trace
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -252,7 +253,7 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
     // (row, lane) records that k_expand filters with the final bound; k_sweep writes plain Cand entries
     const bool use_rec = two_sweep && use16 && !opt.no_frec;
     const int recw = 4 + C;
-    if (w.fcap == 0) { w.fcap = (two_sweep && !use_rec) ? 1u << 20 : 1u << 15; w.rcap = use_rec ? 1u << 16 : 1u << 19; w.frec_cap = 1u << 16; w.rrec_cap = 1u << 14; }
+    if (w.fcap == 0) { w.fcap = (two_sweep && !use_rec) ? 1u << 20 : 1u << 15; w.rcap = use_rec ? 1u << 16 : 1u << 19; w.frec_cap = 1u << 16; w.rrec_cap = 1u << 15; }   // (reverse records at config 5: mean 2.7 k, largest read of a 4096-read tile 21-25 k)
     stats.clear();
     Timer T{&w, stream};
     int done = 0;
@@ -263,6 +264,8 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
         const size_t per_read_all = per_read + (mode == RG_MODE_RECOMBINATION ? ((size_t)w.fcap * sizeof(Cand) + (size_t)w.rcap * (sizeof(Cand) + 4) +
                                                                                      (use_rec ? (size_t)(w.frec_cap + w.rrec_cap) * recw * 4 : 0)) : 0);
         int maxchunk = (int)std::min<size_t>(8192, std::max<size_t>(1, budget / per_read_all));
+        if (opt.chunk_reads > 0) maxchunk = std::min<int>(maxchunk, opt.chunk_reads);
+        const double dbg_t0 = debug ? std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() : 0;
         const int left = nreads - done;
         const int nchunks = (left + maxchunk - 1) / maxchunk;
         int chunk = (left + nchunks - 1) / nchunks;   // even chunks: no short tail launch
@@ -284,6 +287,8 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
         }
         const uint8_t* bad = d_bad + done;
         const long long* off = d_off + done;
+        if (debug) fprintf(stderr, "[rg] chunk of %d reads: buffers ready after %.1f ms\n", chunk,
+                           (std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() - dbg_t0) * 1e3);
         HIPCHK(hipMemsetAsync(w.state.p, 0, sizeof(ReadState) * chunk, stream));
         SweepArgs sa;
         memset(&sa, 0, sizeof sa);
@@ -383,6 +388,8 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
         HIPCHK(hipMemcpyAsync(w.h_sum, d_cells, sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
         HIPCHK(hipMemcpyAsync(w.h_sum + 1, w.need.p, 4 * sizeof(unsigned), hipMemcpyDeviceToHost, stream));
         if ((rc = T.collect(stats))) return rc;
+        if (debug) fprintf(stderr, "[rg] chunk of %d reads: done after %.1f ms\n", chunk,
+                           (std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() - dbg_t0) * 1e3);
         if (memset_err != hipSuccess) return fail(RG_ERR_HIP, std::string("hipMemsetAsync: ") + hipGetErrorString(memset_err));
         if (mode == RG_MODE_RECOMBINATION) {
             // candidate-list / record-list overflow: regrow and redo this chunk (k_layer / k_trace skipped its reads)

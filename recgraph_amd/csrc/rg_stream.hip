@@ -29,16 +29,18 @@ struct rg_reads {
     std::vector<const char*> name_ptrs;
 };
 
-extern "C" {
-
-int32_t rg_reads_from_fasta(const char* text, int64_t len, rg_reads** out) {
-    if (!text || !out || len < 0) return fail(RG_ERR_ARG, "null argument");
-    auto r = std::make_unique<rg_reads>();
-    r->bases.reserve((size_t)len);
-    r->off.push_back(0);
+// Incremental form of the parser: `emit(first, count)` is called whenever `batch` more reads are complete (read i is
+// complete once sequence i is closed AND name i exists: the reference pairs the two lists by index) and once more at the
+// end for the rest.  Returns false ("wrong fasta file format") when the counts differ at the end of the text.
+template <typename Emit>
+static bool parse_fasta(const char* text, int64_t len, rg_reads& r, int64_t batch, Emit&& emit) {
+    r.bases.reserve((size_t)len);
+    r.off.push_back(0);
     // the reference pushes a name at every header and a sequence whenever the one being collected is non-empty at the
     // next header / at the end of the file; the two lists are paired by index afterwards (:41-43 panics when the counts differ)
-    size_t cur_begin = 0;               // start of the sequence being collected inside r->bases
+    size_t cur_begin = 0;               // start of the sequence being collected inside r.bases
+    int64_t emitted = 0;
+    auto ready = [&] { return std::min<int64_t>((int64_t)r.off.size() - 1, (int64_t)r.names.size()); };
     const char* p = text;
     const char* end = text + len;
     while (p < end) {
@@ -48,20 +50,31 @@ int32_t rg_reads_from_fasta(const char* text, int64_t len, rg_reads** out) {
         if (nl && q > p && q[-1] == '\r') --q;              // BufRead::lines drops "\n" or "\r\n" (a '\r' at the very end stays)
         if (q > p) {                                        // empty lines are skipped (:14)
             if (*p == '>') {
-                r->names.emplace_back(p + 1, q);
-                if (r->bases.size() > cur_begin) { r->off.push_back((int64_t)r->bases.size()); cur_begin = r->bases.size(); }
+                r.names.emplace_back(p + 1, q);
+                if (r.bases.size() > cur_begin) { r.off.push_back((int64_t)r.bases.size()); cur_begin = r.bases.size(); }
+                if (batch > 0 && ready() - emitted >= batch) { emit(emitted, batch); emitted += batch; }
             } else {
                 for (const char* c = p; c < q; ++c) {
                     const unsigned char ch = (unsigned char)*c;
                     // '-' -> 'N', ASCII upper-casing (char::to_ascii_uppercase leaves everything else alone)
-                    r->bases.push_back(ch == '-' ? 'N' : (ch >= 'a' && ch <= 'z') ? (char)(ch - 32) : (char)ch);
+                    r.bases.push_back(ch == '-' ? 'N' : (ch >= 'a' && ch <= 'z') ? (char)(ch - 32) : (char)ch);
                 }
             }
         }
         p = nl ? nl + 1 : end;
     }
-    if (r->bases.size() > cur_begin) r->off.push_back((int64_t)r->bases.size());
-    if (r->off.size() - 1 != r->names.size()) return fail(RG_ERR_ARG, "wrong fasta file format");
+    if (r.bases.size() > cur_begin) r.off.push_back((int64_t)r.bases.size());
+    if (r.off.size() - 1 != r.names.size()) return false;
+    if (ready() > emitted) emit(emitted, ready() - emitted);
+    return true;
+}
+
+extern "C" {
+
+int32_t rg_reads_from_fasta(const char* text, int64_t len, rg_reads** out) {
+    if (!text || !out || len < 0) return fail(RG_ERR_ARG, "null argument");
+    auto r = std::make_unique<rg_reads>();
+    if (!parse_fasta(text, len, *r, 0, [](int64_t, int64_t) {})) return fail(RG_ERR_ARG, "wrong fasta file format");
     r->name_ptrs.reserve(r->names.size());
     for (auto& n : r->names) r->name_ptrs.push_back(n.c_str());
     *out = r.release();
@@ -127,6 +140,7 @@ struct rg_stream {
     std::mutex smu;                         // statistics
     std::vector<KernelStat> kstats;
     double host_s[4] = {0, 0, 0, 0};        // set_reads, run, fetch, format
+    double first_s[3] = {0, 0, 0};          // the same phases of every handle's FIRST tile (handle creation, buffer allocation) + context warm-up
     int64_t tiles_done = 0;
     int handles_used = 0;
     std::vector<std::string> stat_names;    // storage for rg_stream_kernel_name
@@ -148,6 +162,13 @@ struct rg_stream {
         if (hipSetDevice(dev) != hipSuccess) (void)hipGetLastError();    // every ABI entry selects the handle's device anyway
         rg_batch* h = nullptr;
         bool counted = false;
+        {
+            // device context of this thread's device now, while the caller still parses / pushes its reads
+            const double w0 = now_s();
+            (void)hipFree(nullptr);
+            std::lock_guard<std::mutex> lk(smu);
+            first_s[2] += now_s() - w0;
+        }
         for (;;) {
             Tile* t = nullptr;
             {
@@ -195,7 +216,7 @@ struct rg_stream {
                 std::lock_guard<std::mutex> lk(smu);
                 for (int k = 0; k < 4; ++k) host_s[k] += ts[k + 1] - ts[k];
                 ++tiles_done;
-                if (h && !counted) { ++handles_used; counted = true; }
+                if (h && !counted) { ++handles_used; counted = true; first_s[0] += ts[1] - ts[0]; first_s[1] += ts[2] - ts[1]; }
                 if (rc == RG_OK)
                     for (auto& s : h->stats) {
                         bool found = false;
@@ -299,6 +320,25 @@ int32_t rg_stream_push(rg_stream* s, const char* reads, const int64_t* read_off,
     return RG_OK;
 }
 
+int32_t rg_stream_push_fasta(rg_stream* s, const char* fasta_text, int64_t len, int64_t* nreads_out) {
+    if (!s || !fasta_text || len < 0) return fail(RG_ERR_ARG, "null argument");
+    rg_reads r;
+    int rc = RG_OK;
+    int64_t total = 0;
+    // tiles go to the workers while the rest of the text is still being parsed
+    const bool ok = parse_fasta(fasta_text, len, r, s->tile_reads, [&](int64_t first, int64_t count) {
+        if (rc != RG_OK) return;
+        std::vector<const char*> names((size_t)count);
+        for (int64_t i = 0; i < count; ++i) names[(size_t)i] = r.names[(size_t)(first + i)].c_str();
+        rc = rg_stream_push(s, r.bases.data(), r.off.data() + first, count, names.data());
+        if (rc == RG_OK) total += count;
+    });
+    if (nreads_out) *nreads_out = total;
+    if (rc != RG_OK) return rc;
+    if (!ok) return fail(RG_ERR_ARG, "wrong fasta file format");
+    return RG_OK;
+}
+
 int32_t rg_stream_finish(rg_stream* s) {
     if (!s) return fail(RG_ERR_ARG, "null stream");
     {
@@ -347,21 +387,22 @@ void rg_stream_destroy(rg_stream* s) { delete s; }
 int32_t rg_stream_kernel_count(rg_stream* s) {
     if (!s) return 0;
     std::lock_guard<std::mutex> lk(s->smu);
-    return (int32_t)s->kstats.size() + 4;
+    return (int32_t)s->kstats.size() + 7;
 }
 static bool stream_stat(rg_stream* s, int32_t k, std::string* name, double* ms, int64_t* launches) {
-    static const char* host_names[4] = {"host:set_reads", "host:run", "host:fetch", "host:format"};
+    static const char* host_names[7] = {"host:set_reads", "host:run", "host:fetch", "host:format", "host:first_tile_create",
+                                        "host:first_tile_run", "host:context_warmup"};
     std::lock_guard<std::mutex> lk(s->smu);
     const int32_t nk = (int32_t)s->kstats.size();
-    if (k < 0 || k >= nk + 4) return false;
+    if (k < 0 || k >= nk + 7) return false;
     if (k < nk) {
         if (name) *name = s->kstats[(size_t)k].name;
         if (ms) *ms = s->kstats[(size_t)k].ms;
         if (launches) *launches = s->kstats[(size_t)k].launches;
     } else {
         if (name) *name = host_names[k - nk];
-        if (ms) *ms = s->host_s[k - nk] * 1e3;
-        if (launches) *launches = s->tiles_done;
+        if (ms) *ms = (k - nk < 4 ? s->host_s[k - nk] : s->first_s[k - nk - 4]) * 1e3;
+        if (launches) *launches = k - nk < 4 ? s->tiles_done : s->handles_used;
     }
     return true;
 }
