@@ -250,7 +250,7 @@ def cpu_legs(args, mode, gfa, reads, first, gpu_text_of, cores, pool):
     v1, n1, s1, _, f1 = leg(max(4, int(5.0 / per_read)), 1)
     sweep = [{"threads": 1, "reads_per_s": round(v1, 3), "reads": n1, "secs": round(s1, 2), "per_thread_efficiency": 1.0,
               "minor_faults_per_read": round(f1)}]
-    for T in sorted({max(1, cores // 8), max(1, cores // 4), max(1, cores // 2), cores}):
+    for T in sorted({max(1, cores // 4), max(1, cores // 2), cores, nw}):
         if T == 1 or T > nw:
             continue
         v, n, s, slowest, flt = leg(max(2, int(3.0 / per_read)), T)
@@ -260,7 +260,7 @@ def cpu_legs(args, mode, gfa, reads, first, gpu_text_of, cores, pool):
     best = max(sweep, key=lambda e: e["reads_per_s"])
     cpu = {"value": best["reads_per_s"], "unit": "reads/s", "cores": best["threads"], "kind": "port",
            "sample": "%s; reads of the last timed step; best of a sweep over %s single-threaded worker processes (forked before "
-                     "the GPU was touched, one per CPU, pinned) on %d host CPUs (%d reads, %.1f s)"
+                     "the GPU was touched, pinned to distinct CPUs) with %d usable host CPUs (%d reads, %.1f s)"
                      % (what, [e["threads"] for e in sweep], cores, best["reads"], best["secs"]),
            "single_thread": {"value": round(v1, 4), "unit": "reads/s", "reads": n1, "secs": round(s1, 2)},
            "all_cores": {"value": best["reads_per_s"], "unit": "reads/s", "threads": best["threads"]},
@@ -410,6 +410,29 @@ class StepGather:
             self.err = ex
 
 
+def cpu_limit():
+    """(CPUs this process may use, description): the scheduler affinity capped by the cgroup CPU quota.  The GPU boxes
+    of this pool show 256 CPUs and carry a quota of 16 (cpu.max "1600000 100000"): beyond 16 busy threads the container is
+    throttled, which is what flattened the thread sweeps of earlier rounds at ~40 reads/s."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    why = "%d CPUs in the affinity mask" % n
+    for path, parse in (("/sys/fs/cgroup/cpu.max", lambda t: t.split()),
+                        ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", lambda t: [t.strip(), open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read().strip()])):
+        try:
+            q, per = parse(open(path).read())
+            if q != "max" and int(q) > 0:
+                lim = max(1, -(-int(q) // int(per)))
+                if lim < n:
+                    n, why = lim, "cgroup CPU quota %s/%s = %d CPUs (of %d visible)" % (q, per, lim, os.cpu_count() or 0)
+            break
+        except (OSError, ValueError):
+            continue
+    return n, why
+
+
 def code_hash():
     """sha256 over the kernel sources: profiles/counters_*.json carry the hash of the tree they were measured on."""
     h = hashlib.sha256()
@@ -432,7 +455,7 @@ def main():
         sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d\n" % (args.gpus, world))
         sys.exit(2)
     stub = os.environ.get("RG_BENCH_STUB") == "1"
-    cores = os.cpu_count() or 1
+    cores, cores_why = cpu_limit()
     # the CPU legs' worker processes: forked NOW, before torch / HIP are imported into this process
     pool = None
     want_cpu = rank == 0 and not args.no_cpu and not stub
@@ -442,7 +465,7 @@ def main():
         O.build()
         oracle_build = O.use_native() or "portable liboracle.so (g++ -O2): the native build failed"
     if want_cpu and world == 1 and args.cpu_reads != 0:
-        pool = CpuPool(cores)
+        pool = CpuPool(2 * cores if cores < (os.cpu_count() or 1) else cores)     # (one leg oversubscribes a quota: shown, not used)
     elif want_cpu:
         pool = CpuPool(max(1, min(8, cores // max(1, world))))      # parity gate only
     import torch
@@ -708,6 +731,7 @@ def main():
             rc = 3
     if cpu is not None:
         cpu["build"] = oracle_build
+        cpu["host_cpus"] = {"usable": cores, "visible": os.cpu_count(), "limit": cores_why}
     out["cpu_baseline"] = cpu
     print(json.dumps(out), flush=True)
     sys.exit(rc)

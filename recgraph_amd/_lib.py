@@ -4,7 +4,8 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "librecgraph_hip.so")
+# RG_LIB_PATH: another build of the same library (timing-only kernel variants of tools/sweep_variants.sh); never set in tests
+_SO = os.environ.get("RG_LIB_PATH") or os.path.join(_HERE, "librecgraph_hip.so")
 
 
 class RecGraphError(RuntimeError):

@@ -11,9 +11,13 @@
 // balance without a static split; the small latency-bound kernels of one tile run beside the sweeps of the other
 // handles' tiles, and all host work of a tile overlaps the device work of the others.  There is no CPU fallback:
 // rg_stream_create fails with RG_ERR_NO_DEVICE when no HIP device is usable.
+#include <sched.h>
+
 #include <algorithm>
 #include <chrono>
 #include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <thread>
@@ -111,6 +115,24 @@ struct Tile {
 };
 
 double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// CPUs this process may actually use: hardware threads capped by the scheduler affinity and by a cgroup CPU quota (a
+// container that shows 256 CPUs and carries a quota of 16 is throttled beyond 16 busy threads).
+int usable_cpus() {
+    int n = (int)std::max(1u, std::thread::hardware_concurrency());
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) n = std::min(n, std::max(1, CPU_COUNT(&set)));
+    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char q[32] = {0};
+        long long per = 0;
+        if (fscanf(f, "%31s %lld", q, &per) == 2 && strcmp(q, "max") != 0 && per > 0) {
+            const long long lim = (atoll(q) + per - 1) / per;
+            if (lim >= 1) n = (int)std::min<long long>(n, lim);
+        }
+        fclose(f);
+    }
+    return n;
+}
 
 bool mode_is_pathwise(int mode) {
     return mode == RG_MODE_PATHWISE || mode == RG_MODE_RECOMBINATION || mode == RG_MODE_PATHWISE_SEMI || mode == RG_MODE_RECOMBINATION_SEMI;
@@ -260,7 +282,7 @@ int32_t rg_stream_create(const rg_graph* g, const rg_params* p, const int32_t* d
     const int K = s->o.handles_per_device > 0 ? std::min(s->o.handles_per_device, 8) : 3;
     s->tile_reads = s->o.tile_reads > 0 ? s->o.tile_reads : (mode_is_pathwise(p->mode) ? 4096 : 8192);
     const int nworkers = K * (int)s->devs.size();
-    const int hw = (int)std::max(1u, std::thread::hardware_concurrency());
+    const int hw = usable_cpus();
     s->format_threads = s->o.format_threads > 0 ? std::min(s->o.format_threads, 64) : std::max(1, std::min(16, hw / std::max(1, nworkers)));
     // HBM share of one handle: what is free on its device now, split over the handles the stream runs there
     s->budget.assign(s->devs.size(), 0);

@@ -154,6 +154,18 @@ struct RowOps16 {
 #ifndef RG_SWEEP16_KRUN
 #define RG_SWEEP16_KRUN 4
 #endif
+// TIMING-ONLY build variants (tools/sweep_variants.sh; the results of such a build are garbage and nothing ships them):
+//   RG_SWEEP16_NOROWS   no rolling-row load / store in the main loop (rows stay whatever the registers hold)
+//   RG_SWEEP16_NOKEYS   the best-member keys are not built (row_end runs on constant keys)
+//   RG_SWEEP16_NOEMIT   row_end stops after the column maxima (no threshold tests, ballots, record / Cand stores)
+//   RG_SWEEP16_NODIRS   no direction-word stores
+#ifdef RG_SWEEP16_NOROWS
+#define RG_ROW_LD(dst, expr) (dst) = (dst)
+#define RG_ROW_ST(expr, v) ((void)0)
+#else
+#define RG_ROW_LD(dst, expr) (dst) = (expr)
+#define RG_ROW_ST(expr, v) (expr) = (v)
+#endif
 
 // kColmax = false: no per-column maxima (the reverse sweep of the record pipeline: its maxima and their cells are
 // taken from its own records by k_colmax_rec)
@@ -269,6 +281,9 @@ __global__ __launch_bounds__(64, 2) void k_sweep16(SweepArgs a) {
                 crow[kColmax ? q : 0] = better ? i : crow[kColmax ? q : 0];
             }
         }
+#ifdef RG_SWEEP16_NOEMIT
+        return;
+#endif
         // tight thresholds (reverse sweep): most rows emit nothing; one max3 tree against the lane's lowest threshold
         // decides for the whole wave whether the per-column test is needed
         bool test = true;
@@ -341,6 +356,9 @@ __global__ __launch_bounds__(64, 2) void k_sweep16(SweepArgs a) {
     // direction words, format 1 (LayerArgs::dir_fmt): C <= 16: one word per lane, U bits of the C columns in the low
     // half and L bits in the high half; C = 32: word 0 = U bits, word 1 = L bits (the masks already are in column order)
     auto store_dirs = [&](int slot, unsigned umask, unsigned lmask) {
+#ifdef RG_SWEEP16_NODIRS
+        return;
+#endif
         if (C <= 16) {
             const unsigned u16 = (umask & ((1u << H) - 1u)) | ((umask >> (16 - H)) & (((1u << H) - 1u) << H));
             const unsigned l16 = (lmask & ((1u << H) - 1u)) | ((lmask >> (16 - H)) & (((1u << H) - 1u) << H));
@@ -402,6 +420,9 @@ __global__ __launch_bounds__(64, 2) void k_sweep16(SweepArgs a) {
     // The path id goes through a VGPR: a gfx9 VALU instruction takes one scalar operand, so (row & 0xffff0000) | k
     // is a single v_and_or_b32 only if the mask is the scalar and k a vector register.
     auto set_keys = [&](int (&bkey)[C], const int (&row)[H], int ks) {   // first member of a row: no reset + max
+#ifdef RG_SWEEP16_NOKEYS
+        return;
+#endif
         int k = ks;
         asm volatile("" : "+v"(k));
 #pragma unroll
@@ -411,6 +432,9 @@ __global__ __launch_bounds__(64, 2) void k_sweep16(SweepArgs a) {
         }
     };
     auto fold_keys = [&](int (&bkey)[C], const int (&row)[H], int ks) {
+#ifdef RG_SWEEP16_NOKEYS
+        return;
+#endif
         int k = ks;
         asm volatile("" : "+v"(k));
 #pragma unroll
@@ -423,6 +447,10 @@ __global__ __launch_bounds__(64, 2) void k_sweep16(SweepArgs a) {
 
     int s[H];
     int bkey[C];
+#ifdef RG_SWEEP16_NOKEYS
+#pragma unroll
+    for (int q = 0; q < C; ++q) bkey[q] = lane * C + q - 40000;
+#endif
     int MU[H], ML[H], SEL[H];
     unsigned lmask = 0;                  // L mask and fill-forward source lane of the current group's alpha: live across
     int src = 0;                         // the continuation entries of a group that spans 64-path pages
@@ -453,7 +481,7 @@ __global__ __launch_bounds__(64, 2) void k_sweep16(SweepArgs a) {
             for (int kk = 0; kk < KRUN; ++kk)
                 if (kk < nm) {
 #pragma unroll
-                    for (int r = 0; r < H; ++r) rr[kk][r] = rows[(long long)mk[kk] * wrow + r * WAVE + lane];
+                    for (int r = 0; r < H; ++r) { rr[kk][r] = 0; RG_ROW_LD(rr[kk][r], rows[(long long)mk[kk] * wrow + r * WAVE + lane]); }
                 }
             int ri = i, rli = li, rslot = slot, rw1 = w1;
             while (true) {
@@ -492,7 +520,7 @@ __global__ __launch_bounds__(64, 2) void k_sweep16(SweepArgs a) {
             for (int kk = 0; kk < KRUN; ++kk)
                 if (kk < nm) {
 #pragma unroll
-                    for (int r = 0; r < H; ++r) rows[(long long)mk[kk] * wrow + r * WAVE + lane] = rr[kk][r];
+                    for (int r = 0; r < H; ++r) RG_ROW_ST(rows[(long long)mk[kk] * wrow + r * WAVE + lane], rr[kk][r]);
                 }
             continue;
         }
@@ -506,22 +534,26 @@ __global__ __launch_bounds__(64, 2) void k_sweep16(SweepArgs a) {
             unsigned long long rest = cont ? gmask : gmask & ~(1ull << (ga - kbase));
             cells += (unsigned long long)nm;
             int nxt[H];
+#ifdef RG_SWEEP16_NOROWS
+#pragma unroll
+            for (int r = 0; r < H; ++r) nxt[r] = s[r] ^ t;
+#endif
             int knext = -1;
             if (rest) {
                 knext = kbase + __builtin_ctzll(rest);
                 rest &= rest - 1;
 #pragma unroll
-                for (int r = 0; r < H; ++r) nxt[r] = rows[(long long)knext * wrow + r * WAVE + lane];
+                for (int r = 0; r < H; ++r) RG_ROW_LD(nxt[r], rows[(long long)knext * wrow + r * WAVE + lane]);
             }
             if (!cont) {
                 int rowa[H];
 #pragma unroll
-                for (int r = 0; r < H; ++r) rowa[r] = rows[(long long)ga * wrow + r * WAVE + lane];
+                for (int r = 0; r < H; ++r) { rowa[r] = s[r]; RG_ROW_LD(rowa[r], rows[(long long)ga * wrow + r * WAVE + lane]); }
                 unsigned umask;
                 RowOps16<C>::alpha(rowa, s, g_i, g0, lane, MU, ML, umask, lmask, src);
                 if (nm > 1) RowOps16<C>::select_steps(SEL, s, MU, g_i, g0, lane);
 #pragma unroll
-                for (int r = 0; r < H; ++r) rows[(long long)ga * wrow + r * WAVE + lane] = rowa[r];
+                for (int r = 0; r < H; ++r) RG_ROW_ST(rows[(long long)ga * wrow + r * WAVE + lane], rowa[r]);
                 if (track) { if (flags & F_FIRST) set_keys(bkey, rowa, ga); else fold_keys(bkey, rowa, ga); }
                 if (semi_end) end_fold(ga, i, rowa);
                 if (dirs) store_dirs(slot, umask, lmask);
@@ -538,11 +570,11 @@ __global__ __launch_bounds__(64, 2) void k_sweep16(SweepArgs a) {
                     knext = kbase + __builtin_ctzll(rest);
                     rest &= rest - 1;
 #pragma unroll
-                    for (int r = 0; r < H; ++r) nxt[r] = rows[(long long)knext * wrow + r * WAVE + lane];
+                    for (int r = 0; r < H; ++r) RG_ROW_LD(nxt[r], rows[(long long)knext * wrow + r * WAVE + lane]);
                 } else knext = -1;
                 RowOps16<C>::member(cur, SEL, lane, MU, ML, lmask, src);
 #pragma unroll
-                for (int r = 0; r < H; ++r) rows[(long long)k * wrow + r * WAVE + lane] = cur[r];
+                for (int r = 0; r < H; ++r) RG_ROW_ST(rows[(long long)k * wrow + r * WAVE + lane], cur[r]);
                 if (track) fold_keys(bkey, cur, k);
                 if (semi_end) end_fold(k, i, cur);
             }

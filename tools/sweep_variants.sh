@@ -1,0 +1,25 @@
+#!/bin/bash
+# Timing-only variants of k_sweep16 ("make the evidence reproducible"): builds one library per
+# -DRG_SWEEP16_* flag into tools/build/ (the results of these builds are garbage: nothing ships or tests them) and times
+# the config-5 sweeps of each with a one-handle stream (kernel durations = HIP events, nothing else on the GPU).
+#   HERE (no GPU):   tools/sweep_variants.sh build
+#   on the GPU box:  tools/sweep_variants.sh run > gpurun_out/sweep_variants.txt
+cd "$(dirname "$0")/.." || exit 1
+VARIANTS="${VARIANTS:-BASE NOKEYS NOEMIT NODIRS NOKEYS_NOEMIT NOROWS_NOEMIT NOROWS_NOKEYS_NOEMIT_NODIRS}"
+if [ "$1" = build ]; then
+  mkdir -p tools/build
+  for v in $VARIANTS; do
+    flags=""; [ $v != BASE ] && for f in ${v//_/ }; do flags="$flags -DRG_SWEEP16_$f"; done
+    rm -rf /tmp/rgvar_$v; mkdir -p /tmp/rgvar_$v
+    cp -r recgraph_amd/csrc /tmp/rgvar_$v/csrc; mkdir -p /tmp/rgvar_$v/include; cp include/recgraph_hip.h /tmp/rgvar_$v/include/
+    mkdir -p /tmp/rgvar_$v/x; mv /tmp/rgvar_$v/csrc /tmp/rgvar_$v/x/csrc; mkdir -p /tmp/rgvar_$v/include
+    ( cd /tmp/rgvar_$v/x/csrc && rm -rf build && make -j8 CXXFLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -Wno-unused-function $flags" > /dev/null 2>&1 ) || { echo "build $v failed"; exit 1; }
+    cp /tmp/rgvar_$v/x/librecgraph_hip.so tools/build/librecgraph_hip_$v.so
+    echo "built $v ($flags)"
+  done
+  exit 0
+fi
+for v in $VARIANTS; do
+  RG_LIB_PATH=$PWD/tools/build/librecgraph_hip_$v.so python3 bench.py --config ${CFG:-C5} --steps 4 --warmup 1 --no-cpu --handles 1 2>/dev/null |
+    python3 -c "import sys,json; d=json.loads(sys.stdin.read()); k=d['kernel_ms_per_step']; print('$v', 'fwd', k.get('k_sweep16_fwd'), 'rev', k.get('k_sweep16_rev'), 'step', d['ms_per_step'])"
+done
