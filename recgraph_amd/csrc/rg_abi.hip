@@ -33,6 +33,7 @@ Options& options() {
         o.no_frec = env("RG_NO_FREC");
         o.debug = env("RG_DEBUG");
         { const char* v = getenv("RG_CHUNK_READS"); o.chunk_reads = v ? atoi(v) : 0; }
+        { const char* v = getenv("RG_LB_BONUS"); o.lb_bonus = v ? atoi(v) : 0; }
     });
     return o;
 }
@@ -406,34 +407,14 @@ static int load_reads(rg_batch* b, const char* reads, const int64_t* read_off, i
     b->nreads = nreads;
     b->off.resize(nreads + 1);
     for (int64_t i = 0; i <= nreads; ++i) b->off[i] = read_off[i] - base;
-    // sequences.rs:13-22 as two 256-entry tables: canonical character ('-' -> 'N', upper case) and base code (0xff = none)
-    static const struct Canon {
-        char ch[256];
-        uint8_t code[256];
-        Canon() {
-            for (int c = 0; c < 256; ++c) {
-                const char u = c == '-' ? 'N' : (char)toupper(c);
-                ch[c] = u;
-                const int k = base_code(u);
-                code[c] = k < 0 ? 0xff : (uint8_t)k;
-            }
-        }
-    } canon;
     b->bad.assign(nreads, 0);
     b->bta.resize(nreads);
-    b->max_n = 0;
-    const unsigned char* src = reinterpret_cast<const unsigned char*>(reads) + base;
     uint8_t* codes = b->stage.p + o_codes;
     b->codes = codes;
-    for (size_t k = 0; k < total; ++k) codes[k] = canon.code[src[k]];       // one table pass over the whole blob
+    // sequences.rs:13-22 ('-' -> 'N', upper case) + base codes, one table pass over the whole blob (rg_reads.cpp)
+    b->max_n = (int)std::min<int64_t>(canonicalise_reads(reads, read_off, nreads, codes, b->bad.data()), INT32_MAX);
     for (int64_t r = 0; r < nreads; ++r) {
         const long long n = b->off[r + 1] - b->off[r];
-        b->max_n = std::max<int>(b->max_n, (int)std::min<long long>(n, INT32_MAX));
-        // a character outside ACGTN (after canonicalisation): the reference panics on the score lookup
-        if (memchr(codes + b->off[r], 0xff, (size_t)n)) {
-            b->bad[r] = 1;
-            for (long long k = b->off[r]; k < b->off[r + 1]; ++k) if (codes[k] == 0xff) codes[k] = 4;
-        }
         // main.rs:57: (b + f * seq.len() as f32) as usize, seq.len() = n + 1
         float v = p->band_b + p->band_f * (float)(n + 1);
         long long bt = p->bta_override >= 0 ? p->bta_override : (v > 0 ? (long long)v : 0);

@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "rg_codes.hpp"
+
 namespace rg {
 
 constexpr int WAVE = 64;
@@ -35,11 +37,6 @@ struct DevRecord {
     int32_t pad;
 };
 
-// traceback op codes (one byte per op, walk order)
-enum : uint8_t { OP_D = 1, OP_U = 2, OP_L = 3, OP_CONT = 0x80 };
-
-// status bits mirror include/recgraph_hip.h
-enum : uint32_t { ST_BAND_WARNING = 1u, ST_BAND_NOT_ENOUGH = 2u, ST_WOULD_PANIC = 4u, ST_BAD_BASE = 8u, ST_OVERFLOW = 0x100u };
 
 __device__ __forceinline__ int wave_incl_sum(int v, int lane) {
 #pragma unroll

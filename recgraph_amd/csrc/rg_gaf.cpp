@@ -9,7 +9,7 @@
 #include <algorithm>
 #include <charconv>
 
-#include "rg_device.hpp"
+#include "rg_codes.hpp"
 #include "rg_host.hpp"
 
 namespace rg {

@@ -6,6 +6,7 @@
 #pragma once
 #include <atomic>
 #include <cstdint>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -22,6 +23,7 @@ struct Options {
     std::atomic<int> three_sweeps{0};   // RG_THREE_SWEEPS: force the three-sweep -m 8 pipeline
     std::atomic<int> no_frec{0};        // RG_NO_FREC: Cand-list forward emission instead of records
     std::atomic<int> debug{0};          // RG_DEBUG: candidate / record statistics on stderr
+    std::atomic<int> lb_bonus{0};       // RG_LB_BONUS (experiments only): added to the forward sweep's lower bound; > 0 may drop candidates
     std::atomic<int> chunk_reads{0};    // RG_CHUNK_READS: most reads one pathwise kernel launch takes (0: what the HBM budget allows, <= 8192)
 };
 Options& options();
@@ -138,6 +140,15 @@ GafFields fields_m0_simd(const HostGraph& g, const std::string& read, const std:
 GafFields fields_poa_banded(const HostGraph& g, const std::string& read, const std::string& name, const ReadRecord& r, int amb = 0);
 GafFields fields_pathwise(const HostGraph& g, const std::string& read, const std::string& name, const ReadRecord& r, int mode);
 void build_rev_ids(HostGraph& g);
+
+// ---- read ingestion (rg_reads.cpp) ----
+struct FastaReads {
+    std::string bases;                  // concatenated canonical bases of all reads
+    std::vector<int64_t> off;           // count + 1
+    std::vector<std::string> names;
+};
+bool parse_fasta(const char* text, int64_t len, FastaReads& r, int64_t batch, const std::function<void(int64_t, int64_t)>& emit);
+int64_t canonicalise_reads(const char* reads, const int64_t* read_off, int64_t nreads, uint8_t* codes, uint8_t* bad);
 std::string f32_display(float v);
 
 }  // namespace rg

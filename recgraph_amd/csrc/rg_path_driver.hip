@@ -311,7 +311,7 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
                 Opt0Args oa{gd, sa.sc, d_reads, off, bad, w.fpoff.p, w.fprow.p, w.lb.p, semi ? 1 : 0};
                 TIMED(T, "k_opt0", launch_opt0(oa, chunk, C, stream));
                 SweepArgs f = sa;
-                f.rev = 0; f.track_best = 1; f.lb = w.lb.p; f.brc = p.base_rec_cost; f.maxmatch = maxmatch;
+                f.rev = 0; f.track_best = 1; f.lb = w.lb.p; f.brc = p.base_rec_cost + opt.lb_bonus; f.maxmatch = maxmatch;
                 f.colmax_out = w.mf.p; f.colarg_out = w.mfarg.p; f.cand = w.fcand.p; f.cand_cap = w.fcap; f.ncand_out = w.nf.p;
                 if (use_rec) { f.cand = nullptr; f.cand_cap = 0; f.frec = w.frec.p; f.frec_cap = w.frec_cap; f.ncand_out = w.nrec.p; }
                 f.dirs = w.fdirs.p; f.dirs_stride = fdirs_stride; f.count_cells = 1;

@@ -26,52 +26,9 @@
 
 // ---------------------------------------------------------------------------------------------------------------------
 // FASTA (sequences::get_sequences, sequences.rs:5-45)
-struct rg_reads {
-    std::string bases;
-    std::vector<int64_t> off;           // count + 1
-    std::vector<std::string> names;
+struct rg_reads : rg::FastaReads {
     std::vector<const char*> name_ptrs;
 };
-
-// Incremental form of the parser: `emit(first, count)` is called whenever `batch` more reads are complete (read i is
-// complete once sequence i is closed AND name i exists: the reference pairs the two lists by index) and once more at the
-// end for the rest.  Returns false ("wrong fasta file format") when the counts differ at the end of the text.
-template <typename Emit>
-static bool parse_fasta(const char* text, int64_t len, rg_reads& r, int64_t batch, Emit&& emit) {
-    r.bases.reserve((size_t)len);
-    r.off.push_back(0);
-    // the reference pushes a name at every header and a sequence whenever the one being collected is non-empty at the
-    // next header / at the end of the file; the two lists are paired by index afterwards (:41-43 panics when the counts differ)
-    size_t cur_begin = 0;               // start of the sequence being collected inside r.bases
-    int64_t emitted = 0;
-    auto ready = [&] { return std::min<int64_t>((int64_t)r.off.size() - 1, (int64_t)r.names.size()); };
-    const char* p = text;
-    const char* end = text + len;
-    while (p < end) {
-        const char* nl = (const char*)memchr(p, '\n', (size_t)(end - p));
-        const char* le = nl ? nl : end;
-        const char* q = le;
-        if (nl && q > p && q[-1] == '\r') --q;              // BufRead::lines drops "\n" or "\r\n" (a '\r' at the very end stays)
-        if (q > p) {                                        // empty lines are skipped (:14)
-            if (*p == '>') {
-                r.names.emplace_back(p + 1, q);
-                if (r.bases.size() > cur_begin) { r.off.push_back((int64_t)r.bases.size()); cur_begin = r.bases.size(); }
-                if (batch > 0 && ready() - emitted >= batch) { emit(emitted, batch); emitted += batch; }
-            } else {
-                for (const char* c = p; c < q; ++c) {
-                    const unsigned char ch = (unsigned char)*c;
-                    // '-' -> 'N', ASCII upper-casing (char::to_ascii_uppercase leaves everything else alone)
-                    r.bases.push_back(ch == '-' ? 'N' : (ch >= 'a' && ch <= 'z') ? (char)(ch - 32) : (char)ch);
-                }
-            }
-        }
-        p = nl ? nl + 1 : end;
-    }
-    if (r.bases.size() > cur_begin) r.off.push_back((int64_t)r.bases.size());
-    if (r.off.size() - 1 != r.names.size()) return false;
-    if (ready() > emitted) emit(emitted, ready() - emitted);
-    return true;
-}
 
 extern "C" {
 

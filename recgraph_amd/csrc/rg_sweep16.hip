@@ -154,6 +154,15 @@ struct RowOps16 {
 #ifndef RG_SWEEP16_KRUN
 #define RG_SWEEP16_KRUN 4
 #endif
+#ifndef RG_SWEEP16_THRLDS
+#define RG_SWEEP16_THRLDS 0
+#endif
+#ifndef RG_SWEEP16_KRUN_REV
+#define RG_SWEEP16_KRUN_REV RG_SWEEP16_KRUN     // the variant without column maxima (reverse sweep of the record pipeline)
+#endif
+#ifndef RG_SWEEP16_REV_WAVES
+#define RG_SWEEP16_REV_WAVES 2                   // waves per SIMD the compiler must fit that variant into
+#endif
 // TIMING-ONLY build variants (tools/sweep_variants.sh; the results of such a build are garbage and nothing ships them):
 //   RG_SWEEP16_NOROWS   no rolling-row load / store in the main loop (rows stay whatever the registers hold)
 //   RG_SWEEP16_NOKEYS   the best-member keys are not built (row_end runs on constant keys)
@@ -173,9 +182,9 @@ struct RowOps16 {
 // kWide = true: graphs with more than 64 paths (step entries carry a 64-path page and continuation entries exist); the
 // narrow variant compiles that logic out (page 0, no continuation: it costs registers the forward sweep does not have)
 template <int C, bool kColmax, bool kRec, bool kWide>
-__global__ __launch_bounds__(64, 2) void k_sweep16(SweepArgs a) {
+__global__ __launch_bounds__(64, (kColmax || C > 16) ? 2 : RG_SWEEP16_REV_WAVES) void k_sweep16(SweepArgs a) {
     constexpr int H = C / 2;
-    constexpr int KRUN = C <= 16 ? RG_SWEEP16_KRUN : 0;   // rows kept in registers across the inner rows of a segment
+    constexpr int KRUN = C <= 16 ? (kColmax ? RG_SWEEP16_KRUN : RG_SWEEP16_KRUN_REV) : 0;   // rows kept in registers across the inner rows of a segment
     const int rd = blockIdx.x;
     const int lane = threadIdx.x;
     const PathGraphDev& g = a.g;
@@ -208,7 +217,15 @@ __global__ __launch_bounds__(64, 2) void k_sweep16(SweepArgs a) {
     int* rows = a.roll + (long long)rd * P * wrow;
     // per-column constants of this lane
     unsigned long long pcode[(H + 7) / 8] = {};   // 8 bits per register: code_lo | code_hi << 3
-    int thrk[C];                         // emission threshold << 16 per column (INT32_MAX = never; columns that do not exist)
+    // emission threshold << 16 per column (INT32_MAX = never; columns that do not exist).  Kept in LDS ([q][lane], read once
+    // per row by the epilogue): the forward variant has no registers to spare (RG_SWEEP16_THRLDS=0: in registers)
+#if RG_SWEEP16_THRLDS
+    int* thrl = lds16 + 64 + 2 * RG_MAXP + 5 * 64;
+#define THRK(q) thrl[(q) * WAVE + lane]
+#else
+    int thrk[C];
+#define THRK(q) thrk[q]
+#endif
     int minthrk = INT32_MAX;             // lowest threshold of the lane
     int minplain = INT32_MAX;            // lowest threshold of the lane without the member rule (rows every path visits)
     const bool tight = a.thr != nullptr; // thresholds from the other sweep's column maxima
@@ -240,11 +257,11 @@ __global__ __launch_bounds__(64, 2) void k_sweep16(SweepArgs a) {
             if (c >= 1 && c < ncols) code = rev ? read[n - c + 1] : read[c];
             const int r = q % H, hi = q / H;
             pcode[r / 8] |= (unsigned long long)code << (8 * (r % 8) + 3 * hi);
-            thrk[q] = thr_key(q, true);
+            THRK(q) = thr_key(q, true);
         }
         // start rows: the gap-only row, identical for every path (uniform gap cost: A = c * gcost, z = 0)
 #pragma unroll
-        for (int q = 0; q < C; ++q) { minthrk = min(minthrk, thrk[q]); minplain = min(minplain, thr_key(q, false)); }
+        for (int q = 0; q < C; ++q) { minthrk = min(minthrk, THRK(q)); minplain = min(minplain, thr_key(q, false)); }
         for (int k = 0; k < P; ++k) {
 #pragma unroll
             for (int r = 0; r < H; ++r) {
@@ -303,7 +320,7 @@ __global__ __launch_bounds__(64, 2) void k_sweep16(SweepArgs a) {
             if (test) {
                 if (knm >= 0) {
 #pragma unroll
-                    for (int q = 0; q < C; ++q) has |= __ballot(bkey[q] >= thrk[q]);
+                    for (int q = 0; q < C; ++q) has |= __ballot(bkey[q] >= THRK(q));
                 } else {
 #pragma unroll
                     for (int q = 0; q < C; ++q) has |= __ballot(bkey[q] >= minplain);
@@ -330,7 +347,8 @@ __global__ __launch_bounds__(64, 2) void k_sweep16(SweepArgs a) {
                 const int tkey = bkey[q] + (lane * C + q) * gz;    // true key: value << 16 | path
                 // (rows every path visits: the lane's lowest plain threshold, but never a column whose own threshold is
                 // "never": outside the read or outside the recombination band)
-                emask |= (knm >= 0 ? (bkey[q] >= thrk[q] && tkey > knm) : (bkey[q] >= minplain && thrk[q] != INT32_MAX)) ? (1u << q) : 0u;
+                const int tq = THRK(q);
+                emask |= (knm >= 0 ? (bkey[q] >= tq && tkey > knm) : (bkey[q] >= minplain && tq != INT32_MAX)) ? (1u << q) : 0u;
             }
         }
         if (cand && __any(emask != 0)) {
@@ -735,7 +753,7 @@ void launch_colmax_rec(const ExpandArgs& a, int* colmax_out, int* colarg_out, in
 
 template <bool kColmax, bool kRec, bool kWide>
 static void launch_sweep16_w(const SweepArgs& a, int nreads, int C, hipStream_t s) {
-    const size_t bytes = (size_t)(64 + 2 * RG_MAXP + 5 * 64) * sizeof(int);
+    const size_t bytes = (size_t)(64 + 2 * RG_MAXP + 5 * 64 + (RG_SWEEP16_THRLDS ? C * WAVE : 0)) * sizeof(int);
     switch (C) {
         case 4: hipLaunchKernelGGL((k_sweep16<4, kColmax, kRec, kWide>), dim3(nreads), dim3(64), bytes, s, a); break;
         case 8: hipLaunchKernelGGL((k_sweep16<8, kColmax, kRec, kWide>), dim3(nreads), dim3(64), bytes, s, a); break;

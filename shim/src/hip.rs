@@ -1,131 +1,65 @@
-//! FFI binding of `include/recgraph_hip.h` (the C ABI of the MI355X library) and thin RAII wrappers.
+//! Safe RAII wrappers over the C ABI of librecgraph_hip.so.  The raw `extern "C"` binding of EVERY symbol of
+//! `include/recgraph_hip.h` lives in `hip_ffi.rs` (generated from the header by tools/gen_rust_ffi.py, re-exported here).
 //! UNCOMPILED: no Rust toolchain exists in the image this was written in.
-#![allow(non_camel_case_types, dead_code)]
+#![allow(dead_code)]
 
 use std::ffi::{CStr, CString};
-use std::os::raw::{c_char, c_float, c_int};
+use std::os::raw::c_char;
 use std::ptr;
 
-pub const RG_OK: i32 = 0;
-pub const RG_READ_BAND_WARNING: u32 = 1;
-pub const RG_READ_BAND_NOT_ENOUGH: u32 = 2;
-pub const RG_READ_WOULD_PANIC: u32 = 4;
-pub const RG_READ_BAD_BASE: u32 = 8;
+pub use crate::hip_ffi::*;
 
-pub const RG_MODE_GLOBAL_POA: i32 = 0;
-pub const RG_MODE_GLOBAL_POA_SCALAR: i32 = 10;
-pub const RG_MODE_GAP_POA: i32 = 2;
-pub const RG_MODE_LOCAL_POA: i32 = 1;
-pub const RG_MODE_GAP_LOCAL_POA: i32 = 3;
-pub const RG_SCORE_MISSING: i32 = -536870912;
-
-/// `rg_params` of recgraph_hip.h (field order and types must match the header exactly).
-#[repr(C)]
-#[derive(Clone, Copy)]
-pub struct rg_params {
-    pub mode: i32,
-    pub scores: [i32; 36],
-    pub gap_open: i32,
-    pub gap_ext: i32,
-    pub band_b: c_float,
-    pub band_f: c_float,
-    pub bta_override: i64,
-    pub base_rec_cost: i32,
-    pub multi_rec_cost: c_float,
-    pub rec_band_width: c_float,
-    pub amb_mode: i32,
-}
-
-/// `rg_gaf_fields` of recgraph_hip.h.
-#[repr(C)]
-#[derive(Clone, Copy, Default)]
-pub struct rg_gaf_fields {
-    pub has_record: i32,
-    pub empty: i32,
-    pub warning: u32,
-    pub strand: c_char,
-    pub query_length: u64,
-    pub query_start: u64,
-    pub query_end: u64,
-    pub path_length: u64,
-    pub path_start: u64,
-    pub path_end: u64,
-    pub residue_matches_number: u64,
-    pub n_path_ids: i64,
-    pub comments_len: i64,
-}
-
-#[repr(C)]
-pub struct rg_graph {
-    _private: [u8; 0],
-}
-#[repr(C)]
-pub struct rg_batch {
-    _private: [u8; 0],
-}
-
-extern "C" {
-    pub fn rg_params_default(p: *mut rg_params, mode: i32);
-    pub fn rg_graph_create_lnz(
-        lnz: *const c_char,
-        l: i64,
-        pred_off: *const i64,
-        pred_rows: *const i64,
-        node_id: *const u64,
-        out: *mut *mut rg_graph,
-    ) -> i32;
-    pub fn rg_graph_destroy(g: *mut rg_graph);
-    pub fn rg_align_batch(
-        g: *const rg_graph,
-        p: *const rg_params,
-        reads: *const c_char,
-        read_off: *const i64,
-        nreads: i64,
-        out: *mut *mut rg_batch,
-    ) -> i32;
-    pub fn rg_batch_destroy(b: *mut rg_batch);
-    pub fn rg_result_status(b: *const rg_batch, i: i64) -> u32;
-    pub fn rg_result_score(b: *const rg_batch, i: i64) -> i32;
-    pub fn rg_result_fields(
-        b: *const rg_batch,
-        i: i64,
-        out: *mut rg_gaf_fields,
-        path_ids: *mut u64,
-        path_cap: i64,
-        comments: *mut c_char,
-        comments_cap: i64,
-    ) -> i32;
-    pub fn rg_last_error() -> *const c_char;
-}
-
-fn last_error() -> String {
+pub fn last_error() -> String {
     unsafe { CStr::from_ptr(rg_last_error()).to_string_lossy().into_owned() }
 }
 
-/// Flattened LnzGraph resident on the GPU (`rg_graph`).
-pub struct Graph {
-    raw: *mut rg_graph,
+fn check(rc: i32) -> Result<(), String> {
+    if rc == RG_OK {
+        Ok(())
+    } else {
+        Err(format!("recgraph_hip error {}: {}", rc, last_error()))
+    }
 }
 
+pub fn default_params(mode: i32) -> rg_params {
+    let mut p = std::mem::MaybeUninit::<rg_params>::uninit();
+    unsafe {
+        rg_params_default(p.as_mut_ptr(), mode);
+        p.assume_init()
+    }
+}
+
+/// Flattened graph resident on the GPU (`rg_graph`): LnzGraph view, plus the PathGraph view when the GFA has P lines.
+pub struct Graph {
+    pub(crate) raw: *mut rg_graph,
+}
+// immutable after creation, shareable across threads and devices (recgraph_hip.h)
+unsafe impl Send for Graph {}
+unsafe impl Sync for Graph {}
+
 impl Graph {
+    /// graph::read_graph / pathwise_graph::read_graph_w_path (graph.rs:11, pathwise_graph.rs:127) on GFA text.
+    pub fn from_gfa_text(text: &str) -> Result<Graph, String> {
+        let mut raw: *mut rg_graph = ptr::null_mut();
+        check(unsafe { rg_graph_from_gfa(text.as_ptr() as *const c_char, text.len() as i64, &mut raw) })?;
+        Ok(Graph { raw })
+    }
+
     /// `lnz` = `'$'` + bases + `'F'`; predecessors of row `i` are `pred_rows[pred_off[i]..pred_off[i+1]]`
     /// (pred_hash order); `node_id[i]` = segment id of row `i` (0 for rows 0 and L-1).
     pub fn from_lnz(lnz: &[u8], pred_off: &[i64], pred_rows: &[i64], node_id: &[u64]) -> Result<Graph, String> {
         let mut raw: *mut rg_graph = ptr::null_mut();
-        let rc = unsafe {
-            rg_graph_create_lnz(
-                lnz.as_ptr() as *const c_char,
-                lnz.len() as i64,
-                pred_off.as_ptr(),
-                pred_rows.as_ptr(),
-                node_id.as_ptr(),
-                &mut raw,
-            )
-        };
-        if rc != RG_OK {
-            return Err(last_error());
-        }
+        check(unsafe {
+            rg_graph_create_lnz(lnz.as_ptr() as *const c_char, lnz.len() as i64, pred_off.as_ptr(), pred_rows.as_ptr(), node_id.as_ptr(), &mut raw)
+        })?;
         Ok(Graph { raw })
+    }
+
+    pub fn rows(&self) -> i64 {
+        unsafe { rg_graph_rows(self.raw) }
+    }
+    pub fn paths(&self) -> i32 {
+        unsafe { rg_graph_paths(self.raw) }
     }
 }
 
@@ -144,6 +78,24 @@ pub struct Record {
     pub comments: String,
 }
 
+fn record_of(raw: *const rg_batch, i: usize) -> Result<Record, String> {
+    let mut f = std::mem::MaybeUninit::<rg_gaf_fields>::zeroed();
+    check(unsafe { rg_result_fields(raw, i as i64, f.as_mut_ptr(), ptr::null_mut(), 0, ptr::null_mut(), 0) })?;
+    let mut f = unsafe { f.assume_init() };
+    let mut ids: Vec<u64> = vec![0; f.n_path_ids.max(1) as usize];
+    let mut com: Vec<u8> = vec![0; f.comments_len as usize + 1];
+    check(unsafe { rg_result_fields(raw, i as i64, &mut f, ids.as_mut_ptr(), ids.len() as i64, com.as_mut_ptr() as *mut c_char, com.len() as i64) })?;
+    ids.truncate(f.n_path_ids as usize);
+    com.truncate(f.comments_len as usize);
+    Ok(Record {
+        status: unsafe { rg_result_status(raw, i as i64) },
+        score: unsafe { rg_result_score(raw, i as i64) },
+        fields: f,
+        path: ids.iter().map(|x| *x as usize).collect(),
+        comments: String::from_utf8_lossy(&com).into_owned(),
+    })
+}
+
 /// create + run + fetch of one read set (`rg_align_batch`); results are read through `record`.
 pub struct Batch {
     raw: *mut rg_batch,
@@ -159,44 +111,11 @@ impl Batch {
         }
         let c = CString::new(blob).map_err(|e| e.to_string())?;
         let mut raw: *mut rg_batch = ptr::null_mut();
-        let rc = unsafe { rg_align_batch(graph.raw, params, c.as_ptr(), off.as_ptr(), reads.len() as i64, &mut raw) };
-        if rc != RG_OK {
-            return Err(last_error());
-        }
+        check(unsafe { rg_align_batch(graph.raw, params, c.as_ptr(), off.as_ptr(), reads.len() as i64, &mut raw) })?;
         Ok(Batch { raw })
     }
-
     pub fn record(&self, i: usize) -> Result<Record, String> {
-        let mut f = rg_gaf_fields::default();
-        let rc = unsafe { rg_result_fields(self.raw, i as i64, &mut f, ptr::null_mut(), 0, ptr::null_mut(), 0) };
-        if rc != RG_OK {
-            return Err(last_error());
-        }
-        let mut ids: Vec<u64> = vec![0; f.n_path_ids.max(1) as usize];
-        let mut com: Vec<u8> = vec![0; f.comments_len as usize + 1];
-        let rc = unsafe {
-            rg_result_fields(
-                self.raw,
-                i as i64,
-                &mut f,
-                ids.as_mut_ptr(),
-                ids.len() as i64,
-                com.as_mut_ptr() as *mut c_char,
-                com.len() as i64,
-            )
-        };
-        if rc != RG_OK {
-            return Err(last_error());
-        }
-        ids.truncate(f.n_path_ids as usize);
-        com.truncate(f.comments_len as usize);
-        Ok(Record {
-            status: unsafe { rg_result_status(self.raw, i as i64) },
-            score: unsafe { rg_result_score(self.raw, i as i64) },
-            fields: f,
-            path: ids.iter().map(|x| *x as usize).collect(),
-            comments: String::from_utf8_lossy(&com).into_owned(),
-        })
+        record_of(self.raw, i)
     }
 }
 
@@ -206,14 +125,107 @@ impl Drop for Batch {
     }
 }
 
-pub fn default_params(mode: i32) -> rg_params {
-    let mut p = std::mem::MaybeUninit::<rg_params>::uninit();
-    unsafe {
-        rg_params_default(p.as_mut_ptr(), mode);
-        p.assume_init()
+/// sequences::get_sequences (sequences.rs:5-45) inside the library: bases blob + offsets + names.
+pub struct Reads {
+    raw: *mut rg_reads,
+}
+
+impl Reads {
+    pub fn from_fasta_text(text: &[u8]) -> Result<Reads, String> {
+        let mut raw: *mut rg_reads = ptr::null_mut();
+        check(unsafe { rg_reads_from_fasta(text.as_ptr() as *const c_char, text.len() as i64, &mut raw) })?;
+        Ok(Reads { raw })
+    }
+    pub fn len(&self) -> usize {
+        unsafe { rg_reads_count(self.raw) as usize }
+    }
+    pub fn name(&self, i: usize) -> String {
+        unsafe { CStr::from_ptr(*rg_reads_names(self.raw).add(i)).to_string_lossy().into_owned() }
     }
 }
 
-// keeps c_int in the import list meaningful for callers that extend the binding
-#[allow(dead_code)]
-type _Unused = c_int;
+impl Drop for Reads {
+    fn drop(&mut self) {
+        unsafe { rg_reads_destroy(self.raw) }
+    }
+}
+
+/// One tile of a stream: the stdout text of its reads (exactly what the reference prints) + per-read status bits.
+pub struct Tile {
+    pub first_read: usize,
+    pub text: Vec<u8>,
+    pub text_off: Vec<i64>,
+    pub status: Vec<u32>,
+    pub score: Vec<i32>,
+    pub device: i32,
+}
+
+/// `rg_stream`: the read loop of main.rs (:56,174,257,297-312) as the pipeline hidden behind the C ABI — tiles of reads
+/// pulled by `handles_per_device` batch handles per device from one queue, results in input order.
+pub struct Stream {
+    raw: *mut rg_stream,
+}
+
+impl Stream {
+    /// `devices`: None = every visible GPU.
+    pub fn new(graph: &Graph, params: &rg_params, devices: Option<&[i32]>, opts: Option<rg_stream_opts>) -> Result<Stream, String> {
+        let mut o = std::mem::MaybeUninit::<rg_stream_opts>::uninit();
+        let o = match opts {
+            Some(x) => x,
+            None => unsafe {
+                rg_stream_opts_default(o.as_mut_ptr());
+                o.assume_init()
+            },
+        };
+        let mut raw: *mut rg_stream = ptr::null_mut();
+        let (dp, dn) = match devices {
+            Some(d) => (d.as_ptr(), d.len() as i32),
+            None => (ptr::null(), 0),
+        };
+        check(unsafe { rg_stream_create(graph.raw, params, dp, dn, &o, &mut raw) })?;
+        Ok(Stream { raw })
+    }
+
+    /// FASTA text parsed inside the library, its reads pushed tile by tile while the rest is parsed.
+    pub fn push_fasta(&mut self, text: &[u8]) -> Result<usize, String> {
+        let mut n: i64 = 0;
+        check(unsafe { rg_stream_push_fasta(self.raw, text.as_ptr() as *const c_char, text.len() as i64, &mut n) })?;
+        Ok(n as usize)
+    }
+
+    pub fn push(&mut self, reads: &Reads) -> Result<(), String> {
+        check(unsafe { rg_stream_push(self.raw, rg_reads_bases(reads.raw), rg_reads_offsets(reads.raw), rg_reads_count(reads.raw), rg_reads_names(reads.raw)) })
+    }
+
+    pub fn finish(&mut self) -> Result<(), String> {
+        check(unsafe { rg_stream_finish(self.raw) })
+    }
+
+    /// The next tile in input order (blocks); Ok(None) after `finish` when everything was delivered.
+    pub fn next(&mut self) -> Result<Option<Tile>, String> {
+        let mut r = std::mem::MaybeUninit::<rg_stream_result>::zeroed();
+        let rc = unsafe { rg_stream_next(self.raw, r.as_mut_ptr()) };
+        if rc == RG_STREAM_END {
+            return Ok(None);
+        }
+        check(rc)?;
+        let r = unsafe { r.assume_init() };
+        let n = r.nreads as usize;
+        unsafe {
+            Ok(Some(Tile {
+                first_read: r.first_read as usize,
+                text: std::slice::from_raw_parts(r.text as *const u8, r.text_len as usize).to_vec(),
+                text_off: std::slice::from_raw_parts(r.text_off, n + 1).to_vec(),
+                status: std::slice::from_raw_parts(r.status, n).to_vec(),
+                score: std::slice::from_raw_parts(r.score, n).to_vec(),
+                device: r.device,
+            }))
+        }
+    }
+}
+
+impl Drop for Stream {
+    fn drop(&mut self) {
+        unsafe { rg_stream_destroy(self.raw) }
+    }
+}

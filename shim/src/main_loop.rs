@@ -1,0 +1,79 @@
+//! The read loops of RecGraph's `src/main.rs` (:56-105 mode 0, :107-172 mode 1, :174-213 mode 2, :215-253 mode 3,
+//! :255-262 mode 4, :263-270 mode 5, :289-313 modes 8 / 9) over the MI355X library: FASTA in, GAF out, every read of the
+//! file through ONE `hip::Stream` (all visible GPUs).  A maintainer calls `align_all` from `main()` in place of the
+//! `match align_mode { .. }` block; `-s true` (the reverse-complement retry of modes 0-3) keeps the reference's per-read
+//! functions of `api.rs`.
+//! UNCOMPILED: no Rust toolchain exists in the image this was written in.
+use std::io::Write;
+
+use crate::args_parser;
+use crate::hip;
+use crate::utils;
+
+/// `-m` of the command line -> `rg_params.mode` (args_parser.rs:31-38).
+fn mode_of(align_mode: i32) -> i32 {
+    match align_mode {
+        0 => hip::RG_MODE_GLOBAL_POA,
+        1 => hip::RG_MODE_LOCAL_POA,
+        2 => hip::RG_MODE_GAP_POA,
+        3 => hip::RG_MODE_GAP_LOCAL_POA,
+        4 => hip::RG_MODE_PATHWISE,
+        5 => hip::RG_MODE_PATHWISE_SEMI,
+        8 => hip::RG_MODE_RECOMBINATION,
+        9 => hip::RG_MODE_RECOMBINATION_SEMI,
+        _ => panic!("Alignment mode must be in [0..9]"), // main.rs:315-317 (6 and 7 stay on the CPU path)
+    }
+}
+
+/// Parameters of the run from the same getters `main.rs` uses (args_parser.rs:148-202).
+fn params_of(align_mode: i32, score_matrix: &std::collections::HashMap<(char, char), i32>) -> hip::rg_params {
+    let mut p = hip::default_params(mode_of(align_mode));
+    let alphabet = ['A', 'C', 'G', 'T', 'N', '-'];
+    for (a, ca) in alphabet.iter().enumerate() {
+        for (b, cb) in alphabet.iter().enumerate() {
+            p.scores[a * 6 + b] = *score_matrix.get(&(*ca, *cb)).unwrap_or(&hip::RG_SCORE_MISSING);
+        }
+    }
+    let (b, f) = args_parser::get_b_f();
+    p.band_b = b;
+    p.band_f = f;
+    let (o, e) = args_parser::get_gap_open_gap_ext();
+    p.gap_open = o;
+    p.gap_ext = e;
+    let (base_rec_cost, multi_rec_cost) = args_parser::get_base_multi_recombination_cost();
+    p.base_rec_cost = base_rec_cost;
+    p.multi_rec_cost = multi_rec_cost;
+    p.rec_band_width = args_parser::get_recombination_band_width();
+    p
+}
+
+/// Aligns every read of `sequence_path` against `graph_path` in mode `align_mode` and writes what `main.rs` writes:
+/// the warning lines on stdout, every record through `utils::write_gaf` (stdout or the `-o` file, with the number
+/// `main.rs` passes: `i + 1` in modes 0-3, `i` in modes 4, 5, 8, 9).
+pub fn align_all(align_mode: i32, sequence_path: &str, graph_path: &str, score_matrix: &std::collections::HashMap<(char, char), i32>) {
+    let gfa = std::fs::read_to_string(graph_path).unwrap();
+    let fasta = std::fs::read(sequence_path).unwrap();
+    let graph = hip::Graph::from_gfa_text(&gfa).unwrap_or_else(|e| panic!("{}", e));
+    let params = params_of(align_mode, score_matrix);
+    let mut stream = hip::Stream::new(&graph, &params, None, None).unwrap_or_else(|e| panic!("{}", e));
+    // sequences::get_sequences (sequences.rs:5-45) runs inside the library; a file whose name / sequence counts differ
+    // comes back as "wrong fasta file format" (:41-43)
+    stream.push_fasta(&fasta).unwrap_or_else(|e| panic!("{}", e));
+    stream.finish().unwrap();
+    let stdout = std::io::stdout();
+    while let Some(tile) = stream.next().unwrap_or_else(|e| panic!("{}", e)) {
+        for i in 0..tile.status.len() {
+            if tile.status[i] & (hip::RG_READ_WOULD_PANIC | hip::RG_READ_BAD_BASE) != 0 {
+                panic!("read {}: the CPU path panics on this input", tile.first_read + i);
+            }
+            let text = &tile.text[tile.text_off[i] as usize..tile.text_off[i + 1] as usize];
+            // the last line is the GAF record; lines before it are the `println!` warnings of the exec functions
+            let body = &text[..text.len() - 1];
+            let cut = body.iter().rposition(|c| *c == b'\n').map(|p| p + 1).unwrap_or(0);
+            stdout.lock().write_all(&text[..cut]).unwrap();
+            let record = String::from_utf8_lossy(&body[cut..]).into_owned();
+            let n = tile.first_read + i;
+            utils::write_gaf(&record, if align_mode <= 3 { n + 1 } else { n });
+        }
+    }
+}

@@ -93,6 +93,33 @@ def test_bad_inputs_are_status_codes_not_aborts(rg):
         api.Graph.from_gfa_text("S\t1\tA\nS\t2\tC\nL\t1\t-\t2\t+\t0M\n")  # reverse orientation
 
 
+def test_duplicate_segment_ids_are_rejected(rg):
+    """`S 1 A` / `S 1 C` used to be accepted silently (flattened as two rows of one id): RG_ERR_GFA (-2)."""
+    from recgraph_amd import _lib, api
+    with pytest.raises(_lib.RecGraphError) as e:
+        api.Graph.from_gfa_text("S\t1\tA\nS\t1\tC\n")
+    assert e.value.code == -2 and "duplicate segment id 1" in str(e.value)
+    with pytest.raises(_lib.RecGraphError):
+        api.Graph.from_gfa_text("S\t1\tA\nS\t2\tC\nS\t3\tG\nS\t2\tT\nL\t1\t+\t2\t+\t0M\nL\t2\t+\t3\t+\t0M\n")
+
+
+def test_option_switches(rg):
+    """rg_set_option / rg_get_option: the diagnostic switches the GPU tests flip (no getenv on the run path)."""
+    from recgraph_amd import _lib, api
+    lib = _lib.load()
+    for name in ("sweep_i32", "three_sweeps", "no_frec", "debug"):
+        assert lib.rg_get_option(name.encode()) == 0
+        api.set_option(name, 1)
+        assert lib.rg_get_option(name.encode()) == 1
+        api.set_option(name, 0)
+    api.set_option("chunk_reads", 2048)
+    assert lib.rg_get_option(b"chunk_reads") == 2048
+    api.set_option("chunk_reads", 0)
+    assert lib.rg_get_option(b"nope") == -1
+    with pytest.raises(_lib.RecGraphError):
+        api.set_option("nope", 1)
+
+
 def test_graphs_that_are_not_topological_are_rejected(rg):
     """The DP kernels read rows above the current one only; a back-link would make them read rows never written
     (ADVICE r1).  RG_ERR_GRAPH (-4) on the host instead."""
@@ -145,6 +172,13 @@ def test_no_cpu_fallback(rg, example_gfa):
     g = api.Graph.from_gfa_text(example_gfa)
     with pytest.raises(_lib.RecGraphError) as e:
         api.align_batch(g, ["ACGT"], ["r"])
+    assert e.value.code == -3
+    # the streaming engine and the one-call multi-device entry too
+    with pytest.raises(_lib.RecGraphError) as e:
+        api.Stream(g, api.make_params(api.MODE_GLOBAL_POA))
+    assert e.value.code == -3
+    with pytest.raises(_lib.RecGraphError) as e:
+        api.align_batch_multi(g, ["ACGT"], ["r"])
     assert e.value.code == -3
 
 
