@@ -34,6 +34,8 @@ Options& options() {
         o.debug = env("RG_DEBUG");
         { const char* v = getenv("RG_CHUNK_READS"); o.chunk_reads = v ? atoi(v) : 0; }
         { const char* v = getenv("RG_LB_BONUS"); o.lb_bonus = v ? atoi(v) : 0; }
+        o.no_spec = env("RG_NO_SPEC");
+        { const char* v = getenv("RG_SPEC_MARGIN"); if (v) o.spec_margin = atoi(v); }
     });
     return o;
 }
@@ -204,7 +206,7 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
                     const long long* d_off, const uint8_t* d_bad, int nreads, int max_n, DevRecord* d_rec, uint8_t* d_ops,
                     long long ops_stride, unsigned long long* d_cells, hipStream_t stream, size_t mem_budget,
                     unsigned long long* cells_out,
-                    std::vector<std::pair<std::string, std::pair<double, long long>>>& stats);
+                    std::vector<std::pair<std::string, std::pair<double, long long>>>& stats, bool allow_spec);
 }
 
 // Text of read i exactly as the reference prints it (warning lines + GAFStruct::to_string), appended to `out`.
@@ -294,12 +296,17 @@ static std::atomic<int>* option_slot(const char* name) {
     if (!strcmp(name, "no_frec")) return &o.no_frec;
     if (!strcmp(name, "debug")) return &o.debug;
     if (!strcmp(name, "chunk_reads")) return &o.chunk_reads;
+    if (!strcmp(name, "no_spec")) return &o.no_spec;
+    if (!strcmp(name, "spec_margin")) return &o.spec_margin;
     return nullptr;
 }
 int32_t rg_set_option(const char* name, int64_t value) {
     std::atomic<int>* s = option_slot(name);
     if (!s) return fail(RG_ERR_ARG, std::string("unknown option ") + (name ? name : "(null)"));
-    *s = s == &options().chunk_reads ? (int)std::max<int64_t>(0, std::min<int64_t>(value, 1 << 20)) : (value ? 1 : 0);
+    Options& o = options();
+    if (s == &o.chunk_reads) *s = (int)std::max<int64_t>(0, std::min<int64_t>(value, 1 << 20));
+    else if (s == &o.spec_margin) *s = (int)std::max<int64_t>(-(1 << 24), std::min<int64_t>(value, 1 << 24));
+    else *s = value ? 1 : 0;
     return RG_OK;
 }
 int64_t rg_get_option(const char* name) {
@@ -645,7 +652,7 @@ int rg_run_pathwise(rg_batch* b) {
     // what this handle already holds counts towards its share of the device
     unsigned long long c = 0;
     int rc = path_driver_run(h, gd, b->p, b->pw, b->in.reads, b->in.off, b->in.bad, (int)b->nreads, b->max_n, b->d_rec.p,
-                             b->d_ops.p, b->ops_stride, b->d_cells.p, b->stream, b->mem_budget, &c, st);
+                             b->d_ops.p, b->ops_stride, b->d_cells.p, b->stream, b->mem_budget, &c, st, true);
     b->stats.clear();
     for (auto& s : st) b->stats.push_back(KernelStat{s.first, s.second.first, s.second.second});
     if (rc) return rc;

@@ -56,7 +56,18 @@ struct PathWorkImpl {
     int nfsteps = 0, nrsteps = 0;
     unsigned fcap = 0, rcap = 0;
     std::vector<hipEvent_t> ev;
-    Buf<unsigned> need;                 // [4] per chunk: largest nf, nr, forward / reverse record count of a read (k_need)
+    Buf<unsigned> need;                 // [8] per chunk: largest nf, nr, forward / reverse record count of a read (k_need); [4] reads whose
+                                        // speculative bound failed (k_verify)
+    // speculative bound (PickArgs): 12-mer table of the paths, per-read pick, and what aligning the failed reads again needs
+    Buf<uint32_t> kmer_keys;
+    Buf<unsigned long long> kmer_masks;
+    unsigned kmer_mask = 0;
+    Buf<int> pick, rt_idx;
+    Buf<uint8_t> rt_flags, rt_reads, rt_bad, rt_ops;
+    Buf<long long> rt_off;
+    Buf<DevRecord> rt_rec;
+    Buf<unsigned long long> rt_cells;
+    PathWork retry;                     // work buffers of that second pass (a handful of reads)
     unsigned long long* h_sum = nullptr;  // pinned: {cell updates of the chunk, need[0..3]} read back once per chunk
     ~PathWorkImpl() {
         for (auto e : ev) (void)hipEventDestroy(e);
@@ -120,7 +131,7 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
                     const long long* d_off, const uint8_t* d_bad, int nreads, int max_n, DevRecord* d_rec, uint8_t* d_ops,
                     long long ops_stride, unsigned long long* d_cells, hipStream_t stream, size_t mem_budget,
                     unsigned long long* cells_out,
-                    std::vector<std::pair<std::string, std::pair<double, long long>>>& stats) {
+                    std::vector<std::pair<std::string, std::pair<double, long long>>>& stats, bool allow_spec) {
     if (!pw.impl) pw.impl = new PathWorkImpl();
     PathWorkImpl& w = *pw.impl;
     const Options& opt = options();
@@ -165,7 +176,7 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
     };
     int rc;
     if (!w.h_sum) HIPCHK(hipHostMalloc((void**)&w.h_sum, 8 * sizeof(unsigned long long), hipHostMallocDefault));
-    if ((rc = w.need.alloc(4))) return rc;
+    if ((rc = w.need.alloc(8))) return rc;
     if (!w.tables) {
         // rows of every path in program order, with the direction-word slot of the group holding the path
         auto build = [&](const std::vector<int32_t>& goff, const std::vector<GroupDesc>& groups, bool fwd,
@@ -188,6 +199,34 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
         std::vector<int> po, pr, ps;
         build(h.fgoff, h.fgroups, true, po, pr, ps);
         if ((rc = w.fpoff.upload(po)) || (rc = w.fprow.upload(pr)) || (rc = w.fpslot.upload(ps))) return rc;
+        if (P <= 64) {
+            // 12-mers of every path -> paths that contain them (k_pick votes with it): open addressing, 24-bit keys
+            constexpr int K = 12;
+            size_t total = 0;
+            for (int k = 0; k < P; ++k) total += (size_t)std::max(0, po[k + 1] - po[k] - K + 1);
+            size_t size = 64;
+            while (size < 2 * total + 2) size <<= 1;
+            std::vector<uint32_t> keys(size, 0xffffffffu);
+            std::vector<unsigned long long> masks(size, 0ull);
+            for (int k = 0; k < P; ++k) {
+                unsigned key = 0;
+                int valid = 0;
+                for (int t = po[k]; t < po[k + 1]; ++t) {
+                    const size_t c = std::string("ACGT").find(h.lnz[pr[t]]);
+                    if (c == std::string::npos) { valid = 0; key = 0; continue; }
+                    key = ((key << 2) | (unsigned)c) & 0xffffffu;
+                    if (++valid < K) continue;
+                    unsigned hsh = (key * 2654435761u) >> 8;
+                    for (unsigned probe = 0;; ++probe) {
+                        const size_t slot = (hsh + probe) & (size - 1);
+                        if (keys[slot] == 0xffffffffu) keys[slot] = key;
+                        if (keys[slot] == key) { masks[slot] |= 1ull << k; break; }
+                    }
+                }
+            }
+            if ((rc = w.kmer_keys.upload(keys)) || (rc = w.kmer_masks.upload(masks))) return rc;
+            w.kmer_mask = (unsigned)(size - 1);
+        }
         build(h.rgoff, h.rgroups, false, po, pr, ps);
         if ((rc = w.rpoff.upload(po)) || (rc = w.rprow.upload(pr)) || (rc = w.rpslot.upload(ps))) return rc;
         // step tables of the sweeps (record layout documented in k_sweep)
@@ -252,15 +291,18 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
     // forward emissions of the two-sweep pipeline are loose (threshold from the path-0 score): k_sweep16 writes them as
     // (row, lane) records that k_expand filters with the final bound; k_sweep writes plain Cand entries
     const bool use_rec = two_sweep && use16 && !opt.no_frec;
+    // speculative forward bound (PickArgs in rg_path_kernels.hpp): checked by k_verify, failed reads aligned again below
+    const bool spec = use_rec && allow_spec && !semi && P <= 64 && !opt.no_spec;
+    const int spec_margin = opt.spec_margin;
     const int recw = 4 + C;
-    if (w.fcap == 0) { w.fcap = (two_sweep && !use_rec) ? 1u << 20 : 1u << 15; w.rcap = use_rec ? 1u << 16 : 1u << 19; w.frec_cap = 1u << 16; w.rrec_cap = 1u << 15; }   // (reverse records at config 5: mean 2.7 k, largest read of a 4096-read tile 21-25 k)
+    if (w.fcap == 0) { w.fcap = (two_sweep && !use_rec) ? 1u << 20 : 1u << 15; w.rcap = use_rec ? 1u << 16 : 1u << 19; w.frec_cap = spec ? 1u << 15 : 1u << 16; w.rrec_cap = 1u << 15; }   // (reverse records at config 5: mean 2.7 k, largest read of a 4096-read tile 21-25 k)
     stats.clear();
     Timer T{&w, stream};
     int done = 0;
     unsigned long long cells_done = 0;
     while (done < nreads) {
         HIPCHK(hipMemsetAsync(d_cells, 0, sizeof(unsigned long long), stream));      // cell updates of this chunk attempt
-        HIPCHK(hipMemsetAsync(w.need.p, 0, 4 * sizeof(unsigned), stream));
+        HIPCHK(hipMemsetAsync(w.need.p, 0, 8 * sizeof(unsigned), stream));
         const size_t per_read_all = per_read + (mode == RG_MODE_RECOMBINATION ? ((size_t)w.fcap * sizeof(Cand) + (size_t)w.rcap * (sizeof(Cand) + 4) +
                                                                                      (use_rec ? (size_t)(w.frec_cap + w.rrec_cap) * recw * 4 : 0)) : 0);
         int maxchunk = (int)std::min<size_t>(8192, std::max<size_t>(1, budget / per_read_all));
@@ -281,6 +323,7 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
                 (rc = w.rcand.alloc((size_t)chunk * w.rcap)) || (rc = w.ridx.alloc((size_t)chunk * w.rcap)) ||
                 (rc = w.nf.alloc(chunk)) || (rc = w.nr.alloc(chunk)) || (rc = w.lb.alloc(chunk)) || (rc = w.nrec.alloc(chunk)))
                 return rc;
+            if (spec && ((rc = w.pick.alloc(chunk)) || (rc = w.rt_flags.alloc(chunk)))) return rc;
             if (use_rec && ((rc = w.frec.alloc((size_t)chunk * w.frec_cap * recw)) || (rc = w.rrec.alloc((size_t)chunk * w.rrec_cap * recw)) ||
                             (rc = w.nrrec.alloc(chunk))))
                 return rc;
@@ -308,10 +351,17 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
             TIMED(T, "k_seed", launch_seed(se, stream));
         } else {
             if (two_sweep) {
-                Opt0Args oa{gd, sa.sc, d_reads, off, bad, w.fpoff.p, w.fprow.p, w.lb.p, semi ? 1 : 0};
+                Opt0Args oa{gd, sa.sc, d_reads, off, bad, w.fpoff.p, w.fprow.p, w.lb.p, semi ? 1 : 0, nullptr, 0};
+                if (spec) {
+                    PickArgs pa{d_reads, off, bad, w.kmer_keys.p, w.kmer_masks.p, w.kmer_mask, P, w.pick.p};
+                    TIMED(T, "k_pick", launch_pick(pa, chunk, stream));
+                    oa.pick = w.pick.p;
+                    oa.margin = spec_margin;
+                }
                 TIMED(T, "k_opt0", launch_opt0(oa, chunk, C, stream));
                 SweepArgs f = sa;
                 f.rev = 0; f.track_best = 1; f.lb = w.lb.p; f.brc = p.base_rec_cost + opt.lb_bonus; f.maxmatch = maxmatch;
+                f.oob = spec ? 1 : 0;        // tight thresholds: most rows emit nothing (row_end tests the lane maximum first)
                 f.colmax_out = w.mf.p; f.colarg_out = w.mfarg.p; f.cand = w.fcand.p; f.cand_cap = w.fcap; f.ncand_out = w.nf.p;
                 if (use_rec) { f.cand = nullptr; f.cand_cap = 0; f.frec = w.frec.p; f.frec_cap = w.frec_cap; f.ncand_out = w.nrec.p; }
                 f.dirs = w.fdirs.p; f.dirs_stride = fdirs_stride; f.count_cells = 1;
@@ -363,6 +413,7 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
             TIMED(T, "k_search", launch_search(sr, chunk, stream));
             // largest list / record counts of the chunk, read back once after the traceback (no host round trip here)
             launch_need(w.state.p, w.nf.p, w.nr.p, use_rec ? w.nrec.p : nullptr, use_rec ? w.nrrec.p : nullptr, w.need.p, chunk, stream);
+            if (spec) launch_verify(w.state.p, w.lb.p, w.need.p + 4, w.rt_flags.p, chunk, stream);
         }
         LayerArgs la;
         memset(&la, 0, sizeof la);
@@ -386,7 +437,7 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
         TIMED(T, "k_trace", launch_trace(ta, C, stream));
         // ONE read-back per chunk: cell updates + overflow summary, through pinned memory on the batch's stream
         HIPCHK(hipMemcpyAsync(w.h_sum, d_cells, sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
-        HIPCHK(hipMemcpyAsync(w.h_sum + 1, w.need.p, 4 * sizeof(unsigned), hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipMemcpyAsync(w.h_sum + 1, w.need.p, 8 * sizeof(unsigned), hipMemcpyDeviceToHost, stream));
         if ((rc = T.collect(stats))) return rc;
         if (debug) fprintf(stderr, "[rg] chunk of %d reads: done after %.1f ms\n", chunk,
                            (std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() - dbg_t0) * 1e3);
@@ -431,7 +482,41 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
             }
             if (redo) continue;
         }
-        cells_done += w.h_sum[0];
+        const unsigned long long chunk_cells = w.h_sum[0];
+        const unsigned nretry = spec ? reinterpret_cast<const unsigned*>(w.h_sum + 1)[4] : 0u;
+        if (debug && spec) fprintf(stderr, "[rg] speculative bound (margin %d): %u of %d reads did not reach it\n", spec_margin, nretry, chunk);
+        if (nretry) {
+            // The speculative bound of these reads was above what they reach: pairs may have been pruned.  Align them again,
+            // as a batch of their own, with the provable bound, and put the records in place.
+            std::vector<uint8_t> fl((size_t)chunk);
+            std::vector<long long> ho((size_t)chunk + 1);
+            HIPCHK(hipMemcpy(fl.data(), w.rt_flags.p, (size_t)chunk, hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpy(ho.data(), d_off + done, sizeof(long long) * ((size_t)chunk + 1), hipMemcpyDeviceToHost));
+            std::vector<int> idx;
+            std::vector<long long> so(1, 0);
+            for (int i = 0; i < chunk; ++i)
+                if (fl[(size_t)i]) { idx.push_back(i); so.push_back(so.back() + (ho[(size_t)i + 1] - ho[(size_t)i])); }
+            const int nr = (int)idx.size();
+            if ((rc = w.rt_idx.upload(idx)) || (rc = w.rt_off.upload(so)) || (rc = w.rt_reads.alloc((size_t)so.back() + 1)) ||
+                (rc = w.rt_bad.alloc((size_t)nr)) || (rc = w.rt_rec.alloc((size_t)nr)) || (rc = w.rt_ops.alloc((size_t)nr * (size_t)ops_stride)) ||
+                (rc = w.rt_cells.alloc(1)))
+                return rc;
+            HIPCHK(hipMemsetAsync(w.rt_bad.p, 0, (size_t)nr, stream));
+            launch_gather_reads(d_reads, d_off + done, w.rt_idx.p, w.rt_off.p, w.rt_reads.p, nr, stream);
+            std::vector<std::pair<std::string, std::pair<double, long long>>> st2;
+            unsigned long long c2 = 0;
+            if ((rc = path_driver_run(h, gd, p, w.retry, w.rt_reads.p, w.rt_off.p, w.rt_bad.p, nr, max_n, w.rt_rec.p, w.rt_ops.p, ops_stride,
+                                      w.rt_cells.p, stream, 0, &c2, st2, false)))
+                return rc;
+            launch_scatter_results(w.rt_idx.p, w.rt_rec.p, w.rt_ops.p, d_rec + done, d_ops + (long long)done * ops_stride, ops_stride, nr, stream);
+            HIPCHK(hipStreamSynchronize(stream));
+            for (auto& e : st2) {
+                bool found = false;
+                for (auto& st : stats) if (st.first == e.first) { st.second.first += e.second.first; st.second.second += e.second.second; found = true; }
+                if (!found) stats.push_back(e);
+            }
+        }
+        cells_done += chunk_cells;
         done += chunk;
     }
     if (cells_out) *cells_out = cells_done;

@@ -53,7 +53,7 @@ struct SweepArgs {
     int dir_words;             // u32 words per (row, group) slot
     unsigned long long* cells;
     int count_cells;
-    int oob;                   // unused (computed per read from rbw)
+    int oob;                   // 1: the thresholds are tight (speculative bound): the epilogue tests the lane maximum before the columns
     // k_sweep16, two-sweep pipeline: emissions go out as one record per (row, lane) instead of one Cand per cell: (4 + C) ints = {row << 6 | lane, column mask, 0, 0, key[C]} with key = value << 16 | path
     int* frec;                 // [reads][frec_cap][4 + C] or null
     unsigned frec_cap;
@@ -118,9 +118,30 @@ struct Opt0Args {
     const long long* read_off;
     const uint8_t* bad;
     const int* fpoff; const int* fprow;
-    int* lb;                   // out: exact global alignment score of the read against path 0
+    int* lb;                   // out: exact global alignment score of the read against path 0 (pick == null) ...
     int semi;
+    const int* pick;           // ... or against path pick[rd], minus `margin`: the SPECULATIVE bound (see k_pick)
+    int margin;
 };
+
+// Speculative lower bound of the -m 8 search maximum.  The forward sweep of the two-sweep pipeline emits every cell that
+// could still pair up to `lb`; the only PROVABLE lb before the sweep is the alignment of the read against path 0 (the one
+// path that is the alpha of all its groups), which lies ~1500 below the seed at config 5 and lets 40 000 records per read
+// through.  Instead: k_pick votes for the path that shares most sampled 12-mers with the read, k_opt0 aligns the read
+// against THAT path, lb' = that score - margin, and k_verify checks the speculation afterwards: the pruning with lb' is
+// exact iff the search maximum found is >= lb' (every pair that beats or ties it was then kept); the reads that fail
+// (rs->status & ST_RETRY) are aligned again with the provable bound (rg_path_driver.hip).
+struct PickArgs {
+    const uint8_t* reads;
+    const long long* read_off;
+    const uint8_t* bad;
+    const uint32_t* keys;      // open-addressing table of the 12-mers of every path: key (24 bits) or 0xffffffff
+    const unsigned long long* masks;   // paths that contain the 12-mer (P <= 64)
+    unsigned table_mask;       // table size - 1 (power of two)
+    int P;
+    int* pick;                 // out: path with the most votes (lowest id on ties; 0 when nothing matched)
+};
+constexpr uint32_t ST_RETRY = 0x200u;   // internal: the speculative bound of this read did not hold
 
 struct SearchArgs {
     PathGraphDev g;
@@ -184,6 +205,10 @@ void launch_expand(const ExpandArgs& a, int nreads, int C, hipStream_t s);
 void launch_colmax_rec(const ExpandArgs& a, int* colmax_out, int* colarg_out, int nreads, int C, hipStream_t s);
 void launch_seed(const SeedArgs& a, hipStream_t s);
 void launch_opt0(const Opt0Args& a, int nreads, int C, hipStream_t s);
+void launch_pick(const PickArgs& a, int nreads, hipStream_t s);
+void launch_verify(ReadState* st, const int* lb, unsigned* nretry, uint8_t* flags, int nreads, hipStream_t s);
+void launch_gather_reads(const uint8_t* reads, const long long* off, const int* idx, const long long* sub_off, uint8_t* out, int n, hipStream_t s);
+void launch_scatter_results(const int* idx, const DevRecord* sub_rec, const uint8_t* sub_ops, DevRecord* rec, uint8_t* ops, long long ops_stride, int n, hipStream_t s);
 void launch_threshold(const ThrArgs& a, int nreads, hipStream_t s);
 void launch_bound(const BoundArgs& a, int nreads, hipStream_t s);
 void launch_search(const SearchArgs& a, int nreads, hipStream_t s);

@@ -523,7 +523,8 @@ __global__ __launch_bounds__(64) void k_opt0(Opt0Args a) {
 #pragma unroll
         for (int q = 0; q < C; ++q) { GP[q] += pre; row[q] = lane * C + q < ncols ? GP[q] : NEG; }
     }
-    const int beg = a.fpoff[0], cnt = a.fpoff[1] - beg;
+    const int pk = a.pick ? a.pick[rd] : 0;      // (only path 0's score is a provable bound: see PickArgs)
+    const int beg = a.fpoff[pk], cnt = a.fpoff[pk + 1] - beg;
     int semibest = NEG;
     for (int t = 0; t < cnt; ++t) {
         const int i = a.fprow[beg + t];
@@ -562,7 +563,79 @@ __global__ __launch_bounds__(64) void k_opt0(Opt0Args a) {
     int v = NEG;
 #pragma unroll
     for (int q = 0; q < C; ++q) if (q == ql) v = row[q];
-    if (lane == ln) a.lb[rd] = a.semi ? semibest : v;
+    if (lane == ln) a.lb[rd] = (a.semi ? semibest : v) - (a.pick ? a.margin : 0);
+}
+
+// ---------------------------------------------------------------------------------
+// Path vote for the speculative bound (PickArgs): one wave per read samples up to 256 12-mers of the read, looks each up
+// in the table of the paths' 12-mers and gives one vote to every path that contains it; lane b counts the votes of path b.
+__global__ __launch_bounds__(64) void k_pick(PickArgs a) {
+    const int rd = blockIdx.x;
+    const int lane = threadIdx.x;
+    const long long ro = a.read_off[rd];
+    const int n = (int)(a.read_off[rd + 1] - ro);
+    __shared__ unsigned long long smask[256];
+    constexpr int K = 12;
+    const int npos = n - K + 1;
+    if (a.bad[rd] || npos < 1) { if (lane == 0) a.pick[rd] = 0; return; }
+    const int step = (npos + 255) / 256;
+    const int nsamp = (npos + step - 1) / step;             // <= 256
+    for (int t = lane; t < 256; t += WAVE) {
+        unsigned long long m = 0;
+        if (t < nsamp) {
+            const uint8_t* p = a.reads + ro + (long long)t * step;
+            unsigned key = 0;
+            bool ok = true;
+            for (int e = 0; e < K; ++e) { const unsigned c = p[e]; ok = ok && c < 4; key = (key << 2) | (c & 3u); }
+            if (ok) {
+                unsigned h = (key * 2654435761u) >> 8;
+                for (int probe = 0; probe < 64; ++probe) {
+                    const unsigned slot = (h + probe) & a.table_mask;
+                    const unsigned kk = a.keys[slot];
+                    if (kk == key) { m = a.masks[slot]; break; }
+                    if (kk == 0xffffffffu) break;
+                }
+            }
+        }
+        smask[t] = m;
+    }
+    __syncthreads();
+    int votes = 0;
+    for (int t = 0; t < nsamp; ++t) votes += (int)((smask[t] >> lane) & 1ull);
+    if (lane >= a.P) votes = -1;
+    int key = (votes << 8) | (255 - lane);                   // most votes, lowest path id on ties
+    for (int d = WAVE / 2; d >= 1; d >>= 1) key = max(key, __shfl_xor(key, d, WAVE));
+    if (lane == 0) a.pick[rd] = (key >> 8) > 0 ? 255 - (key & 255) : 0;
+}
+
+// After k_search: the speculation held iff the maximum found is >= the bound the forward sweep pruned with.
+__global__ __launch_bounds__(256) void k_verify(ReadState* st, const int* lb, unsigned* nretry, uint8_t* flags, int nreads) {
+    const int rd = blockIdx.x * blockDim.x + threadIdx.x;
+    if (rd >= nreads) return;
+    ReadState* rs = st + rd;
+    uint8_t f = 0;
+    if (!(rs->status & (ST_BAD_BASE | ST_WOULD_PANIC | ST_OVERFLOW)) && rs->fscore < (float)lb[rd]) {
+        rs->status |= ST_RETRY;
+        f = 1;
+        atomicAdd(nretry, 1u);
+    }
+    flags[rd] = f;
+}
+
+// bases of the reads to align again, compacted (sub_off: their offsets in `out`)
+__global__ __launch_bounds__(256) void k_gather_reads(const uint8_t* reads, const long long* off, const int* idx, const long long* sub_off,
+                                                      uint8_t* out) {
+    const int t = blockIdx.x;
+    const long long src = off[idx[t]], len = off[idx[t] + 1] - src, dst = sub_off[t];
+    for (long long i = threadIdx.x; i < len; i += blockDim.x) out[dst + i] = reads[src + i];
+}
+__global__ __launch_bounds__(256) void k_scatter_results(const int* idx, const DevRecord* sub_rec, const uint8_t* sub_ops, DevRecord* rec,
+                                                         uint8_t* ops, long long ops_stride) {
+    const int t = blockIdx.x;
+    const int rd = idx[t];
+    if (threadIdx.x == 0) rec[rd] = sub_rec[t];
+    const int nops = sub_rec[t].n_ops;
+    for (int i = threadIdx.x; i < nops; i += blockDim.x) ops[(long long)rd * ops_stride + i] = sub_ops[(long long)t * ops_stride + i];
 }
 
 // After the forward sweep: seed / best path (pathwise_alignment.rs:305-325,
@@ -1113,6 +1186,17 @@ void launch_opt0(const Opt0Args& a, int nreads, int C, hipStream_t s) {
         case 16: hipLaunchKernelGGL((k_opt0<16>), dim3(nreads), dim3(64), 0, s, a); break;
         default: hipLaunchKernelGGL((k_opt0<32>), dim3(nreads), dim3(64), 0, s, a); break;
     }
+}
+void launch_pick(const PickArgs& a, int nreads, hipStream_t s) { hipLaunchKernelGGL(k_pick, dim3(nreads), dim3(64), 0, s, a); }
+void launch_verify(ReadState* st, const int* lb, unsigned* nretry, uint8_t* flags, int nreads, hipStream_t s) {
+    hipLaunchKernelGGL(k_verify, dim3((nreads + 255) / 256), dim3(256), 0, s, st, lb, nretry, flags, nreads);
+}
+void launch_gather_reads(const uint8_t* reads, const long long* off, const int* idx, const long long* sub_off, uint8_t* out, int n, hipStream_t s) {
+    hipLaunchKernelGGL(k_gather_reads, dim3(n), dim3(256), 0, s, reads, off, idx, sub_off, out);
+}
+void launch_scatter_results(const int* idx, const DevRecord* sub_rec, const uint8_t* sub_ops, DevRecord* rec, uint8_t* ops, long long ops_stride,
+                            int n, hipStream_t s) {
+    hipLaunchKernelGGL(k_scatter_results, dim3(n), dim3(256), 0, s, idx, sub_rec, sub_ops, rec, ops, ops_stride);
 }
 void launch_threshold(const ThrArgs& a, int nreads, hipStream_t s) {
     hipLaunchKernelGGL(k_threshold, dim3((a.wpad + 255) / 256, nreads), dim3(256), 0, s, a);

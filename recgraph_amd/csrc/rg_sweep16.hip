@@ -228,7 +228,7 @@ __global__ __launch_bounds__(64, (kColmax || C > 16) ? 2 : RG_SWEEP16_REV_WAVES)
 #endif
     int minthrk = INT32_MAX;             // lowest threshold of the lane
     int minplain = INT32_MAX;            // lowest threshold of the lane without the member rule (rows every path visits)
-    const bool tight = a.thr != nullptr; // thresholds from the other sweep's column maxima
+    const bool tight = a.thr != nullptr || a.oob; // thresholds from the other sweep's column maxima / from the speculative bound
     const int oob = max((int)((float)(n + 1) * (1.0f - a.rbw) / 2.0f), 1);
     // Emission threshold of lane column q as a z-space key (z << 16): keys are z << 16 | path with |z| < 2^15, so a
     // threshold outside that range means always / never.  `member_rule`: additionally require a true value >= 0 with

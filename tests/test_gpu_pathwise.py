@@ -167,6 +167,43 @@ def test_sweep_kernel_variants_agree(oracle):
         assert texts[i] == og.align(oracle.M8_ABS, r, name="read%d" % i, scores=table)[0]
 
 
+def test_speculative_forward_bound(oracle):
+    """-m 8, two-sweep record pipeline, P <= 64: the forward sweep prunes with a SPECULATIVE bound (score against the path
+    k_pick votes for, minus a margin) that k_verify checks afterwards; reads whose search maximum stayed below it are
+    aligned again with the provable bound.  Same bytes with the speculation off (no_spec), with the default margin, with
+    a zero margin, and with a margin that makes EVERY read fail the check (all of them go through the second pass)."""
+    from recgraph_amd import api, synth
+    g = synth.haplotype_graph(2500, 12, path_len=400, seed=71)
+    rd = synth.haplotype_reads(g, 60, length=400, seed=72, mosaic_frac=0.6) + [g.path_sequence(4)[:333], "ACGTTGCA" * 9, "A", "GG"]
+    gg = api.Graph.from_gfa_text(g.gfa())
+    names = ["r%d" % i for i in range(len(rd))]
+    base = _check(oracle, g.gfa(), rd, api.MODE_RECOMBINATION, oracle.M8_ABS)
+    try:
+        for margin in (0, 40, -1000000):
+            api.set_option("spec_margin", margin)
+            texts, _ = api.align_batch(gg, rd, names, mode=api.MODE_RECOMBINATION)
+            assert texts == base, margin
+            for R, r, B in ((0, 0.1, 0.8), (9, 0.5, 1.0)):
+                exp = _check(oracle, g.gfa(), rd[:20], api.MODE_RECOMBINATION, oracle.M8_ABS, R=R, r=r, B=B)
+                assert exp is not None
+        api.set_option("spec_margin", 160)
+        api.set_option("no_spec", 1)
+        texts, _ = api.align_batch(gg, rd, names, mode=api.MODE_RECOMBINATION)
+        assert texts == base
+    finally:
+        api.set_option("spec_margin", 160)
+        api.set_option("no_spec", 0)
+    # a stream tile with forced failures in two chunks (chunk_reads) keeps the input order
+    try:
+        api.set_option("spec_margin", -1000000)
+        api.set_option("chunk_reads", 24)
+        texts, _ = api.align_stream(gg, rd, names, mode=api.MODE_RECOMBINATION, device_ids=[0], handles_per_device=2, tile_reads=40)
+        assert texts == base
+    finally:
+        api.set_option("spec_margin", 160)
+        api.set_option("chunk_reads", 0)
+
+
 def test_three_sweep_pipeline(oracle):
     """The -m 8 / -m 9 pipeline the driver takes when a gap entry is positive (no path-0 lower bound for the forward
     thresholds: forward column maxima first, reverse sweep, forward again) or on request (RG_THREE_SWEEPS), with the
