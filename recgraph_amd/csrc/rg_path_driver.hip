@@ -295,7 +295,7 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
     const bool spec = use_rec && allow_spec && !semi && P <= 64 && !opt.no_spec;
     const int spec_margin = opt.spec_margin;
     const int recw = 4 + C;
-    if (w.fcap == 0) { w.fcap = (two_sweep && !use_rec) ? 1u << 20 : 1u << 15; w.rcap = use_rec ? 1u << 16 : 1u << 19; w.frec_cap = spec ? 1u << 15 : 1u << 16; w.rrec_cap = 1u << 15; }   // (reverse records at config 5: mean 2.7 k, largest read of a 4096-read tile 21-25 k)
+    if (w.fcap == 0) { w.fcap = (two_sweep && !use_rec) ? 1u << 20 : 1u << 15; w.rcap = use_rec ? 1u << 16 : 1u << 19; w.frec_cap = 1u << 16; w.rrec_cap = 1u << 15; }   // (reverse records at config 5: mean 2.7 k, largest read of a 4096-read tile 21-25 k)
     stats.clear();
     Timer T{&w, stream};
     int done = 0;
