@@ -45,7 +45,7 @@ struct PathWorkImpl {
     bool tables = false;
     Buf<int> fpoff, fprow, fpslot, rpoff, rprow, rpslot;
     Buf<ReadState> state;
-    Buf<int> roll, mf, wr, mfarg, wrarg, thr, flayer, rlayer;
+    Buf<int> roll, mf, mfc, wr, mfarg, wrarg, thr, flayer, rlayer;
     Buf<uint32_t> fdirs, rdirs;
     Buf<Cand> fcand, rcand;
     Buf<unsigned> nf, nr, ridx, nrec, nrrec;
@@ -317,7 +317,7 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
         if ((rc = w.roll.alloc((size_t)chunk * P * wpad))) return rc;
         if (mode == RG_MODE_RECOMBINATION) {
             if ((rc = w.rdirs.alloc((size_t)chunk * rdirs_stride)) || (rc = w.rlayer.alloc((size_t)chunk * layer_stride)) ||
-                (rc = w.mf.alloc((size_t)chunk * wpad)) || (rc = w.wr.alloc((size_t)chunk * wpad)) ||
+                (rc = w.mf.alloc((size_t)chunk * wpad)) || (rc = w.mfc.alloc((size_t)chunk * wpad)) || (rc = w.wr.alloc((size_t)chunk * wpad)) ||
                 (rc = w.mfarg.alloc((size_t)chunk * wpad)) || (rc = w.wrarg.alloc((size_t)chunk * wpad)) ||
                 (rc = w.thr.alloc((size_t)chunk * wpad)) || (rc = w.fcand.alloc((size_t)chunk * w.fcap)) ||
                 (rc = w.rcand.alloc((size_t)chunk * w.rcap)) || (rc = w.ridx.alloc((size_t)chunk * w.rcap)) ||
@@ -363,7 +363,12 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
                 f.rev = 0; f.track_best = 1; f.lb = w.lb.p; f.brc = p.base_rec_cost + opt.lb_bonus; f.maxmatch = maxmatch;
                 f.oob = spec ? 1 : 0;        // tight thresholds: most rows emit nothing (row_end tests the lane maximum first)
                 f.colmax_out = w.mf.p; f.colarg_out = w.mfarg.p; f.cand = w.fcand.p; f.cand_cap = w.fcap; f.ncand_out = w.nf.p;
-                if (use_rec) { f.cand = nullptr; f.cand_cap = 0; f.frec = w.frec.p; f.frec_cap = w.frec_cap; f.ncand_out = w.nrec.p; }
+                if (use_rec) {
+                    // records; exact column maxima as packed values only (k_sweep16<.., 2, ..>): the cell k_bound pairs per
+                    // column comes from the records (k_colmax_rec below)
+                    f.cand = nullptr; f.cand_cap = 0; f.frec = w.frec.p; f.frec_cap = w.frec_cap; f.ncand_out = w.nrec.p;
+                    f.colarg_out = nullptr;
+                }
                 f.dirs = w.fdirs.p; f.dirs_stride = fdirs_stride; f.count_cells = 1;
                 TIMED(T, use16 ? "k_sweep16_fwd" : "k_sweep_fwd", sweep(f, chunk));
                 TIMED(T, "k_seed", launch_seed(se, stream));
@@ -388,8 +393,12 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
                 ExpandArgs ec{w.state.p, w.rrec.p, w.rrec_cap, w.nrrec.p, nullptr, 0, nullptr, nullptr, wpad, p.base_rec_cost, gd.knm, 1, off,
                               p.rec_band_width, p.scores[5]};
                 TIMED(T, "k_colmax_rec", launch_colmax_rec(ec, w.wr.p, w.wrarg.p, chunk, C, stream));
+                // best recorded forward cell per column (value + cell) for k_bound: any real pair is a valid lower bound
+                ExpandArgs fc{w.state.p, w.frec.p, w.frec_cap, w.nrec.p, nullptr, 0, nullptr, nullptr, wpad, p.base_rec_cost, gd.knm, 0, off,
+                              p.rec_band_width, p.scores[5]};
+                TIMED(T, "k_colmax_rec_fwd", launch_colmax_rec(fc, w.mfc.p, w.mfarg.p, chunk, C, stream));
             }
-            BoundArgs ba{gd, w.state.p, off, w.mf.p, w.mfarg.p, w.wr.p, w.wrarg.p, wpad, p.base_rec_cost, p.multi_rec_cost,
+            BoundArgs ba{gd, w.state.p, off, use_rec ? w.mfc.p : w.mf.p, w.mfarg.p, w.wr.p, w.wrarg.p, wpad, p.base_rec_cost, p.multi_rec_cost,
                          p.rec_band_width};
             TIMED(T, "k_bound", launch_bound(ba, chunk, stream));
             if (!two_sweep) {

@@ -176,15 +176,18 @@ struct RowOps16 {
 #define RG_ROW_ST(expr, v) (expr) = (v)
 #endif
 
-// kColmax = false: no per-column maxima (the reverse sweep of the record pipeline: its maxima and their cells are
+// kColmax = 2: per-column maxima as packed VALUES only (8 v_perm + 8 v_pk_max per row instead of 48 compare / select
+// instructions and 24 fewer live registers): the forward sweep of the record pipeline — the other sweep's thresholds
+// need the exact maxima, while the cell k_bound pairs per column is taken from this sweep's records (k_colmax_rec)
+// kColmax = 0: no per-column maxima (the reverse sweep of the record pipeline: its maxima and their cells are
 // taken from its own records by k_colmax_rec)
 // kRec = true: emissions leave as (row, lane) records (a.frec); false: as Cand entries (a.cand) or not at all
 // kWide = true: graphs with more than 64 paths (step entries carry a 64-path page and continuation entries exist); the
 // narrow variant compiles that logic out (page 0, no continuation: it costs registers the forward sweep does not have)
-template <int C, bool kColmax, bool kRec, bool kWide>
-__global__ __launch_bounds__(64, (kColmax || C > 16) ? 2 : RG_SWEEP16_REV_WAVES) void k_sweep16(SweepArgs a) {
+template <int C, int kColmax, bool kRec, bool kWide>
+__global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_WAVES) void k_sweep16(SweepArgs a) {
     constexpr int H = C / 2;
-    constexpr int KRUN = C <= 16 ? (kColmax ? RG_SWEEP16_KRUN : RG_SWEEP16_KRUN_REV) : 0;   // rows kept in registers across the inner rows of a segment
+    constexpr int KRUN = C <= 16 ? (kColmax != 0 ? RG_SWEEP16_KRUN : RG_SWEEP16_KRUN_REV) : 0;   // rows kept in registers across the inner rows of a segment
     const int rd = blockIdx.x;
     const int lane = threadIdx.x;
     const PathGraphDev& g = a.g;
@@ -272,9 +275,12 @@ __global__ __launch_bounds__(64, (kColmax || C > 16) ? 2 : RG_SWEEP16_REV_WAVES)
     }
     __syncthreads();
 
-    int ckey[kColmax ? C : 1], crow[kColmax ? C : 1];   // best (value << 16 | path) per column and its row
+    int ckey[kColmax == 1 ? C : 1], crow[kColmax == 1 ? C : 1];   // best (value << 16 | path) per column and its row
 #pragma unroll
-    for (int q = 0; q < (kColmax ? C : 1); ++q) { ckey[q] = INT32_MIN; crow[q] = 0; }
+    for (int q = 0; q < (kColmax == 1 ? C : 1); ++q) { ckey[q] = INT32_MIN; crow[q] = 0; }
+    int cmv[kColmax == 2 ? H : 1];                                 // packed z-space maxima (values only)
+#pragma unroll
+    for (int r = 0; r < (kColmax == 2 ? H : 1); ++r) cmv[r] = NEGPAIR;
     unsigned ncand = 0;
     unsigned long long cells = 0;
     Cand* cand = !kRec && a.cand ? a.cand + (long long)rd * a.cand_cap : nullptr;
@@ -290,12 +296,20 @@ __global__ __launch_bounds__(64, (kColmax || C > 16) ? 2 : RG_SWEEP16_REV_WAVES)
         // can only raise a non-positive maximum, which loosens thresholds, never tightens them); emissions apply it
         // (it removes most of the negative-valued cells the loose forward thresholds would let through).
         unsigned emask = 0;
-        if (kColmax) {
+        if (kColmax == 1) {
 #pragma unroll
             for (int q = 0; q < C; ++q) {
-                const bool better = bkey[q] > ckey[kColmax ? q : 0];
-                ckey[kColmax ? q : 0] = better ? bkey[q] : ckey[kColmax ? q : 0];
-                crow[kColmax ? q : 0] = better ? i : crow[kColmax ? q : 0];
+                const bool better = bkey[q] > ckey[kColmax == 1 ? q : 0];
+                ckey[kColmax == 1 ? q : 0] = better ? bkey[q] : ckey[kColmax == 1 ? q : 0];
+                crow[kColmax == 1 ? q : 0] = better ? i : crow[kColmax == 1 ? q : 0];
+            }
+        }
+        if (kColmax == 2) {
+#pragma unroll
+            for (int r = 0; r < H; ++r) {
+                // value halves of the two keys of register r: low column | high column << 16
+                const int v2 = (int)__builtin_amdgcn_perm((unsigned)bkey[r + H], (unsigned)bkey[r], 0x07060302u);
+                cmv[kColmax == 2 ? r : 0] = pk_max(cmv[kColmax == 2 ? r : 0], v2);
             }
         }
 #ifdef RG_SWEEP16_NOEMIT
@@ -603,14 +617,23 @@ __global__ __launch_bounds__(64, (kColmax || C > 16) ? 2 : RG_SWEEP16_REV_WAVES)
     }
 
     // ---- outputs ----
-    if (kColmax && a.colmax_out) {
+    if (kColmax == 1 && a.colmax_out) {
 #pragma unroll
         for (int q = 0; q < C; ++q) {
             const int c = lane * C + q;
             if (c < ncols) {
-                a.colmax_out[(long long)rd * wpad + (rev ? n - c : c)] = ckey[kColmax ? q : 0] == INT32_MIN ? NEG32 : (ckey[kColmax ? q : 0] >> 16) + c * gcost;
-                if (a.colarg_out) a.colarg_out[(long long)rd * wpad + (rev ? n - c : c)] = (crow[kColmax ? q : 0] << 8) | (ckey[kColmax ? q : 0] & 255);
+                a.colmax_out[(long long)rd * wpad + (rev ? n - c : c)] = ckey[kColmax == 1 ? q : 0] == INT32_MIN ? NEG32 : (ckey[kColmax == 1 ? q : 0] >> 16) + c * gcost;
+                if (a.colarg_out) a.colarg_out[(long long)rd * wpad + (rev ? n - c : c)] = (crow[kColmax == 1 ? q : 0] << 8) | (ckey[kColmax == 1 ? q : 0] & 255);
             }
+        }
+    }
+    if (kColmax == 2 && a.colmax_out) {
+#pragma unroll
+        for (int q = 0; q < C; ++q) {
+            const int c = lane * C + q;
+            const int pv = cmv[kColmax == 2 ? q % H : 0];
+            const int z = q >= H ? hi16(pv) : lo16(pv);
+            if (c < ncols) a.colmax_out[(long long)rd * wpad + (rev ? n - c : c)] = z <= NEG16 ? NEG32 : z + c * gcost;
         }
     }
     if (a.ncand_out && lane == 0) a.ncand_out[rd] = ncand;
@@ -751,7 +774,7 @@ void launch_colmax_rec(const ExpandArgs& a, int* colmax_out, int* colarg_out, in
     }
 }
 
-template <bool kColmax, bool kRec, bool kWide>
+template <int kColmax, bool kRec, bool kWide>
 static void launch_sweep16_w(const SweepArgs& a, int nreads, int C, hipStream_t s) {
     const size_t bytes = (size_t)(64 + 2 * RG_MAXP + 5 * 64 + (RG_SWEEP16_THRLDS ? C * WAVE : 0)) * sizeof(int);
     switch (C) {
@@ -761,16 +784,17 @@ static void launch_sweep16_w(const SweepArgs& a, int nreads, int C, hipStream_t 
         default: hipLaunchKernelGGL((k_sweep16<32, kColmax, kRec, kWide>), dim3(nreads), dim3(64), bytes, s, a); break;
     }
 }
-template <bool kColmax, bool kRec>
+template <int kColmax, bool kRec>
 static void launch_sweep16_c(const SweepArgs& a, int nreads, int C, hipStream_t s) {
     if (a.g.P > 64) launch_sweep16_w<kColmax, kRec, true>(a, nreads, C, s);
     else launch_sweep16_w<kColmax, kRec, false>(a, nreads, C, s);
 }
 void launch_sweep16(const SweepArgs& a, int nreads, int C, hipStream_t s) {
     // a sweep that writes records and is not asked for column maxima skips their tracking
-    if (a.frec && !a.colmax_out) launch_sweep16_c<false, true>(a, nreads, C, s);
-    else if (a.frec) launch_sweep16_c<true, true>(a, nreads, C, s);
-    else launch_sweep16_c<true, false>(a, nreads, C, s);
+    if (a.frec && !a.colmax_out) launch_sweep16_c<0, true>(a, nreads, C, s);
+    else if (a.frec && !a.colarg_out) launch_sweep16_c<2, true>(a, nreads, C, s);     // maxima without their cells
+    else if (a.frec) launch_sweep16_c<1, true>(a, nreads, C, s);
+    else launch_sweep16_c<1, false>(a, nreads, C, s);
 }
 
 }  // namespace rg
