@@ -433,14 +433,18 @@ def cpu_limit():
     return n, why
 
 
+KERNEL_SOURCES = ("rg_sweep16.hip", "rg_pathwise.hip", "rg_path_driver.hip", "rg_poa.hip", "rg_poa_banded.hip", "rg_poa_local.hip",
+                  "rg_device.hpp", "rg_codes.hpp", "rg_path_kernels.hpp", "rg_path_args.hpp", "rg_poa_args.hpp")
+
+
 def code_hash():
-    """sha256 over the kernel sources: profiles/counters_*.json carry the hash of the tree they were measured on."""
+    """sha256 over the kernel sources and the pipeline driver: profiles/counters_*.json carry the hash of the tree they
+    were measured on (host-side files — ABI, stream, parsers — do not change what the counters count)."""
     h = hashlib.sha256()
     d = os.path.join(ROOT, "recgraph_amd", "csrc")
-    for f in sorted(os.listdir(d)):
-        if f.endswith((".hip", ".hpp", ".cpp")):
-            h.update(f.encode())
-            h.update(open(os.path.join(d, f), "rb").read())
+    for f in KERNEL_SOURCES:
+        h.update(f.encode())
+        h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
 
 

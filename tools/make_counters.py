@@ -103,7 +103,8 @@ for cfg in ("C2", "C3", "C4", "C5"):
     if "SQ_INSTS_VALU" in tot:
         out["valu_winstr_per_read_per_launch"] = tot["SQ_INSTS_VALU"][0] / tot["SQ_INSTS_VALU"][1] / reads_per_launch
     for cn in ("SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_ANY",
-               "SQ_INSTS_SALU", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_LDS", "SQ_INSTS_SMEM"):
+               "SQ_INSTS_SALU", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_LDS", "SQ_INSTS_SMEM", "SQ_WAIT_INST_LDS",
+               "SQ_ACTIVE_INST_LDS", "SQ_ACTIVE_INST_VMEM", "SQ_ACTIVE_INST_SCA", "SQ_ACTIVE_INST_MISC", "SQ_INST_CYCLES_SALU", "SQ_WAVES"):
         if cn in tot:
             out[cn + "_per_launch"] = tot[cn][0] / tot[cn][1]
     json.dump(out, open(os.path.join(O, "counters_%s.json" % cfg), "w"), indent=1)
