@@ -204,6 +204,20 @@ def test_speculative_forward_bound(oracle):
         api.set_option("chunk_reads", 0)
 
 
+def test_scores_beyond_the_32_bit_keys_are_refused():
+    """the i32 sweep packs (value, path) keys as value * 256 + path: a batch whose scores could reach 2^23 in
+    magnitude is refused with RG_ERR_CAPACITY (-5) instead of wrapping silently; just below the limit it still runs."""
+    from recgraph_amd import _lib, api, synth
+    g = synth.haplotype_graph(1200, 4, path_len=400, seed=91)
+    rd = synth.haplotype_reads(g, 4, length=400, seed=92, mosaic_frac=0.5)
+    gg = api.Graph.from_gfa_text(g.gfa())
+    with pytest.raises(_lib.RecGraphError) as e:
+        api.align_batch(gg, rd, None, mode=api.MODE_RECOMBINATION, score_matrix=api.create_score_matrix_i32(6000, -6000))
+    assert e.value.code == -5 and "2^23" in str(e.value)
+    texts, status = api.align_batch(gg, rd, None, mode=api.MODE_PATHWISE, score_matrix=api.create_score_matrix_i32(2000, -2500))
+    assert len(texts) == 4 and not any(status)
+
+
 def test_three_sweep_pipeline(oracle):
     """The -m 8 / -m 9 pipeline the driver takes when a gap entry is positive (no path-0 lower bound for the forward
     thresholds: forward column maxima first, reverse sweep, forward again) or on request (RG_THREE_SWEEPS), with the
