@@ -287,7 +287,10 @@ int32_t rg_stream_handles(rg_stream* s);      /* batch handles that aligned at l
 
 /* Process-wide diagnostic switches, also settable through the environment (read once when the library is loaded):
  * "sweep_i32" (RG_SWEEP_I32: i32 sweep kernel even when the packed 16-bit one is admissible), "three_sweeps"
- * (RG_THREE_SWEEPS), "no_frec" (RG_NO_FREC: Cand-list forward emission), "debug" (RG_DEBUG: list statistics on stderr).
+ * (RG_THREE_SWEEPS), "no_frec" (RG_NO_FREC: Cand-list forward emission), "no_spec" (RG_NO_SPEC: -m 8 forward sweep
+ * pruned with the provable bound instead of the speculative one), "spec_margin" (RG_SPEC_MARGIN, an integer: what the
+ * speculative bound subtracts from the picked path's score; default 160), "chunk_reads" (RG_CHUNK_READS, an integer:
+ * most reads one pathwise kernel launch takes), "debug" (RG_DEBUG: list statistics on stderr).
  * The variants compute the same records byte for byte (tests/test_gpu_pathwise.py). */
 int32_t rg_set_option(const char* name, int64_t value);
 int64_t rg_get_option(const char* name);      /* -1: unknown option */

@@ -168,6 +168,7 @@ struct rg_stream {
                 rc = rg_batch_set_reads(h, t->bases.data(), t->off.data(), t->n);
             }
             ts[1] = now_s();
+            if (rc == RG_OK) { std::string().swap(t->bases); std::vector<int64_t>().swap(t->off); }    // the handle holds its own copy now
             if (rc == RG_OK) rc = rg_batch_run(h);
             ts[2] = now_s();
             if (rc == RG_OK) rc = rg_batch_fetch(h);

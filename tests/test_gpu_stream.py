@@ -129,6 +129,29 @@ def test_fasta_in_gaf_out_through_the_library_and_the_cli(tmp_path, oracle, exam
     assert out.read_text() == "".join(exp[1:])
 
 
+def test_push_fasta_pushes_tiles_while_parsing_and_refuses_a_bad_file(example_gfa):
+    from recgraph_amd import api
+    g = api.Graph.from_gfa_text(example_gfa)
+    fa = open(os.path.join(ROOT, "tests", "golden", "example_reads.fa"), "rb").read()
+    whole = api.Reads.from_fasta_text(fa)
+    base, _ = api.align_batch(g, whole.sequences(), whole.names, mode=api.MODE_GLOBAL_POA)
+    st = api.Stream(g, api.make_params(api.MODE_GLOBAL_POA), device_ids=[0], tile_reads=7)
+    assert st.push_fasta(fa) == len(whole)
+    assert st.push_fasta(b">x y\nacgtn-ACGT\n") == 1          # canonicalised inside: ACGTNNACGT
+    st.finish()
+    tiles = list(st)
+    assert [t.n for t in tiles] == [7] * 7 + [3, 1]
+    assert b"".join(t.text for t in tiles[:-1]).decode() == "".join(base)
+    one, _ = api.align_batch(g, ["ACGTNNACGT"], ["x y"], mode=api.MODE_GLOBAL_POA, seq_index_base=len(whole) + 1)
+    assert tiles[-1].text.decode() == one[0]
+    st.close()
+    # name / sequence counts differ at the end of the text: refused (sequences.rs:41-43), after the complete reads before it were pushed
+    st = api.Stream(g, api.make_params(api.MODE_GLOBAL_POA), device_ids=[0], tile_reads=2)
+    with pytest.raises(api._lib.RecGraphError, match="wrong fasta file format"):
+        st.push_fasta(b">a\nACGT\n>b\nGGCC\n>c\nTTAA\n>d\n")
+    st.close()
+
+
 def test_two_distinct_devices():
     """The shared tile queue over two different GPUs (skipped on a one-GPU box)."""
     from recgraph_amd import _lib, api

@@ -32,6 +32,9 @@ with open(fa, "w") as f:
             k += 1
         b += 1
 gen_s = time.time() - t0
+# VRAM freed by a process that just exited is scrubbed by the driver (~35 GB/s) and the next process's hipMalloc waits for
+# it (profiles/r03_notes.md): measure the CLI on an idle device
+time.sleep(float(os.environ.get("RG_E2E_IDLE", "15")))
 t0 = time.time()
 with open(out, "wb") as fo:
     p = subprocess.run([sys.executable, "-m", "recgraph_amd.cli", fa, gfa, "-m", "8", "-R", "4", "-r", "0.1", "-B", "1", "--timing"], stdout=fo,
