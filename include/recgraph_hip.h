@@ -241,7 +241,10 @@ typedef struct rg_stream_opts {
     int32_t keep_records;         /* 1: every tile also keeps its records (rg_stream_result.records)           */
     int64_t seq_index_base;       /* seq_index of the first read pushed                                        */
     int32_t no_text;              /* 1: skip the GAF text (records only)                                       */
-    int32_t reserved;
+    int32_t spin_wait;            /* 0: rg_stream_create sets hipDeviceScheduleBlockingSync on its devices (a process-wide
+                                     device flag): host threads waiting for the GPU sleep instead of spinning — by default
+                                     every HIP wait burns a CPU, 3 per GPU here, which a node-wide CPU quota cannot afford.
+                                     1: leave the devices' scheduling flags alone                              */
 } rg_stream_opts;
 typedef struct rg_stream_result {
     int64_t first_read;           /* index (push order) of the tile's first read                               */

@@ -23,7 +23,7 @@ class GafFields(C.Structure):
 
 class StreamOpts(C.Structure):
     _fields_ = [("handles_per_device", C.c_int32), ("tile_reads", C.c_int32), ("format_threads", C.c_int32),
-                ("keep_records", C.c_int32), ("seq_index_base", C.c_int64), ("no_text", C.c_int32), ("reserved", C.c_int32)]
+                ("keep_records", C.c_int32), ("seq_index_base", C.c_int64), ("no_text", C.c_int32), ("spin_wait", C.c_int32)]
 
 
 class StreamResult(C.Structure):

@@ -470,13 +470,13 @@ class Stream:
     reads pulled by ``handles_per_device`` batch handles per device from one queue, results in input order."""
 
     def __init__(self, graph, params, device_ids=None, handles_per_device=0, tile_reads=0, format_threads=0,
-                 seq_index_base=1, keep_records=False, no_text=False):
+                 seq_index_base=1, keep_records=False, no_text=False, spin_wait=False):
         lib = _lib.load()
         self.graph = graph
         o = _lib.StreamOpts()
         lib.rg_stream_opts_default(C.byref(o))
         o.handles_per_device, o.tile_reads, o.format_threads = handles_per_device, tile_reads, format_threads
-        o.seq_index_base, o.keep_records, o.no_text = seq_index_base, int(keep_records), int(no_text)
+        o.seq_index_base, o.keep_records, o.no_text, o.spin_wait = seq_index_base, int(keep_records), int(no_text), int(spin_wait)
         devs = (C.c_int32 * len(device_ids))(*device_ids) if device_ids is not None else None
         self._h = C.c_void_p()
         check(lib.rg_stream_create(graph._h, C.byref(params), devs, len(device_ids) if device_ids is not None else 0,

@@ -71,9 +71,7 @@ struct Timed {
         return RG_OK;
     }
     int collect() {
-        if (!b->done_ev) HIPCHK(hipEventCreateWithFlags(&b->done_ev, hipEventBlockingSync | hipEventDisableTiming));
-        HIPCHK(hipEventRecord(b->done_ev, b->stream));
-        HIPCHK(hipEventSynchronize(b->done_ev));     // blocking wait (no spinning host thread per handle)
+        HIPCHK(hipStreamSynchronize(b->stream));
         for (auto& pe : pending) {
             float ms = 0;
             HIPCHK(hipEventElapsedTime(&ms, b->ev_pool[pe.second].first, b->ev_pool[pe.second].second));
