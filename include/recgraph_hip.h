@@ -241,10 +241,10 @@ typedef struct rg_stream_opts {
     int32_t keep_records;         /* 1: every tile also keeps its records (rg_stream_result.records)           */
     int64_t seq_index_base;       /* seq_index of the first read pushed                                        */
     int32_t no_text;              /* 1: skip the GAF text (records only)                                       */
-    int32_t spin_wait;            /* 0: rg_stream_create sets hipDeviceScheduleBlockingSync on its devices (a process-wide
-                                     device flag): host threads waiting for the GPU sleep instead of spinning — by default
-                                     every HIP wait burns a CPU, 3 per GPU here, which a node-wide CPU quota cannot afford.
-                                     1: leave the devices' scheduling flags alone                              */
+    int32_t spin_wait;            /* 0: the long waits for the device (one per kernel pipeline) poll an event with short
+                                     sleeps — every HIP wait spins a CPU by default, 3 threads per GPU here, which a
+                                     node under a CPU quota cannot afford; 1: hipStreamSynchronize (process-wide, same
+                                     as rg_set_option("spin_wait", 1))                                          */
 } rg_stream_opts;
 typedef struct rg_stream_result {
     int64_t first_read;           /* index (push order) of the tile's first read                               */
@@ -293,7 +293,8 @@ int32_t rg_stream_handles(rg_stream* s);      /* batch handles that aligned at l
  * (RG_THREE_SWEEPS), "no_frec" (RG_NO_FREC: Cand-list forward emission), "no_spec" (RG_NO_SPEC: -m 8 forward sweep
  * pruned with the provable bound instead of the speculative one), "spec_margin" (RG_SPEC_MARGIN, an integer: what the
  * speculative bound subtracts from the picked path's score; default 160), "chunk_reads" (RG_CHUNK_READS, an integer:
- * most reads one pathwise kernel launch takes), "debug" (RG_DEBUG: list statistics on stderr).
+ * most reads one pathwise kernel launch takes), "spin_wait" (RG_SPIN_WAIT: hipStreamSynchronize instead of sleep-polling
+ * for the long waits), "debug" (RG_DEBUG: list statistics on stderr).
  * The variants compute the same records byte for byte (tests/test_gpu_pathwise.py). */
 int32_t rg_set_option(const char* name, int64_t value);
 int64_t rg_get_option(const char* name);      /* -1: unknown option */

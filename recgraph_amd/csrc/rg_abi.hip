@@ -12,6 +12,9 @@
 #include <mutex>
 #include <thread>
 
+#include <unistd.h>
+
+#include <cstdio>
 #include <cstdlib>
 
 #include "rg_batch_impl.hpp"
@@ -35,9 +38,24 @@ Options& options() {
         { const char* v = getenv("RG_CHUNK_READS"); o.chunk_reads = v ? atoi(v) : 0; }
         { const char* v = getenv("RG_LB_BONUS"); o.lb_bonus = v ? atoi(v) : 0; }
         o.no_spec = env("RG_NO_SPEC");
+        o.spin_wait = env("RG_SPIN_WAIT");
         { const char* v = getenv("RG_SPEC_MARGIN"); if (v) o.spec_margin = atoi(v); }
     });
     return o;
+}
+
+int wait_stream_sleeping(void* stream, void* ev) {
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (options().spin_wait || !ev) return (int)hipStreamSynchronize(s);
+    hipEvent_t e = static_cast<hipEvent_t>(ev);
+    hipError_t rc = hipEventRecord(e, s);
+    if (rc != hipSuccess) return (int)rc;
+    for (unsigned spins = 0;; ++spins) {
+        rc = hipEventQuery(e);
+        if (rc != hipErrorNotReady) return (int)rc;
+        (void)hipGetLastError();                         // hipErrorNotReady is sticky in hipGetLastError
+        usleep(50);                                      // ~100 us per poll with the timer slack: a few % of one CPU per thread
+    }
 }
 }  // namespace rg
 
@@ -71,7 +89,8 @@ struct Timed {
         return RG_OK;
     }
     int collect() {
-        HIPCHK(hipStreamSynchronize(b->stream));
+        if (!b->done_ev) HIPCHK(hipEventCreateWithFlags(&b->done_ev, hipEventDisableTiming));
+        HIPCHK((hipError_t)wait_stream_sleeping(b->stream, b->done_ev));
         for (auto& pe : pending) {
             float ms = 0;
             HIPCHK(hipEventElapsedTime(&ms, b->ev_pool[pe.second].first, b->ev_pool[pe.second].second));
@@ -156,6 +175,8 @@ int run_poa(rg_batch* b) {
         const long long maxchunk = (long long)std::min<size_t>((size_t)b->nreads, budget / per_read);
         const long long nchunks = (b->nreads + maxchunk - 1) / maxchunk;
         const long long chunk = (b->nreads + nchunks - 1) / nchunks;      // even launches
+        if (options().debug) fprintf(stderr, "[rg] run_poa attempt %d: cap_cells %lld, budget %.1f GB, per read %.2f MB, chunk %lld of %lld reads\n", attempt,
+                                     b->cap_cells, budget / 1e9, per_read / 1e6, chunk, (long long)b->nreads);
         if ((rc = b->d_arena_m.alloc((size_t)chunk * b->cap_cells * planes)) ||
             (rc = b->d_arena_pw.alloc((size_t)chunk * b->cap_cells * planes)) || (rc = b->d_rinfo.alloc((size_t)chunk * h.L))) {
             if (rc == RG_ERR_HIP && chunk > 1 && oom_shift < 8) { ++oom_shift; continue; }   // out of memory: smaller launches
@@ -297,6 +318,7 @@ static std::atomic<int>* option_slot(const char* name) {
     if (!strcmp(name, "debug")) return &o.debug;
     if (!strcmp(name, "chunk_reads")) return &o.chunk_reads;
     if (!strcmp(name, "no_spec")) return &o.no_spec;
+    if (!strcmp(name, "spin_wait")) return &o.spin_wait;
     if (!strcmp(name, "spec_margin")) return &o.spec_margin;
     return nullptr;
 }

@@ -216,8 +216,10 @@ struct rg_batch {
     uint64_t cells = 0;
     std::vector<KernelStat> stats;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+    hipEvent_t done_ev = nullptr;      // end-of-run marker polled by wait_stream_sleeping
     ~rg_batch() {
         for (auto& e : ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+        if (done_ev) (void)hipEventDestroy(done_ev);
         if (stream) (void)hipStreamDestroy(stream);
     }
 };

@@ -23,12 +23,20 @@ struct Options {
     std::atomic<int> three_sweeps{0};   // RG_THREE_SWEEPS: force the three-sweep -m 8 pipeline
     std::atomic<int> no_frec{0};        // RG_NO_FREC: Cand-list forward emission instead of records
     std::atomic<int> debug{0};          // RG_DEBUG: candidate / record statistics on stderr
+    std::atomic<int> spin_wait{0};      // RG_SPIN_WAIT: long waits for the device through hipStreamSynchronize (spins a CPU) instead of
+                                        // hipEventQuery + usleep polling
     std::atomic<int> no_spec{0};        // RG_NO_SPEC: -m 8 forward sweep with the provable bound (path 0) instead of the speculative one
     std::atomic<int> spec_margin{160};  // RG_SPEC_MARGIN: what the speculative bound subtracts from the picked path's score
     std::atomic<int> lb_bonus{0};       // RG_LB_BONUS (experiments only): added to the forward sweep's lower bound; > 0 may drop candidates
     std::atomic<int> chunk_reads{0};    // RG_CHUNK_READS: most reads one pathwise kernel launch takes (0: what the HBM budget allows, <= 8192)
 };
 Options& options();
+// Waits for everything enqueued on `stream` so far WITHOUT spinning: records `ev` and polls it with short sleeps.  Every HIP
+// wait spins by default (hipStreamSynchronize / hipEventSynchronize of a 0.5 s kernel = 0.5 s of CPU, hipEventBlockingSync
+// events included: tools/probes/wait_probe.hip) — three such threads per GPU on a node under a CPU quota starve everything
+// else — and the runtime's own blocking mode (hipDeviceScheduleBlockingSync) deadlocked here when two threads sat in
+// hipFree's implicit device synchronisation at once (profiles/r03_notes.md).  Returns a hipError_t as int.
+int wait_stream_sleeping(void* stream, void* ev);
 
 int fail(int code, const std::string& msg);
 

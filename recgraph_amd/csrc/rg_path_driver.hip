@@ -56,6 +56,7 @@ struct PathWorkImpl {
     int nfsteps = 0, nrsteps = 0;
     unsigned fcap = 0, rcap = 0;
     std::vector<hipEvent_t> ev;
+    hipEvent_t done_ev = nullptr;       // end-of-chunk marker polled by wait_stream_sleeping (no spinning host thread per handle)
     Buf<unsigned> need;                 // [8] per chunk: largest nf, nr, forward / reverse record count of a read (k_need); [4] reads whose
                                         // speculative bound failed (k_verify)
     // speculative bound (PickArgs): 12-mer table of the paths, per-read pick, and what aligning the failed reads again needs
@@ -71,6 +72,7 @@ struct PathWorkImpl {
     unsigned long long* h_sum = nullptr;  // pinned: {cell updates of the chunk, need[0..3]} read back once per chunk
     ~PathWorkImpl() {
         for (auto e : ev) (void)hipEventDestroy(e);
+        if (done_ev) (void)hipEventDestroy(done_ev);
         if (h_sum) (void)hipHostFree(h_sum);
     }
 };
@@ -101,7 +103,8 @@ struct Timer {
         return RG_OK;
     }
     int collect(std::vector<std::pair<std::string, std::pair<double, long long>>>& stats) {
-        HIPCHK(hipStreamSynchronize(s));
+        if (!w->done_ev) HIPCHK(hipEventCreateWithFlags(&w->done_ev, hipEventDisableTiming));
+        HIPCHK((hipError_t)wait_stream_sleeping(s, w->done_ev));
         for (auto& p : pend) {
             float ms = 0;
             HIPCHK(hipEventElapsedTime(&ms, w->ev[p.e0], w->ev[p.e1]));

@@ -62,7 +62,10 @@ __device__ __forceinline__ int m_at(const M0Ctx& x, int p, int c) {
     return x.min_score;
 }
 
-template <bool kLdsRead>
+// kUniGap: every read base has the same gap cost (all matrices the reference's CLI builds, score_matrix.rs:35-105): the
+// prefix sum G of the left sweep's gap costs is then (columns so far) * g and needs neither its DPP scan nor the two
+// dependent LDS lookups of the chunk head's base.
+template <bool kLdsRead, bool kUniGap>
 __global__ __launch_bounds__(64) void k_m0_simd(PoaArgs a) {
     const int slot = blockIdx.x;              // arena slot of this launch
     const int rd = a.read_base + slot;        // read of the batch
@@ -94,6 +97,7 @@ __global__ __launch_bounds__(64) void k_m0_simd(PoaArgs a) {
     int4* rinfo = a.rinfo + (long long)slot * L;
     const unsigned long long bta = (unsigned long long)a.bta[rd];
     const int GAP = 5;
+    const int ugap = sct[GAP];            // (kUniGap: the cost of every read base)
     M0Ctx cx{am, rinfo, a.col0, 2 * W * sct[read_at(1) * 6 + GAP]};  // global_abpoa.rs:20
     long long off = 0;
     unsigned long long ncells = 0;
@@ -207,8 +211,17 @@ __global__ __launch_bounds__(64) void k_m0_simd(PoaArgs a) {
                 // columns cb-1 .. cb+63 of the row above lie in at most two of its chunks: k0 and k0 + 1
                 const int k0 = (cb - 1 - p_start) >> 6;             // arithmetic shift: -1 when cb - 1 < p_start
                 const int lo = pv_chunk(k0 < 0 ? 0 : k0), hi = pv_chunk(k0 + 1 < KC ? k0 + 1 : KC - 1);
-                bu = prev_at(c, k0, lo, hi);
-                const int dprev = prev_at(c - 1, k0, lo, hi);     // (the shuffles inside must run with all lanes enabled)
+                bu = prev_at(c, k0, lo, hi);                      // (the shuffles inside must run with all lanes enabled)
+                // m[i-1][c-1] is the lane to the left's m[i-1][c]; lane 0 takes column cb - 1 straight from the registers
+                // of the row above (a wave-uniform position: v_readlane, no second pair of shuffles)
+                const int i0 = cb - 1 - p_start;
+                const int e_lo = __builtin_amdgcn_readlane(lo, i0 & (WAVE - 1)), e_hi = __builtin_amdgcn_readlane(hi, i0 & (WAVE - 1));
+                const int e0 = (cb - 1 >= p_start && cb - 1 < p_right) ? ((i0 >> 6) == k0 ? e_lo : e_hi) : cx.min_score;
+                // (the DPP move must run with every lane enabled: as an operand of the select below the compiler sinks it into the
+                // `lane != 0` region, where lane 1 reads a disabled lane and keeps the identity; the empty asm pins it here)
+                int left_bu = dpp_shr1(bu, 0);
+                asm volatile("" : "+v"(left_bu));
+                const int dprev = lane == 0 ? e0 : left_bu;
                 bd = (c - 1 == 0 && i - 1 > 0) ? c0_prev : dprev;
             }
             if (act) {
@@ -233,17 +246,20 @@ __global__ __launch_bounds__(64) void k_m0_simd(PoaArgs a) {
                     const bool isd = ds > us;                      // ties -> up (:144)
                     b = isd ? ds : us;
                     pw = isd ? ((uint32_t)pd << 2 | 1u) : ((uint32_t)pu << 2 | 2u);
-                    const int head = start + ((c - start) / 8) * 8;
-                    gc = sct[read_at(head) * 6 + GAP];           // gap key of the chunk head (:157)
+                    if (!kUniGap) {
+                        const int head = start + ((c - start) / 8) * 8;
+                        gc = sct[read_at(head) * 6 + GAP];       // gap key of the chunk head (:157)
+                    }
                 } else {
                     const int ds = bd + (nwp ? sct[rc * 6 + li] : sct[li * 6 + rc]);  // swapped key (:206)
                     const bool isd = ds >= us;                     // tail: D > U > L (:175-181)
                     b = isd ? ds : us;
                     pw = isd ? ((uint32_t)pd << 2 | 1u) : ((uint32_t)pu << 2 | 2u);
-                    gc = sct[rc * 6 + GAP];
+                    if (!kUniGap) gc = sct[rc * 6 + GAP];
                 }
             }
-            const int G = dpp_incl_sum(gc) + carry_G;
+            // active lanes are a prefix of the wave: with one gap cost for every base the inclusive sum is (lane + 1) * g
+            const int G = kUniGap ? carry_G + (lane + 1) * ugap : dpp_incl_sum(gc) + carry_G;
             const int y = act ? b - G : INT32_MIN / 2;
             const int zi = dpp_incl_max(y, INT32_MIN / 2);
             int zprev = dpp_shr1(zi, INT32_MIN / 2);
@@ -264,7 +280,7 @@ __global__ __launch_bounds__(64) void k_m0_simd(PoaArgs a) {
                 best_v = cmx; best_c = cb + 63 - __clzll((long long)at);
             }
             carry_z = max(carry_z, __builtin_amdgcn_readlane(zi, WAVE - 1));
-            carry_G = __builtin_amdgcn_readlane(G, WAVE - 1);
+            carry_G = kUniGap ? carry_G + min(WAVE, right - cb) * ugap : __builtin_amdgcn_readlane(G, WAVE - 1);
         }
         if (lane == 0) rinfo[i] = make_int4((int)off, start, right, best_c);
         off += width;
@@ -339,8 +355,12 @@ __global__ __launch_bounds__(64) void k_m0_simd(PoaArgs a) {
 
 void launch_m0_simd(const PoaArgs& a, hipStream_t s) {
     const size_t bytes = 36 * sizeof(int) + (a.lds_read ? (((size_t)a.max_n + 2 + 3) & ~(size_t)3) : 0);
-    if (a.lds_read) hipLaunchKernelGGL((k_m0_simd<true>), dim3(a.nreads), dim3(64), bytes, s, a);
-    else hipLaunchKernelGGL((k_m0_simd<false>), dim3(a.nreads), dim3(64), bytes, s, a);
+    bool uni = true;                     // one gap cost for every read base (ACGTN)
+    for (int b = 1; b < 5; ++b) uni = uni && a.sc.t[b * 6 + 5] == a.sc.t[5];
+    if (a.lds_read && uni) hipLaunchKernelGGL((k_m0_simd<true, true>), dim3(a.nreads), dim3(64), bytes, s, a);
+    else if (a.lds_read) hipLaunchKernelGGL((k_m0_simd<true, false>), dim3(a.nreads), dim3(64), bytes, s, a);
+    else if (uni) hipLaunchKernelGGL((k_m0_simd<false, true>), dim3(a.nreads), dim3(64), bytes, s, a);
+    else hipLaunchKernelGGL((k_m0_simd<false, false>), dim3(a.nreads), dim3(64), bytes, s, a);
 }
 
 }  // namespace rg

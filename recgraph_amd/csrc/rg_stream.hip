@@ -159,6 +159,8 @@ struct rg_stream {
             }
             double ts[5];
             ts[0] = now_s();
+            const bool dbg = options().debug != 0;
+            if (dbg) fprintf(stderr, "[rg] stream worker %d: tile %lld (%lld reads) starts\n", slot, (long long)t->id, (long long)t->n);
             int rc;
             if (!h) {
                 // (the handle is created on the first tile: its work buffers are sized by what it actually aligns)
@@ -192,6 +194,8 @@ struct rg_stream {
                 t->err = g_last_error;
             }
             ts[4] = now_s();
+            if (dbg) fprintf(stderr, "[rg] stream worker %d: tile %lld done rc %d: set_reads %.1f run %.1f fetch %.1f format %.1f ms\n", slot, (long long)t->id, rc,
+                             (ts[1] - ts[0]) * 1e3, (ts[2] - ts[1]) * 1e3, (ts[3] - ts[2]) * 1e3, (ts[4] - ts[3]) * 1e3);
             {
                 std::lock_guard<std::mutex> lk(smu);
                 for (int k = 0; k < 4; ++k) host_s[k] += ts[k + 1] - ts[k];
@@ -237,6 +241,7 @@ int32_t rg_stream_create(const rg_graph* g, const rg_params* p, const int32_t* d
     } else {
         for (int d = 0; d < visible; ++d) s->devs.push_back(d);
     }
+    if (s->o.spin_wait) options().spin_wait = 1;      // (process-wide, like rg_set_option("spin_wait", 1))
     const int K = s->o.handles_per_device > 0 ? std::min(s->o.handles_per_device, 8) : 3;
     s->tile_reads = s->o.tile_reads > 0 ? s->o.tile_reads : (mode_is_pathwise(p->mode) ? 4096 : 8192);
     const int nworkers = K * (int)s->devs.size();
@@ -247,10 +252,6 @@ int32_t rg_stream_create(const rg_graph* g, const rg_params* p, const int32_t* d
     for (size_t k = 0; k < s->devs.size(); ++k) {
         DevGuard dg(s->devs[k]);
         HIPCHK(dg.err);
-        // host threads that wait for this device sleep instead of spinning (see rg_stream_opts.spin_wait); the flag can be
-        // set on an active context (measured: hipStreamSynchronize / hipEventSynchronize of a 0.5 s kernel cost 0.5 s of CPU
-        // without it, blocking events included, and 0.003 s with it)
-        if (!s->o.spin_wait && hipSetDeviceFlags(hipDeviceScheduleBlockingSync) != hipSuccess) (void)hipGetLastError();
         size_t fr = 0, tot = 0;
         HIPCHK(hipMemGetInfo(&fr, &tot));
         const size_t same = (size_t)std::count(s->devs.begin(), s->devs.end(), s->devs[k]);
