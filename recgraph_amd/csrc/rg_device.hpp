@@ -61,8 +61,14 @@ template <int kCtrl, int kRowMask>
 __device__ __forceinline__ int dpp_mov(int identity, int v) {
     return __builtin_amdgcn_update_dpp(identity, v, kCtrl, kRowMask, 0xf, false);
 }
-// value of lane-1 (lane 0 gets `identity`)
-__device__ __forceinline__ int dpp_shr1(int v, int identity) { return dpp_mov<0x138, 0xf>(identity, v); }
+// value of lane-1 (lane 0 gets `identity`).  The empty asm pins the move where the caller wrote it: as an operand of a
+// `lane == 0 ? a : dpp_shr1(x)` select the compiler sank it into the `lane != 0` region, where lane 1 reads a DISABLED
+// lane 0 and silently keeps the identity (found in k_m0_simd, profiles/r03_notes.md).
+__device__ __forceinline__ int dpp_shr1(int v, int identity) {
+    int r = dpp_mov<0x138, 0xf>(identity, v);
+    asm volatile("" : "+v"(r));
+    return r;
+}
 
 __device__ __forceinline__ int dpp_incl_max(int v, int identity) {
     v = max(v, dpp_mov<0x111, 0xf>(identity, v));   // row_shr:1

@@ -217,10 +217,8 @@ __global__ __launch_bounds__(64) void k_m0_simd(PoaArgs a) {
                 const int i0 = cb - 1 - p_start;
                 const int e_lo = __builtin_amdgcn_readlane(lo, i0 & (WAVE - 1)), e_hi = __builtin_amdgcn_readlane(hi, i0 & (WAVE - 1));
                 const int e0 = (cb - 1 >= p_start && cb - 1 < p_right) ? ((i0 >> 6) == k0 ? e_lo : e_hi) : cx.min_score;
-                // (the DPP move must run with every lane enabled: as an operand of the select below the compiler sinks it into the
-                // `lane != 0` region, where lane 1 reads a disabled lane and keeps the identity; the empty asm pins it here)
-                int left_bu = dpp_shr1(bu, 0);
-                asm volatile("" : "+v"(left_bu));
+                // (dpp_shr1 pins the move here, where every lane is enabled: see rg_device.hpp)
+                const int left_bu = dpp_shr1(bu, 0);
                 const int dprev = lane == 0 ? e0 : left_bu;
                 bd = (c - 1 == 0 && i - 1 > 0) ? c0_prev : dprev;
             }
