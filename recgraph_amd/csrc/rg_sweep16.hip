@@ -49,6 +49,10 @@ __device__ __forceinline__ int pk_max(int a, int b) {
 __device__ __forceinline__ int pk_minu(int a, int b) {
     return __builtin_bit_cast(int, __builtin_elementwise_min(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
 }
+// saturating packed difference (v_pk_sub_i16 ... clamp): the sign of each half is the sign of the true difference
+__device__ __forceinline__ int pk_sub_sat(int a, int b) {
+    return __builtin_bit_cast(int, __builtin_elementwise_sub_sat(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b)));
+}
 // per half: 0xffff where the half of `v` is negative, else 0  (v_pk_ashrrev_i16)
 __device__ __forceinline__ int pk_sign(int v) {
     return __builtin_bit_cast(int, (s16x2)(__builtin_bit_cast(s16x2, v) >> (s16x2)(15)));
@@ -229,6 +233,8 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
     int thrk[C];
 #define THRK(q) thrk[q]
 #endif
+    int thz[kRec ? H : 1];               // packed (threshold >> 16) pairs, see below
+    int minplain2 = 0;
     int minthrk = INT32_MAX;             // lowest threshold of the lane
     int minplain = INT32_MAX;            // lowest threshold of the lane without the member rule (rows every path visits)
     const bool tight = a.thr != nullptr || a.oob; // thresholds from the other sweep's column maxima / from the speculative bound
@@ -265,6 +271,12 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
         // start rows: the gap-only row, identical for every path (uniform gap cost: A = c * gcost, z = 0)
 #pragma unroll
         for (int q = 0; q < C; ++q) { minthrk = min(minthrk, THRK(q)); minplain = min(minplain, thr_key(q, false)); }
+        // packed 16-bit form of the thresholds for the lazy-key pretest of the register-resident rows: a key z << 16 | path
+        // can reach a threshold only if z >= threshold >> 16 (INT32_MAX -> 32767: never; INT32_MIN -> -32768: always)
+#pragma unroll
+        for (int r = 0; r < (kRec ? H : 1); ++r)
+            thz[kRec ? r : 0] = pack16(THRK(kRec ? r : 0) >> 16, THRK(kRec ? r + H : 0) >> 16);
+        minplain2 = pack16(minplain >> 16, minplain >> 16);
         for (int k = 0; k < P; ++k) {
 #pragma unroll
             for (int r = 0; r < H; ++r) {
@@ -291,12 +303,13 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
     // so a cell is usable iff its winner is a member: value > 0, or value == 0 and path > knm, or no non-member
     // exists -> bkey > kthr with kthr = knm (>= 0) or INT32_MIN).  ckey keeps the best usable key per column and the
     // row it came from; emission compares against thr << 16.
-    auto row_end = [&](int i, int knm, const int (&bkey)[C]) {
+    // pre_done: the caller tracked the column maxima itself and already knows that some column reaches its threshold
+    auto row_end = [&](int i, int knm, const int (&bkey)[C], bool pre_done = false) {
         // The column maxima ignore that rule (k_bound re-checks the recorded cell; an unusable cell has value <= 0 and
         // can only raise a non-positive maximum, which loosens thresholds, never tightens them); emissions apply it
         // (it removes most of the negative-valued cells the loose forward thresholds would let through).
         unsigned emask = 0;
-        if (kColmax == 1) {
+        if (kColmax == 1 && !pre_done) {
 #pragma unroll
             for (int q = 0; q < C; ++q) {
                 const bool better = bkey[q] > ckey[kColmax == 1 ? q : 0];
@@ -304,7 +317,7 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
                 crow[kColmax == 1 ? q : 0] = better ? i : crow[kColmax == 1 ? q : 0];
             }
         }
-        if (kColmax == 2) {
+        if (kColmax == 2 && !pre_done) {
 #pragma unroll
             for (int r = 0; r < H; ++r) {
                 // value halves of the two keys of register r: low column | high column << 16
@@ -318,7 +331,7 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
         // tight thresholds (reverse sweep): most rows emit nothing; one max3 tree against the lane's lowest threshold
         // decides for the whole wave whether the per-column test is needed
         bool test = true;
-        if (tight) {
+        if (tight && !pre_done) {
             int mx = bkey[0];
 #pragma unroll
             for (int q = 1; q < C; ++q) mx = max(mx, bkey[q]);
@@ -529,7 +542,40 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
                 for (int kk = 1; kk < KRUN; ++kk)
                     if (kk < nm) RowOps16<C>::member(rr[kk], SEL, lane, MU, ML, lmask, src);
                 cells += (unsigned long long)nm;
-                if (track) {
+                if (track && kRec && kColmax != 1) {
+                    // LAZY KEYS (rows in registers): the best VALUE per column is a packed maximum over the members (8
+                    // v_pk_max per member instead of 32 key instructions); it feeds the packed column maxima directly, and
+                    // the (value, path) keys are only built when some column of some lane can reach its threshold
+                    // (saturating packed compare against thz: a superset of the exact test row_end applies)
+                    int bv[H];
+#pragma unroll
+                    for (int r = 0; r < H; ++r) bv[r] = rr[0][r];
+#pragma unroll
+                    for (int kk = 1; kk < KRUN; ++kk)
+                        if (kk < nm) {
+#pragma unroll
+                            for (int r = 0; r < H; ++r) bv[r] = pk_max(bv[r], rr[kk][r]);
+                        }
+                    if (kColmax == 2) {
+#pragma unroll
+                        for (int r = 0; r < H; ++r) cmv[kColmax == 2 ? r : 0] = pk_max(cmv[kColmax == 2 ? r : 0], bv[r]);
+                    }
+                    const int knm_row = ((rw1 >> 20) & 511) - 1;
+                    int acc = -1;
+                    if (knm_row >= 0) {
+#pragma unroll
+                        for (int r = 0; r < H; ++r) acc &= pk_sub_sat(bv[r], thz[kRec ? r : 0]);
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < H; ++r) acc &= pk_sub_sat(bv[r], minplain2);
+                    }
+                    if (__any(((unsigned)acc & 0x80008000u) != 0x80008000u)) {      // some half >= its threshold
+                        set_keys(bkey, rr[0], mk[0]);
+#pragma unroll
+                        for (int kk = 1; kk < KRUN; ++kk) if (kk < nm) fold_keys(bkey, rr[kk], mk[kk]);
+                        row_end(ri, knm_row, bkey, true);
+                    }
+                } else if (track) {
                     set_keys(bkey, rr[0], mk[0]);
 #pragma unroll
                     for (int kk = 1; kk < KRUN; ++kk) if (kk < nm) fold_keys(bkey, rr[kk], mk[kk]);
