@@ -175,6 +175,10 @@ struct RowOps16 {
 #ifdef RG_SWEEP16_NOROWS
 #define RG_ROW_LD(dst, expr) (dst) = (dst)
 #define RG_ROW_ST(expr, v) ((void)0)
+#elif defined(RG_SWEEP16_NOROWS32)
+//   RG_SWEEP16_NOROWS32 no row traffic for the steps whose group holds 16 or more paths (the rows every path visits)
+#define RG_ROW_LD(dst, expr) do { if (nm < 16) (dst) = (expr); } while (0)
+#define RG_ROW_ST(expr, v) do { if (nm < 16) (expr) = (v); } while (0)
 #else
 #define RG_ROW_LD(dst, expr) (dst) = (expr)
 #define RG_ROW_ST(expr, v) (expr) = (v)
@@ -612,7 +616,7 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
             unsigned long long rest = cont ? gmask : gmask & ~(1ull << (ga - kbase));
             cells += (unsigned long long)nm;
             int nxt[H];
-#ifdef RG_SWEEP16_NOROWS
+#if defined(RG_SWEEP16_NOROWS) || defined(RG_SWEEP16_NOROWS32)
 #pragma unroll
             for (int r = 0; r < H; ++r) nxt[r] = s[r] ^ t;
 #endif
