@@ -38,6 +38,7 @@ Options& options() {
         { const char* v = getenv("RG_CHUNK_READS"); o.chunk_reads = v ? atoi(v) : 0; }
         { const char* v = getenv("RG_LB_BONUS"); o.lb_bonus = v ? atoi(v) : 0; }
         o.no_spec = env("RG_NO_SPEC");
+        o.no_gather = env("RG_NO_GATHER");
         o.spin_wait = env("RG_SPIN_WAIT");
         { const char* v = getenv("RG_SPEC_MARGIN"); if (v) o.spec_margin = atoi(v); }
     });
@@ -318,6 +319,7 @@ static std::atomic<int>* option_slot(const char* name) {
     if (!strcmp(name, "debug")) return &o.debug;
     if (!strcmp(name, "chunk_reads")) return &o.chunk_reads;
     if (!strcmp(name, "no_spec")) return &o.no_spec;
+    if (!strcmp(name, "no_gather")) return &o.no_gather;
     if (!strcmp(name, "spin_wait")) return &o.spin_wait;
     if (!strcmp(name, "spec_margin")) return &o.spec_margin;
     return nullptr;

@@ -242,13 +242,17 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
                 const int li = (int)std::string("ACGTN").find(h.lnz[i]);
                 for (int gi = goff[i]; gi < goff[i + 1]; ++gi) {
                     // x: row (20) | base code (3) | flags (3: first / last entry of the row, inner row of a one-entry
-                    //    segment run) | group alpha bit (6)
+                    //    segment run) | group alpha bit (6) — for an INNER row the alpha is the lowest member (k_sweep* take
+                    //    it from the mask) and the field holds the number of inner rows left in the run, this one
+                    //    included (capped at 63): k_sweep16 handles long runs of wide groups in one piece (gather runs)
                     // y: slot (20) | knm + 1 (9) | page (2) | continuation entry (1)        z, w: members of the page
                     int flags = 0;
                     if (gi == goff[i]) flags |= 1;
                     if (gi + 1 == goff[i + 1]) flags |= 2;
-                    if (inner && goff[i + 1] - goff[i] == 1) flags |= 4;
                     const bool cont = groups[gi].ga == GroupDesc::GA_CONT;
+                    if (inner && goff[i + 1] - goff[i] == 1 && !cont && groups[gi].mask &&
+                        groups[gi].ga == (uint32_t)__builtin_ctzll(groups[gi].mask))
+                        flags |= 4;
                     int4 r;
                     r.x = (int)((unsigned)i | ((unsigned)li << 20) | ((unsigned)flags << 23) | ((cont ? 0u : groups[gi].ga) << 26));
                     r.y = (int)((unsigned)groups[gi].slot | ((unsigned)(h.knm[i] + 1) << 20) | ((unsigned)groups[gi].page << 29) |
@@ -257,6 +261,13 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
                     r.w = (int)(unsigned)(groups[gi].mask >> 32);
                     out.push_back(r);
                 }
+            }
+            // inner records: alpha field := inner rows left in the run (consecutive inner records = rows of one segment)
+            int left = 0;
+            for (size_t t = out.size(); t-- > 0;) {
+                const bool inner = ((unsigned)out[t].x >> 23) & 4u;
+                left = inner ? std::min(left + 1, 63) : 0;
+                if (inner) out[t].x = (int)(((unsigned)out[t].x & 0x03ffffffu) | ((unsigned)left << 26));
             }
         };
         std::vector<int4> st;
@@ -344,6 +355,13 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
         sa.fsteps = w.fsteps.p; sa.rsteps = w.rsteps.p; sa.nfsteps = w.nfsteps; sa.nrsteps = w.nrsteps;
         sa.semi = semi ? 1 : 0;
         sa.nwv = nwv;
+        {
+            // gather runs of k_sweep16: z of a member lies in [-(rows + c) * maxabs, 2 c * maxabs]: the difference of two
+            // members at one cell is at most (rows + 3 c) * maxabs, which must fit a signed 16-bit half
+            long long maxabs = 0;
+            for (int i = 0; i < 35; ++i) if (p.scores[i] != RG_SCORE_MISSING) maxabs = std::max<long long>(maxabs, std::llabs((long long)p.scores[i]));
+            sa.gather_ok = use16 && !opt.no_gather && (long long)(h.max_path_rows + 3 * (max_n + 2)) * maxabs <= 32700 ? 1 : 0;
+        }
         sa.rbw = p.rec_band_width; sa.cand_cap = 0; sa.dir_words = dir_words; sa.cells = d_cells;
         SeedArgs se;
         se.g = gd; se.state = w.state.p; se.nreads = chunk; se.mode = pmode; se.sc = sa.sc; se.reads = d_reads; se.read_off = off;

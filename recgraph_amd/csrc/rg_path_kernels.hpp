@@ -58,6 +58,7 @@ struct SweepArgs {
     int* frec;                 // [reads][frec_cap][4 + C] or null
     unsigned frec_cap;
     int nwv;                   // waves (column stripes of 2048) per read: > 1 for reads longer than 2047 bases (k_sweep<32, true, true>)
+    int gather_ok;             // k_sweep16 gather runs: the difference of two members' packed values provably fits 16 bits
 };
 
 // expands the (row, lane) records of the forward sweep into Cand entries, keeping only cells that can still reach

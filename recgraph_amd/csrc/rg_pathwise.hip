@@ -399,7 +399,8 @@ __global__ __launch_bounds__(kStripes ? 512 : 64, kStripes ? 1 : RG_SWEEP_WAVES)
         int slot = w1 & 0xfffff;
         const int kbase = ((w1 >> 29) & 3) * 64;        // first path id of the entry's 64-path page
         const bool cont = w1 < 0;                       // continuation entry of a group that spans pages: members only
-        int ga = kbase + ((w0 >> 26) & 63);
+        // (an inner row of a one-entry segment run: the alpha is the lowest member, the field holds the run length left)
+        int ga = kbase + ((flags & 4) ? __builtin_ctzll(gmask | (1ull << 63)) : ((w0 >> 26) & 63));
         const int nm = __popcll(gmask);
         // ---- general (row, group) step ----
         const int g_i = __builtin_amdgcn_readfirstlane(sct[li * 6 + GAP]);

@@ -123,6 +123,8 @@ struct RowOps16 {
         for (int r = 0; r < H; ++r) SEL[r] = bfi(MU[r], r == 0 ? GI0 : GI, s[r]);
     }
 
+    // kMove: pure data movement (no step added): what a gather run applies to its column map
+    template <bool kMove = false>
     static __device__ __forceinline__ void member(int (&row)[H], const int (&SEL)[H], int lane,
                                                   const int (&MU)[H], const int (&ML)[H], unsigned lmask, int src) {
         int prev = __builtin_amdgcn_alignbit(row[H - 1], dpp_shr1(row[H - 1], NEGPAIR), 16);
@@ -130,7 +132,7 @@ struct RowOps16 {
 #pragma unroll
         for (int r = 0; r < H; ++r) {
             const int old = row[r];
-            const int base = pk_add(bfi(MU[r], old, prev), SEL[r]);  // U: old + g_i, D: prev + (s - g)
+            const int base = kMove ? bfi(MU[r], old, prev) : pk_add(bfi(MU[r], old, prev), SEL[r]);  // U: old + g_i, D: prev + (s - g)
             row[r] = base;
             lastv = bfi(ML[r], lastv, base);
             prev = old;
@@ -160,6 +162,18 @@ struct RowOps16 {
 #endif
 #ifndef RG_SWEEP16_THRLDS
 #define RG_SWEEP16_THRLDS 0
+#endif
+#ifndef RG_SWEEP16_GATHER
+#define RG_SWEEP16_GATHER 1          // gather runs (see k_sweep16); RG_SWEEP16_GATHER_MIN: shortest run / narrowest group they take
+#endif
+#ifndef RG_SWEEP16_GATHER_FWD
+#define RG_SWEEP16_GATHER_FWD 0      // the forward record variant has no registers for them (121 spilled with them compiled in)
+#endif
+#ifndef RG_SWEEP16_GATHER_MINRUN
+#define RG_SWEEP16_GATHER_MINRUN 3
+#endif
+#ifndef RG_SWEEP16_GATHER_MINNM
+#define RG_SWEEP16_GATHER_MINNM 8
 #endif
 #ifndef RG_SWEEP16_KRUN_REV
 #define RG_SWEEP16_KRUN_REV RG_SWEEP16_KRUN     // the variant without column maxima (reverse sweep of the record pipeline)
@@ -218,6 +232,10 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
     int* endv = lds16 + 64;              // [RG_MAXP]
     int* endr = lds16 + 64 + RG_MAXP;    // [RG_MAXP]
     int* s2 = lds16 + 64 + 2 * RG_MAXP;  // [5][64] packed score pairs: s2[li*64 + (code_lo | code_hi << 3)]
+    // gather runs (below): gT[q][lane] = best (delta << 16 | path) of the run's members at the run start, gS[r][lane] = one
+    // member's packed row at the run start
+    int* gT = lds16 + 64 + 2 * RG_MAXP + 5 * 64 + (RG_SWEEP16_THRLDS ? C * WAVE : 0);   // [C][64]
+    int* gS = gT + C * WAVE;                                                               // [H][64]
     if (lane < 36) sct[lane] = a.sc.t[lane];
     __syncthreads();
     const int gcost = sct[GAP];          // uniform read-gap cost (checked by the launcher): the z-space slope
@@ -513,8 +531,151 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
         const int slot = w1 & 0xfffff;
         const int kbase = kWide ? ((w1 >> 29) & 3) * 64 : 0;   // first path id of the entry's 64-path page
         const bool cont = kWide && w1 < 0;                     // continuation entry of a group that spans pages: members only
-        const int ga = kbase + ((w0 >> 26) & 63);
+        // (an inner row of a one-entry segment run: the alpha is the lowest member, the field holds the run length left)
+        const int ga = kbase + ((flags & F_INNER) ? __builtin_ctzll(gmask | (1ull << 63)) : ((w0 >> 26) & 63));
         const int nm = __popcll(gmask);
+        if (RG_SWEEP16_GATHER && (kColmax == 0 || (kColmax == 2 && RG_SWEEP16_GATHER_FWD)) && !kWide && a.gather_ok && !semi_end && (flags & F_INNER) && nm >= RG_SWEEP16_GATHER_MINNM &&
+            ((w0 >> 26) & 63) >= RG_SWEEP16_GATHER_MINRUN) {
+            // ---- GATHER RUN: R consecutive inner rows of a segment that a wide group (nm paths, one group, alpha = its lowest
+            // path) runs through.  Every member follows the alpha's directions, and a direction only MOVES values (D: from
+            // column c - 1 of the row above, U: from column c, L: from column c - 1 of the new row) and adds a constant that
+            // does not depend on the member.  So delta_k = row_k - row_alpha is carried through the run by pure data
+            // movement, the same for every k: a gather G (column -> column of the run's first row) that is itself updated like
+            // a member row with zero steps.  The run therefore costs, per row, the alpha + G + one table gather for the best
+            // member per column — not nm member updates — and per member ONE pass at each end of the run; the members'
+            // rolling rows are read twice and written once per run instead of once each per row (for the rows every path
+            // visits that traffic was 58 % of the sweep's, 10 ms of a 93 ms step: profiles/r03_notes.md).
+            const int R = (w0 >> 26) & 63;
+            const int ka = ga;
+            int A[H], G[H];
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < H; ++r) { A[r] = rows[(long long)ka * wrow + r * WAVE + lane]; gS[r * WAVE + lane] = A[r]; }   // gS: the alpha's row at the run start
+            // (1) best (delta, path) per column over the members at the run start; ties -> highest path id: members in
+            // ascending order, a later one replaces on >=.  Packed: delta = row_k - A0 (saturating: |delta| fits, gather_ok)
+#ifndef RG_G_NOPH1
+            {
+                int bd[H], bk[H];
+#pragma unroll
+                for (int r = 0; r < H; ++r) { bd[r] = 0; bk[r] = pack16(ka, ka); }
+                unsigned long long rest = gmask & ~(1ull << (ka - kbase));
+                int nx[H];
+                int kn = -1;
+                if (rest) {
+                    kn = kbase + __builtin_ctzll(rest); rest &= rest - 1;
+#pragma unroll
+                    for (int r = 0; r < H; ++r) nx[r] = rows[(long long)kn * wrow + r * WAVE + lane];
+                }
+                while (kn >= 0) {
+                    const int k = kn;
+                    int cur[H];
+#pragma unroll
+                    for (int r = 0; r < H; ++r) cur[r] = nx[r];
+                    if (rest) {
+                        kn = kbase + __builtin_ctzll(rest); rest &= rest - 1;
+#pragma unroll
+                        for (int r = 0; r < H; ++r) nx[r] = rows[(long long)kn * wrow + r * WAVE + lane];
+                    } else kn = -1;
+                    int kk = k;
+                    asm volatile("" : "+v"(kk));
+                    const int K2 = (int)(((unsigned)kk << 16) | (unsigned)kk);
+#pragma unroll
+                    for (int r = 0; r < H; ++r) {
+                        const int d = pk_sub_sat(cur[r], A[r]);
+                        const int lt = pk_sign(pk_sub_sat(d, bd[r]));       // 0xffff where d < best: keep
+                        bd[r] = pk_max(bd[r], d);
+                        bk[r] = bfi(lt, bk[r], K2);
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < H; ++r) {
+                    gT[r * WAVE + lane] = (int)(((unsigned)bd[r] << 16) | ((unsigned)bk[r] & 0xffffu));            // column r of the lane
+                    gT[(r + H) * WAVE + lane] = (int)(((unsigned)bd[r] & 0xffff0000u) | ((unsigned)bk[r] >> 16)); // column H + r
+                }
+            }
+#endif
+            // (2) G: column -> code of the run-start column whose delta it carries; code = word index of the packed row
+            // layout [r][lane] * 2 + half
+#pragma unroll
+            for (int r = 0; r < H; ++r) { const int w = r * WAVE + lane; G[r] = pack16(2 * w, 2 * w + 1); }
+            __syncthreads();
+            int ri = i, rli = li, rslot = slot, rw1 = w1;
+            for (int step = 0;; ++step) {
+                const int g_i = __builtin_amdgcn_readfirstlane(sct[rli * 6 + GAP]);
+                const int g0 = a.semi ? 0 : g_i;
+#pragma unroll
+                for (int r = 0; r < H; ++r) s[r] = s2[rli * 64 + (int)((pcode[r / 8] >> (8 * (r % 8))) & 63)];
+                unsigned umask;
+                RowOps16<C>::alpha(A, s, g_i, g0, lane, MU, ML, umask, lmask, src);
+                if (dirs) store_dirs(rslot, umask, lmask);
+                RowOps16<C>::template member<true>(G, MU, lane, MU, ML, lmask, src);   // the gather follows the directions, adds nothing (SEL unused)
+                cells += (unsigned long long)nm;
+#ifndef RG_G_NOKEYS
+                if (track) {
+                    // best member per column of this row: alpha value + best delta of the run-start column G points at
+#pragma unroll
+                    for (int r = 0; r < H; ++r) {
+                        const int c0 = G[r] & 0xffff, c1 = (unsigned)G[r] >> 16;
+                        const int t0 = gT[((c0 >> 1) + ((c0 & 1) << (31 - __builtin_clz(H * WAVE)))) ];
+                        const int t1 = gT[((c1 >> 1) + ((c1 & 1) << (31 - __builtin_clz(H * WAVE)))) ];
+                        bkey[r] = t0 + (int)((unsigned)A[r] << 16);
+                        bkey[r + H] = t1 + (int)((unsigned)A[r] & 0xffff0000u);
+                    }
+                    row_end(ri, ((rw1 >> 20) & 511) - 1, bkey);
+                }
+#endif
+                ++t;
+                if (step + 1 >= R || t >= nsteps) break;
+                int nw0, nw1;
+                unsigned long long ngm;
+                fetch(t, nw0, nw1, ngm);
+                ri = nw0 & 0xfffff; rli = (nw0 >> 20) & 7; rslot = nw1 & 0xfffff; rw1 = nw1;
+            }
+            // (3) every member once: row_k(end)[c] = A(end)[c] - A0[G(c)] + row_k(start)[G(c)]
+#ifndef RG_G_NOPH3
+            {
+                int B[H];
+                __syncthreads();
+#pragma unroll
+                for (int r = 0; r < H; ++r) {
+                    const int c0 = G[r] & 0xffff, c1 = (unsigned)G[r] >> 16;
+                    const int w0v = gS[c0 >> 1], w1v = gS[c1 >> 1];
+                    const int a0 = (c0 & 1) ? hi16(w0v) : lo16(w0v), a1 = (c1 & 1) ? hi16(w1v) : lo16(w1v);
+                    B[r] = pk_sub_sat(A[r], pack16(a0, a1));
+                }
+#pragma unroll
+                for (int r = 0; r < H; ++r) rows[(long long)ka * wrow + r * WAVE + lane] = A[r];
+                unsigned long long rest = gmask & ~(1ull << (ka - kbase));
+                int nx[H];
+                int kn = -1;
+                if (rest) {
+                    kn = kbase + __builtin_ctzll(rest); rest &= rest - 1;
+#pragma unroll
+                    for (int r = 0; r < H; ++r) nx[r] = rows[(long long)kn * wrow + r * WAVE + lane];
+                }
+                while (kn >= 0) {
+                    const int k = kn;
+                    __syncthreads();
+#pragma unroll
+                    for (int r = 0; r < H; ++r) gS[r * WAVE + lane] = nx[r];
+                    if (rest) {
+                        kn = kbase + __builtin_ctzll(rest); rest &= rest - 1;
+#pragma unroll
+                        for (int r = 0; r < H; ++r) nx[r] = rows[(long long)kn * wrow + r * WAVE + lane];
+                    } else kn = -1;
+                    __syncthreads();
+#pragma unroll
+                    for (int r = 0; r < H; ++r) {
+                        const int c0 = G[r] & 0xffff, c1 = (unsigned)G[r] >> 16;
+                        const int w0v = gS[c0 >> 1], w1v = gS[c1 >> 1];
+                        const int v0 = (c0 & 1) ? hi16(w0v) : lo16(w0v), v1 = (c1 & 1) ? hi16(w1v) : lo16(w1v);
+                        rows[(long long)k * wrow + r * WAVE + lane] = pk_add(B[r], pack16(v0, v1));
+                    }
+                }
+            }
+#endif
+            continue;
+        }
         if (KRUN > 0 && (flags & F_INNER) && nm <= KRUN) {
             // ---- inner rows of a segment with a small group: the same paths, one group, predecessor = previous row.
             // Their rows stay in registers for the whole run: no row load/store latency, no HBM traffic.  The group
@@ -826,7 +987,7 @@ void launch_colmax_rec(const ExpandArgs& a, int* colmax_out, int* colarg_out, in
 
 template <int kColmax, bool kRec, bool kWide>
 static void launch_sweep16_w(const SweepArgs& a, int nreads, int C, hipStream_t s) {
-    const size_t bytes = (size_t)(64 + 2 * RG_MAXP + 5 * 64 + (RG_SWEEP16_THRLDS ? C * WAVE : 0)) * sizeof(int);
+    const size_t bytes = (size_t)(64 + 2 * RG_MAXP + 5 * 64 + (RG_SWEEP16_THRLDS ? C * WAVE : 0) + (RG_SWEEP16_GATHER ? C * WAVE + C / 2 * WAVE : 0)) * sizeof(int);
     switch (C) {
         case 4: hipLaunchKernelGGL((k_sweep16<4, kColmax, kRec, kWide>), dim3(nreads), dim3(64), bytes, s, a); break;
         case 8: hipLaunchKernelGGL((k_sweep16<8, kColmax, kRec, kWide>), dim3(nreads), dim3(64), bytes, s, a); break;

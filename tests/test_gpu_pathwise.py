@@ -218,6 +218,27 @@ def test_scores_beyond_the_32_bit_keys_are_refused():
     assert len(texts) == 4 and not any(status)
 
 
+def test_gather_runs(oracle):
+    """k_sweep16 gather runs: long runs of inner rows that a wide group (>= 8 paths) goes through are processed as the alpha
+    + a column map, the members once per run.  Graphs with long segments shared by many paths, global and semiglobal, with
+    and without the switch (`no_gather`): byte-identical records, equal to the oracle."""
+    from recgraph_amd import api, synth
+    for P, rows, plen, shared, seed in ((12, 1400, 300, 0.8, 101), (32, 2600, 400, 0.6, 102), (60, 1800, 260, 0.9, 103)):
+        g = synth.haplotype_graph(rows, P, path_len=plen, seed=seed, shared_frac=shared)
+        rd = synth.haplotype_reads(g, 24, length=plen, seed=seed + 1, mosaic_frac=0.6) + [g.path_sequence(P - 1)[:plen - 5], "ACGT" * 6]
+        gg = api.Graph.from_gfa_text(g.gfa())
+        names = ["r%d" % i for i in range(len(rd))]
+        for mode, om, reads in ((api.MODE_RECOMBINATION, oracle.M8_ABS, rd), (api.MODE_RECOMBINATION_SEMI, oracle.M9_ABS, [r[:plen * 2 // 3] for r in rd[:10]])):
+            base = _check(oracle, g.gfa(), reads, mode, om)
+            try:
+                api.set_option("no_gather", 1)
+                texts, _ = api.align_batch(gg, reads, names[:len(reads)], mode=mode)
+            finally:
+                api.set_option("no_gather", 0)
+            assert texts == base, (P, mode)
+        _check(oracle, g.gfa(), rd[:6], api.MODE_RECOMBINATION, oracle.M8_ABS, R=0, r=0.1, B=0.8)
+
+
 def test_three_sweep_pipeline(oracle):
     """The -m 8 / -m 9 pipeline the driver takes when a gap entry is positive (no path-0 lower bound for the forward
     thresholds: forward column maxima first, reverse sweep, forward again) or on request (RG_THREE_SWEEPS), with the
