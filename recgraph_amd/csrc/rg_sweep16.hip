@@ -167,7 +167,7 @@ struct RowOps16 {
 #define RG_SWEEP16_GATHER 1          // gather runs (see k_sweep16); RG_SWEEP16_GATHER_MIN: shortest run / narrowest group they take
 #endif
 #ifndef RG_SWEEP16_GATHER_FWD
-#define RG_SWEEP16_GATHER_FWD 0      // the forward record variant has no registers for them (121 spilled with them compiled in)
+#define RG_SWEEP16_GATHER_FWD 1      // the forward record variant spills 121 registers with them compiled in and still gains 3 ms (47.7 -> 44.7)
 #endif
 #ifndef RG_SWEEP16_GATHER_MINRUN
 #define RG_SWEEP16_GATHER_MINRUN 3
@@ -534,7 +534,7 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
         // (an inner row of a one-entry segment run: the alpha is the lowest member, the field holds the run length left)
         const int ga = kbase + ((flags & F_INNER) ? __builtin_ctzll(gmask | (1ull << 63)) : ((w0 >> 26) & 63));
         const int nm = __popcll(gmask);
-        if (RG_SWEEP16_GATHER && (kColmax == 0 || (kColmax == 2 && RG_SWEEP16_GATHER_FWD)) && !kWide && a.gather_ok && !semi_end && (flags & F_INNER) && nm >= RG_SWEEP16_GATHER_MINNM &&
+        if (RG_SWEEP16_GATHER && kRec && (kColmax == 0 || (kColmax == 2 && RG_SWEEP16_GATHER_FWD)) && !kWide && a.gather_ok && !semi_end && (flags & F_INNER) && nm >= RG_SWEEP16_GATHER_MINNM &&
             ((w0 >> 26) & 63) >= RG_SWEEP16_GATHER_MINRUN) {
             // ---- GATHER RUN: R consecutive inner rows of a segment that a wide group (nm paths, one group, alpha = its lowest
             // path) runs through.  Every member follows the alpha's directions, and a direction only MOVES values (D: from
@@ -612,16 +612,39 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
                 cells += (unsigned long long)nm;
 #ifndef RG_G_NOKEYS
                 if (track) {
-                    // best member per column of this row: alpha value + best delta of the run-start column G points at
+                    // best member per column of this row: alpha value + best delta of the run-start column G points at (packed
+                    // values bv + packed paths K2); the (value, path) keys only when some column can reach its threshold
+                    int bv[H], K2[H];
+                    constexpr int HS = 31 - __builtin_clz(H * WAVE);      // log2 of the words of one packed row
 #pragma unroll
                     for (int r = 0; r < H; ++r) {
                         const int c0 = G[r] & 0xffff, c1 = (unsigned)G[r] >> 16;
-                        const int t0 = gT[((c0 >> 1) + ((c0 & 1) << (31 - __builtin_clz(H * WAVE)))) ];
-                        const int t1 = gT[((c1 >> 1) + ((c1 & 1) << (31 - __builtin_clz(H * WAVE)))) ];
-                        bkey[r] = t0 + (int)((unsigned)A[r] << 16);
-                        bkey[r + H] = t1 + (int)((unsigned)A[r] & 0xffff0000u);
+                        const unsigned t0 = (unsigned)gT[(c0 >> 1) + ((c0 & 1) << HS)];
+                        const unsigned t1 = (unsigned)gT[(c1 >> 1) + ((c1 & 1) << HS)];
+                        bv[r] = pk_add(A[r], (int)__builtin_amdgcn_perm(t1, t0, 0x07060302u));     // delta halves
+                        K2[r] = (int)__builtin_amdgcn_perm(t1, t0, 0x05040100u);                    // path halves
                     }
-                    row_end(ri, ((rw1 >> 20) & 511) - 1, bkey);
+                    if (kColmax == 2) {
+#pragma unroll
+                        for (int r = 0; r < H; ++r) cmv[kColmax == 2 ? r : 0] = pk_max(cmv[kColmax == 2 ? r : 0], bv[r]);
+                    }
+                    const int knm_row = ((rw1 >> 20) & 511) - 1;
+                    int acc = -1;
+                    if (knm_row >= 0) {
+#pragma unroll
+                        for (int r = 0; r < H; ++r) acc &= pk_sub_sat(bv[r], thz[kRec ? r : 0]);
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < H; ++r) acc &= pk_sub_sat(bv[r], minplain2);
+                    }
+                    if (__any(((unsigned)acc & 0x80008000u) != 0x80008000u)) {
+#pragma unroll
+                        for (int r = 0; r < H; ++r) {
+                            bkey[r] = (int)(((unsigned)bv[r] << 16) | ((unsigned)K2[r] & 0xffffu));
+                            bkey[r + H] = (int)(((unsigned)bv[r] & 0xffff0000u) | ((unsigned)K2[r] >> 16));
+                        }
+                        row_end(ri, knm_row, bkey, true);
+                    }
                 }
 #endif
                 ++t;
