@@ -244,7 +244,8 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
                     // x: row (20) | base code (3) | flags (3: first / last entry of the row, inner row of a one-entry
                     //    segment run) | group alpha bit (6) — for an INNER row the alpha is the lowest member (k_sweep* take
                     //    it from the mask) and the field holds the number of inner rows left in the run, this one
-                    //    included (capped at 63): k_sweep16 handles long runs of wide groups in one piece (gather runs)
+                    //    included (capped at 63; 0 when a gather run does not pay): k_sweep16 handles long runs of wide
+                    //    groups in one piece (gather runs)
                     // y: slot (20) | knm + 1 (9) | page (2) | continuation entry (1)        z, w: members of the page
                     int flags = 0;
                     if (gi == goff[i]) flags |= 1;
@@ -262,12 +263,19 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
                     out.push_back(r);
                 }
             }
-            // inner records: alpha field := inner rows left in the run (consecutive inner records = rows of one segment)
+            // inner records: alpha field := inner rows left in the run (consecutive inner records = rows of one segment) when a
+            // gather run of k_sweep16 pays from here, else 0.  A gather run costs ~180 instructions per member once per run
+            // (two passes) + ~160 per row, the member-by-member form ~77 per member and row: it pays when
+            // R * (77 (nm - 1) - 160) >= 200 (nm - 1)  (32 paths: 3 rows, 8 paths: 4, 5 paths: 6).
             int left = 0;
             for (size_t t = out.size(); t-- > 0;) {
                 const bool inner = ((unsigned)out[t].x >> 23) & 4u;
                 left = inner ? std::min(left + 1, 63) : 0;
-                if (inner) out[t].x = (int)(((unsigned)out[t].x & 0x03ffffffu) | ((unsigned)left << 26));
+                if (inner) {
+                    const int nm = __builtin_popcountll(((unsigned long long)(unsigned)out[t].w << 32) | (unsigned)out[t].z);
+                    const bool pays = left * (77 * (nm - 1) - 160) >= 200 * (nm - 1);
+                    out[t].x = (int)(((unsigned)out[t].x & 0x03ffffffu) | ((unsigned)(pays ? left : 0) << 26));
+                }
             }
         };
         std::vector<int4> st;

@@ -164,17 +164,12 @@ struct RowOps16 {
 #define RG_SWEEP16_THRLDS 0
 #endif
 #ifndef RG_SWEEP16_GATHER
-#define RG_SWEEP16_GATHER 1          // gather runs (see k_sweep16); RG_SWEEP16_GATHER_MIN: shortest run / narrowest group they take
+#define RG_SWEEP16_GATHER 1          // gather runs (see k_sweep16 and gather_pays)
 #endif
 #ifndef RG_SWEEP16_GATHER_FWD
 #define RG_SWEEP16_GATHER_FWD 1      // the forward record variant spills 121 registers with them compiled in and still gains 3 ms (47.7 -> 44.7)
 #endif
-#ifndef RG_SWEEP16_GATHER_MINRUN
-#define RG_SWEEP16_GATHER_MINRUN 3
-#endif
-#ifndef RG_SWEEP16_GATHER_MINNM
-#define RG_SWEEP16_GATHER_MINNM 8
-#endif
+
 #ifndef RG_SWEEP16_KRUN_REV
 #define RG_SWEEP16_KRUN_REV RG_SWEEP16_KRUN     // the variant without column maxima (reverse sweep of the record pipeline)
 #endif
@@ -534,8 +529,8 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
         // (an inner row of a one-entry segment run: the alpha is the lowest member, the field holds the run length left)
         const int ga = kbase + ((flags & F_INNER) ? __builtin_ctzll(gmask | (1ull << 63)) : ((w0 >> 26) & 63));
         const int nm = __popcll(gmask);
-        if (RG_SWEEP16_GATHER && kRec && (kColmax == 0 || (kColmax == 2 && RG_SWEEP16_GATHER_FWD)) && !kWide && a.gather_ok && !semi_end && (flags & F_INNER) && nm >= RG_SWEEP16_GATHER_MINNM &&
-            ((w0 >> 26) & 63) >= RG_SWEEP16_GATHER_MINRUN) {
+        if (RG_SWEEP16_GATHER && kRec && (kColmax == 0 || (kColmax == 2 && RG_SWEEP16_GATHER_FWD)) && !kWide && a.gather_ok && !semi_end && (flags & F_INNER) && nm > KRUN &&
+            ((w0 >> 26) & 63) != 0) {
             // ---- GATHER RUN: R consecutive inner rows of a segment that a wide group (nm paths, one group, alpha = its lowest
             // path) runs through.  Every member follows the alpha's directions, and a direction only MOVES values (D: from
             // column c - 1 of the row above, U: from column c, L: from column c - 1 of the new row) and adds a constant that
