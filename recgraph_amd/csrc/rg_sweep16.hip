@@ -529,7 +529,7 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
         // (an inner row of a one-entry segment run: the alpha is the lowest member, the field holds the run length left)
         const int ga = kbase + ((flags & F_INNER) ? __builtin_ctzll(gmask | (1ull << 63)) : ((w0 >> 26) & 63));
         const int nm = __popcll(gmask);
-        if (RG_SWEEP16_GATHER && kRec && (kColmax == 0 || (kColmax == 2 && RG_SWEEP16_GATHER_FWD)) && !kWide && a.gather_ok && !semi_end && (flags & F_INNER) && nm > KRUN &&
+        if (RG_SWEEP16_GATHER && (kRec ? (kColmax == 0 || (kColmax == 2 && RG_SWEEP16_GATHER_FWD)) : !track) && !kWide && a.gather_ok && !semi_end && (flags & F_INNER) && nm > KRUN &&
             ((w0 >> 26) & 63) != 0) {
             // ---- GATHER RUN: R consecutive inner rows of a segment that a wide group (nm paths, one group, alpha = its lowest
             // path) runs through.  Every member follows the alpha's directions, and a direction only MOVES values (D: from
@@ -606,7 +606,7 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
                 RowOps16<C>::template member<true>(G, MU, lane, MU, ML, lmask, src);   // the gather follows the directions, adds nothing (SEL unused)
                 cells += (unsigned long long)nm;
 #ifndef RG_G_NOKEYS
-                if (track) {
+                if (kRec && track) {
                     // best member per column of this row: alpha value + best delta of the run-start column G points at (packed
                     // values bv + packed paths K2); the (value, path) keys only when some column can reach its threshold
                     int bv[H], K2[H];
