@@ -36,6 +36,7 @@ Options& options() {
         o.no_frec = env("RG_NO_FREC");
         o.debug = env("RG_DEBUG");
         { const char* v = getenv("RG_CHUNK_READS"); o.chunk_reads = v ? atoi(v) : 0; }
+        { const char* v = getenv("RG_STRIPE_C"); o.stripe_c = v ? atoi(v) : 0; }
         { const char* v = getenv("RG_LB_BONUS"); o.lb_bonus = v ? atoi(v) : 0; }
         o.no_spec = env("RG_NO_SPEC");
         o.no_gather = env("RG_NO_GATHER");
@@ -318,6 +319,7 @@ static std::atomic<int>* option_slot(const char* name) {
     if (!strcmp(name, "no_frec")) return &o.no_frec;
     if (!strcmp(name, "debug")) return &o.debug;
     if (!strcmp(name, "chunk_reads")) return &o.chunk_reads;
+    if (!strcmp(name, "stripe_c")) return &o.stripe_c;
     if (!strcmp(name, "no_spec")) return &o.no_spec;
     if (!strcmp(name, "no_gather")) return &o.no_gather;
     if (!strcmp(name, "spin_wait")) return &o.spin_wait;
@@ -328,7 +330,8 @@ int32_t rg_set_option(const char* name, int64_t value) {
     std::atomic<int>* s = option_slot(name);
     if (!s) return fail(RG_ERR_ARG, std::string("unknown option ") + (name ? name : "(null)"));
     Options& o = options();
-    if (s == &o.chunk_reads) *s = (int)std::max<int64_t>(0, std::min<int64_t>(value, 1 << 20));
+    if (s == &o.stripe_c) *s = (int)std::max<int64_t>(0, std::min<int64_t>(value, 32));
+    else if (s == &o.chunk_reads) *s = (int)std::max<int64_t>(0, std::min<int64_t>(value, 1 << 20));
     else if (s == &o.spec_margin) *s = (int)std::max<int64_t>(-(1 << 24), std::min<int64_t>(value, 1 << 24));
     else *s = value ? 1 : 0;
     return RG_OK;

@@ -146,8 +146,14 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
     const int P = h.P, L = h.L;
     int C = 4;
     while (C * WAVE < max_n + 1 && C < 32) C *= 2;
-    // Reads longer than 2047 bases: column stripes of 2048, one wave per stripe in one workgroup (k_sweep / k_layer
-    // <32, true>): i32 rows, Cand lists, three sweeps; needs a uniform read-gap cost (every matrix the reference's CLI builds)
+    // Reads longer than 2047 bases: column stripes, one wave per stripe in one workgroup of at most 8 waves (k_sweep /
+    // k_layer <C, true>): i32 rows, Cand lists; needs a uniform read-gap cost (every matrix the reference's CLI builds).
+    // Stripes of 1024 columns (C = 16: rows, keys and thresholds fit the 256 registers) up to 8191 bases; 2048 (C = 32,
+    // which spills 800 registers) beyond; RG_STRIPE_C / rg_set_option("stripe_c") overrides (8, 16, 32).
+    if (max_n + 1 > 32 * WAVE) {
+        C = max_n + 1 <= 8 * 16 * WAVE ? 16 : 32;
+        if ((opt.stripe_c == 8 || opt.stripe_c == 16 || opt.stripe_c == 32) && max_n + 1 <= 8 * opt.stripe_c * WAVE) C = opt.stripe_c;
+    }
     const int nwv = (max_n + 1 + C * WAVE - 1) / (C * WAVE);
     if (nwv > 8) return fail(RG_ERR_ARG, "reads longer than 16383 bases are not supported by the pathwise kernels");
     if (nwv > 1)

@@ -1165,9 +1165,14 @@ static void launch_sweep_c(const SweepArgs& a, int nreads, hipStream_t s) {
 }
 void launch_sweep(const SweepArgs& a, int nreads, int C, hipStream_t s) {
     if (a.nwv > 1) {
-        // striped long reads: a.nwv waves per read, 32 columns per lane, uniform read-gap cost (checked by the driver)
+        // striped long reads: a.nwv waves per read, C columns per lane (16: the rows and keys fit the registers; 32 spills
+        // 800 of them and only serves reads beyond 8 x 1024 columns), uniform read-gap cost (checked by the driver)
         const size_t bytes = (64 + 2 * RG_MAXP + a.nwv * (FIFO_WORDS + 2)) * sizeof(int);
-        hipLaunchKernelGGL((k_sweep<32, true, true>), dim3(nreads), dim3(64 * a.nwv), bytes, s, a);
+        switch (C) {
+            case 8: hipLaunchKernelGGL((k_sweep<8, true, true>), dim3(nreads), dim3(64 * a.nwv), bytes, s, a); break;
+            case 16: hipLaunchKernelGGL((k_sweep<16, true, true>), dim3(nreads), dim3(64 * a.nwv), bytes, s, a); break;
+            default: hipLaunchKernelGGL((k_sweep<32, true, true>), dim3(nreads), dim3(64 * a.nwv), bytes, s, a); break;
+        }
         return;
     }
     switch (C) {
@@ -1210,7 +1215,14 @@ void launch_search(const SearchArgs& a, int nreads, hipStream_t s) {
     hipLaunchKernelGGL(k_search, dim3(nreads), dim3(64), bytes, s, a);
 }
 void launch_layer(const LayerArgs& a, int nreads, int C, hipStream_t s) {
-    if (a.nwv > 1) { hipLaunchKernelGGL((k_layer<32, true>), dim3(nreads), dim3(64 * a.nwv), 0, s, a); return; }
+    if (a.nwv > 1) {
+        switch (C) {
+            case 8: hipLaunchKernelGGL((k_layer<8, true>), dim3(nreads), dim3(64 * a.nwv), 0, s, a); break;
+            case 16: hipLaunchKernelGGL((k_layer<16, true>), dim3(nreads), dim3(64 * a.nwv), 0, s, a); break;
+            default: hipLaunchKernelGGL((k_layer<32, true>), dim3(nreads), dim3(64 * a.nwv), 0, s, a); break;
+        }
+        return;
+    }
     switch (C) {
         case 4: hipLaunchKernelGGL((k_layer<4>), dim3(nreads), dim3(64), 0, s, a); break;
         case 8: hipLaunchKernelGGL((k_layer<8>), dim3(nreads), dim3(64), 0, s, a); break;

@@ -310,8 +310,8 @@ def test_more_than_64_paths(oracle):
 
 
 def test_reads_longer_than_2047_bases(oracle):
-    """Striped long reads: column stripes of 2048, one wave per stripe in one workgroup, carries through LDS FIFOs
-    (k_sweep / k_layer <32, true, true>), 2 to 4 stripes, mixed with short reads in the same batch."""
+    """Striped long reads: column stripes of 1024 (up to 8191 bases) or 2048, one wave per stripe in one workgroup,
+    carries through LDS FIFOs (k_sweep / k_layer <C, true, true>), 3 to 7 stripes, mixed with short reads in the same batch."""
     from recgraph_amd import api, synth
     for plen, rows, P, nreads, seed in ((2600, 4200, 4, 5, 61), (5000, 7000, 3, 3, 62), (7000, 9000, 2, 2, 63)):
         g = synth.haplotype_graph(rows, P, path_len=plen, seed=seed)
@@ -323,3 +323,20 @@ def test_reads_longer_than_2047_bases(oracle):
         semi = [r[:len(r) * 2 // 3] for r in rd[:3]]
         _check(oracle, g.gfa(), semi, api.MODE_PATHWISE_SEMI, oracle.M5_ABS)
         _check(oracle, g.gfa(), semi, api.MODE_RECOMBINATION_SEMI, oracle.M9_ABS)
+        if plen == 2600:
+            # the same batch at the other stripe widths (512 and 2048 columns per wave: 6 and 2 stripes)
+            gg = api.Graph.from_gfa_text(g.gfa())
+            names = ["r%d" % i for i in range(len(rd))]
+            base = {m: api.align_batch(gg, rd, names, mode=m)[0] for m in (api.MODE_PATHWISE, api.MODE_RECOMBINATION)}
+            for c in (8, 32):
+                api.set_option("stripe_c", c)
+                try:
+                    for m in base:
+                        assert api.align_batch(gg, rd, names, mode=m)[0] == base[m], (c, m)
+                finally:
+                    api.set_option("stripe_c", 0)
+    # beyond 8 stripes of 1024 columns: 2048-column stripes
+    g = synth.haplotype_graph(10500, 2, path_len=8400, seed=64)
+    rd = synth.haplotype_reads(g, 1, length=8400, seed=164, mosaic_frac=1.0)
+    _check(oracle, g.gfa(), rd, api.MODE_PATHWISE, oracle.M4_ABS)
+    _check(oracle, g.gfa(), rd, api.MODE_RECOMBINATION, oracle.M8_ABS)
