@@ -257,9 +257,12 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
                     if (gi == goff[i]) flags |= 1;
                     if (gi + 1 == goff[i + 1]) flags |= 2;
                     const bool cont = groups[gi].ga == GroupDesc::GA_CONT;
-                    if (inner && goff[i + 1] - goff[i] == 1 && !cont && groups[gi].mask &&
+                    if (goff[i + 1] - goff[i] == 1 && !cont && groups[gi].mask &&
                         groups[gi].ga == (uint32_t)__builtin_ctzll(groups[gi].mask))
-                        flags |= 4;
+                        // one group led by its lowest member: an inner row of a segment run (7), or — the first row of a
+                        // segment, e.g. of an allele between two shared segments — the HEAD of one (4 alone): the kernels
+                        // start a register / gather run on either, and continue one only into a 7
+                        flags = inner ? 7 : 4;
                     int4 r;
                     r.x = (int)((unsigned)i | ((unsigned)li << 20) | ((unsigned)flags << 23) | ((cont ? 0u : groups[gi].ga) << 26));
                     r.y = (int)((unsigned)groups[gi].slot | ((unsigned)(h.knm[i] + 1) << 20) | ((unsigned)groups[gi].page << 29) |
@@ -281,6 +284,7 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
                     const int nm = __builtin_popcountll(((unsigned long long)(unsigned)out[t].w << 32) | (unsigned)out[t].z);
                     const bool pays = left * (77 * (nm - 1) - 160) >= 200 * (nm - 1);
                     out[t].x = (int)(((unsigned)out[t].x & 0x03ffffffu) | ((unsigned)(pays ? left : 0) << 26));
+                    if ((((unsigned)out[t].x >> 23) & 7u) == 4u) left = 0;      // a HEAD: the record before it belongs to another segment
                 }
             }
         };

@@ -396,6 +396,7 @@ __global__ __launch_bounds__(kStripes ? 512 : 64, kStripes ? 1 : RG_SWEEP_WAVES)
         int i = w0 & 0xfffff;
         int li = (w0 >> 20) & 7;
         int flags = (w0 >> 23) & 7;
+        if (flags == 4) flags = 7;                      // head of a run (see the step table in rg_path_driver.hip): an ordinary one-group row here
         int slot = w1 & 0xfffff;
         const int kbase = ((w1 >> 29) & 3) * 64;        // first path id of the entry's 64-path page
         const bool cont = w1 < 0;                       // continuation entry of a group that spans pages: members only

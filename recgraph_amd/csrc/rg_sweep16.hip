@@ -522,7 +522,9 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
         fetch(t, w0, w1, gmask);
         const int i = w0 & 0xfffff;
         const int li = (w0 >> 20) & 7;
-        const int flags = (w0 >> 23) & 7;
+        // (flags == F_INNER alone: the HEAD of a run — a segment's first row that has one group led by its lowest member;
+        // it starts a register / gather run exactly like an inner row, but no run continues INTO it)
+        const int flags = ((w0 >> 23) & 7) == F_INNER ? 7 : ((w0 >> 23) & 7);
         const int slot = w1 & 0xfffff;
         const int kbase = kWide ? ((w1 >> 29) & 3) * 64 : 0;   // first path id of the entry's 64-path page
         const bool cont = kWide && w1 < 0;                     // continuation entry of a group that spans pages: members only
@@ -771,7 +773,7 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
                 }
                 ++t;
                 if (t >= nsteps) break;
-                if (!((peek_w0(t) >> 23) & F_INNER)) break;     // next record starts another segment
+                if (((peek_w0(t) >> 23) & 7) != 7) break;       // next record starts another segment (a HEAD or a general row)
                 int nw0, nw1;
                 unsigned long long ngm;
                 fetch(t, nw0, nw1, ngm);
