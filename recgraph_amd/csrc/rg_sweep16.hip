@@ -226,11 +226,17 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
     int* sct = lds16;                    // [36] score table
     int* endv = lds16 + 64;              // [RG_MAXP]
     int* endr = lds16 + 64 + RG_MAXP;    // [RG_MAXP]
-    int* s2 = lds16 + 64 + 2 * RG_MAXP;  // [5][64] packed score pairs: s2[li*64 + (code_lo | code_hi << 3)]
+    // [5][64] packed score pairs: s2[li*64 + (code_lo | code_hi << 3)] — only read while the profile below is built: it
+    // shares the words of gT / gS (C * 64 + C / 2 * 64 >= 320 words)
+    int* s2 = lds16 + 64 + 2 * RG_MAXP + (RG_SWEEP16_THRLDS ? C * WAVE : 0);
     // gather runs (below): gT[q][lane] = best (delta << 16 | path) of the run's members at the run start, gS[r][lane] = one
     // member's packed row at the run start
-    int* gT = lds16 + 64 + 2 * RG_MAXP + 5 * 64 + (RG_SWEEP16_THRLDS ? C * WAVE : 0);   // [C][64]
+    int* gT = lds16 + 64 + 2 * RG_MAXP + (RG_SWEEP16_THRLDS ? C * WAVE : 0);            // [C][64]
     int* gS = gT + C * WAVE;                                                               // [H][64]
+    // score profile of this read: sprof[(li * 64 + lane) * H + r] = the packed (s - g) pair register r of the lane adds on a
+    // diagonal step into a row whose base is li — one 16-byte LDS read per four registers and row instead of a code
+    // extraction + table lookup per register (24 VALU instructions per row at C = 16)
+    int* sprof = gS + H * WAVE;                                                            // [5][64][H]
     if (lane < 36) sct[lane] = a.sc.t[lane];
     __syncthreads();
     const int gcost = sct[GAP];          // uniform read-gap cost (checked by the launcher): the z-space slope
@@ -244,7 +250,7 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
     // emission threshold << 16 per column (INT32_MAX = never; columns that do not exist).  Kept in LDS ([q][lane], read once
     // per row by the epilogue): the forward variant has no registers to spare (RG_SWEEP16_THRLDS=0: in registers)
 #if RG_SWEEP16_THRLDS
-    int* thrl = lds16 + 64 + 2 * RG_MAXP + 5 * 64;
+    int* thrl = lds16 + 64 + 2 * RG_MAXP;
 #define THRK(q) thrl[(q) * WAVE + lane]
 #else
     int thrk[C];
@@ -284,6 +290,11 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
             const int r = q % H, hi = q / H;
             pcode[r / 8] |= (unsigned long long)code << (8 * (r % 8) + 3 * hi);
             THRK(q) = thr_key(q, true);
+        }
+#pragma unroll
+        for (int li = 0; li < 5; ++li) {
+#pragma unroll
+            for (int r = 0; r < H; ++r) sprof[(li * WAVE + lane) * H + r] = s2[li * 64 + (int)((pcode[r / 8] >> (8 * (r % 8))) & 63)];
         }
         // start rows: the gap-only row, identical for every path (uniform gap cost: A = c * gcost, z = 0)
 #pragma unroll
@@ -508,6 +519,19 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
     };
 
     int s[H];
+    auto load_steps = [&](int li_) {
+        const int* sp = sprof + (li_ * WAVE + lane) * H;
+        if constexpr (H >= 4) {
+#pragma unroll
+            for (int r4 = 0; r4 < H / 4; ++r4) {
+                const int4 v = reinterpret_cast<const int4*>(sp)[r4];
+                s[4 * r4] = v.x; s[4 * r4 + 1] = v.y; s[4 * r4 + 2] = v.z; s[4 * r4 + 3] = v.w;
+            }
+        } else {
+            const int2 v = *reinterpret_cast<const int2*>(sp);
+            s[0] = v.x; s[1] = v.y;
+        }
+    };
     int bkey[C];
 #ifdef RG_SWEEP16_NOKEYS
 #pragma unroll
@@ -600,8 +624,7 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
             for (int step = 0;; ++step) {
                 const int g_i = __builtin_amdgcn_readfirstlane(sct[rli * 6 + GAP]);
                 const int g0 = a.semi ? 0 : g_i;
-#pragma unroll
-                for (int r = 0; r < H; ++r) s[r] = s2[rli * 64 + (int)((pcode[r / 8] >> (8 * (r % 8))) & 63)];
+                load_steps(rli);
                 unsigned umask;
                 RowOps16<C>::alpha(A, s, g_i, g0, lane, MU, ML, umask, lmask, src);
                 if (dirs) store_dirs(rslot, umask, lmask);
@@ -717,8 +740,7 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
             while (true) {
                 const int g_i = __builtin_amdgcn_readfirstlane(sct[rli * 6 + GAP]);
                 const int g0 = a.semi ? 0 : g_i;
-#pragma unroll
-                for (int r = 0; r < H; ++r) s[r] = s2[rli * 64 + (int)((pcode[r / 8] >> (8 * (r % 8))) & 63)];
+                load_steps(rli);
                 unsigned umask;
                 RowOps16<C>::alpha(rr[0], s, g_i, g0, lane, MU, ML, umask, lmask, src);
                 if (nm > 1) RowOps16<C>::select_steps(SEL, s, MU, g_i, g0, lane);
@@ -789,10 +811,7 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
         }
         const int g_i = __builtin_amdgcn_readfirstlane(sct[li * 6 + GAP]);
         const int g0 = a.semi ? 0 : g_i;
-        if (flags & F_FIRST) {
-#pragma unroll
-            for (int r = 0; r < H; ++r) s[r] = s2[li * 64 + (int)((pcode[r / 8] >> (8 * (r % 8))) & 63)];
-        }
+        if (flags & F_FIRST) load_steps(li);
         {
             unsigned long long rest = cont ? gmask : gmask & ~(1ull << (ga - kbase));
             cells += (unsigned long long)nm;
@@ -1007,7 +1026,7 @@ void launch_colmax_rec(const ExpandArgs& a, int* colmax_out, int* colarg_out, in
 
 template <int kColmax, bool kRec, bool kWide>
 static void launch_sweep16_w(const SweepArgs& a, int nreads, int C, hipStream_t s) {
-    const size_t bytes = (size_t)(64 + 2 * RG_MAXP + 5 * 64 + (RG_SWEEP16_THRLDS ? C * WAVE : 0) + (RG_SWEEP16_GATHER ? C * WAVE + C / 2 * WAVE : 0)) * sizeof(int);
+    const size_t bytes = (size_t)(64 + 2 * RG_MAXP + (RG_SWEEP16_THRLDS ? C * WAVE : 0) + C * WAVE + C / 2 * WAVE + 5 * WAVE * (C / 2)) * sizeof(int);
     switch (C) {
         case 4: hipLaunchKernelGGL((k_sweep16<4, kColmax, kRec, kWide>), dim3(nreads), dim3(64), bytes, s, a); break;
         case 8: hipLaunchKernelGGL((k_sweep16<8, kColmax, kRec, kWide>), dim3(nreads), dim3(64), bytes, s, a); break;
