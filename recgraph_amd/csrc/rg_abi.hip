@@ -40,6 +40,7 @@ Options& options() {
         { const char* v = getenv("RG_LB_BONUS"); o.lb_bonus = v ? atoi(v) : 0; }
         o.no_spec = env("RG_NO_SPEC");
         o.no_gather = env("RG_NO_GATHER");
+        o.no_split = env("RG_NO_SPLIT");
         o.spin_wait = env("RG_SPIN_WAIT");
         { const char* v = getenv("RG_SPEC_MARGIN"); if (v) o.spec_margin = atoi(v); }
     });
@@ -322,6 +323,7 @@ static std::atomic<int>* option_slot(const char* name) {
     if (!strcmp(name, "stripe_c")) return &o.stripe_c;
     if (!strcmp(name, "no_spec")) return &o.no_spec;
     if (!strcmp(name, "no_gather")) return &o.no_gather;
+    if (!strcmp(name, "no_split")) return &o.no_split;
     if (!strcmp(name, "spin_wait")) return &o.spin_wait;
     if (!strcmp(name, "spec_margin")) return &o.spec_margin;
     return nullptr;

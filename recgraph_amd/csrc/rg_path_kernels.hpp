@@ -38,6 +38,9 @@ struct SweepArgs {
     const int4* fsteps;        // step tables (one record per (row, edge group), sweep order), see k_sweep
     const int4* rsteps;
     int nfsteps, nrsteps;
+    const int4* fsplit;        // the same records with TAILs (rg_path_driver.hip: split tables), or null; launch_sweep16 hands
+    const int4* rsplit;        // them to the record variants of k_sweep16 when `use_split` says the batch qualifies
+    int use_split;
     const int* lb;             // per read lower bound of S0: when set (forward sweep only) the threshold of column
                                // j is lb + brc - (n - j) * maxmatch (no reverse information needed)
     int brc, maxmatch;

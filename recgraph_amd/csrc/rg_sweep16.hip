@@ -170,6 +170,10 @@ struct RowOps16 {
 #define RG_SWEEP16_GATHER_FWD 1      // the forward record variant spills 121 registers with them compiled in and still gains 3 ms (47.7 -> 44.7)
 #endif
 
+#ifndef RG_SWEEP16_PF
+#define RG_SWEEP16_PF 0              // > 0: rolling rows of the records ahead touched early (one load per row: 16 lanes x 128 B). Measured SLOWER (fwd 39.5 -> 40.9 ms, rev 35.0 -> 36.5, config 4 15.8 -> 19.9): the sweep is bound by the fabric traffic of those rows, not by their latency
+#endif
+
 #ifndef RG_SWEEP16_KRUN_REV
 #define RG_SWEEP16_KRUN_REV RG_SWEEP16_KRUN     // the variant without column maxima (reverse sweep of the record pipeline)
 #endif
@@ -467,6 +471,40 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
         return idx == 0 && tt > 0 ? __builtin_amdgcn_readlane(recs_next.x, 0) : __builtin_amdgcn_readlane(recs.x, idx);
     };
 
+    // ROW PREFETCH.  A register run / a general record starts with the loads of its members' rolling rows, which miss the L2
+    // (2048 resident reads x 64 KB): a full Infinity Cache / HBM latency with nothing else to issue.  The records ahead are
+    // already in registers (two batches of 64), so their members' rows are touched early: ONE load per row (lanes 0-15
+    // read one word of each of its 128-byte lines), retired into a sink when the current record / run is done.
+    constexpr int NPF = RG_SWEEP16_PF > 0 && !kWide ? RG_SWEEP16_PF : 1;
+    int pfv[NPF];
+    int pf_sink = 0;
+    auto peek_mask = [&](int tt) -> unsigned long long {      // members of record tt (0: outside the batches held / past the end)
+        const int d = tt - (t & ~(WAVE - 1));
+        if (tt >= nsteps || d >= 2 * WAVE) return 0ull;
+        const unsigned z = (unsigned)(d < WAVE ? __builtin_amdgcn_readlane(recs.z, d) : __builtin_amdgcn_readlane(recs_next.z, d - WAVE));
+        const unsigned w = (unsigned)(d < WAVE ? __builtin_amdgcn_readlane(recs.w, d) : __builtin_amdgcn_readlane(recs_next.w, d - WAVE));
+        return ((unsigned long long)w << 32) | z;
+    };
+    auto prefetch_rows = [&](unsigned long long gm, unsigned long long gm2) {
+        if (RG_SWEEP16_PF <= 0 || kWide) return;
+        const int poff = ((lane & 15) * 32) & (wrow - 1);
+#pragma unroll
+        for (int e = 0; e < NPF; ++e) {
+            pfv[e] = 0;
+            if (!gm) { gm = gm2; gm2 = 0; }
+            if (gm) {
+                const int k = __builtin_ctzll(gm);
+                gm &= gm - 1;
+                pfv[e] = rows[(long long)k * wrow + poff];
+            }
+        }
+    };
+    auto retire_prefetch = [&]() {
+        if (RG_SWEEP16_PF <= 0 || kWide) return;
+#pragma unroll
+        for (int e = 0; e < NPF; ++e) pf_sink ^= pfv[e];
+    };
+
     // semiglobal end-row selection (see k_sweep)
     const bool semi_end = a.semi && !rev;
     const int ln_end = n / C, ql_end = n % C;
@@ -548,15 +586,22 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
         const int li = (w0 >> 20) & 7;
         // (flags == F_INNER alone: the HEAD of a run — a segment's first row that has one group led by its lowest member;
         // it starts a register / gather run exactly like an inner row, but no run continues INTO it)
-        const int flags = ((w0 >> 23) & 7) == F_INNER ? 7 : ((w0 >> 23) & 7);
+        // A TAIL (bit F_INNER with a zero run field; split step tables only, see rg_path_driver.hip): one group of a row
+        // that has several, placed right behind the register run of the SAME paths on its predecessor row — the run
+        // continues into it (the rows stay in registers) and its keys fold into the row's bkey like a general record's.
+        const int flags = (((w0 >> 23) & 7) == F_INNER && ((w0 >> 26) & 63) != 0) ? 7 : ((w0 >> 23) & 7);
         const int slot = w1 & 0xfffff;
         const int kbase = kWide ? ((w1 >> 29) & 3) * 64 : 0;   // first path id of the entry's 64-path page
         const bool cont = kWide && w1 < 0;                     // continuation entry of a group that spans pages: members only
         // (an inner row of a one-entry segment run: the alpha is the lowest member, the field holds the run length left)
         const int ga = kbase + ((flags & F_INNER) ? __builtin_ctzll(gmask | (1ull << 63)) : ((w0 >> 26) & 63));
         const int nm = __popcll(gmask);
+        // (inner / head records: the alpha field holds the rows left in the run, this one included, capped at 63.)  A gather
+        // run costs ~180 instructions per member once per run (two passes) + ~160 per row, the member-by-member form ~77 per
+        // member and row: it pays when R * (77 (nm - 1) - 160) >= 200 (nm - 1)  (32 paths: 3 rows, 8 paths: 4, 5 paths: 6)
+        const int run_left = (flags & F_INNER) ? ((w0 >> 26) & 63) : 0;
         if (RG_SWEEP16_GATHER && (kRec ? (kColmax == 0 || (kColmax == 2 && RG_SWEEP16_GATHER_FWD)) : !track) && !kWide && a.gather_ok && !semi_end && (flags & F_INNER) && nm > KRUN &&
-            ((w0 >> 26) & 63) != 0) {
+            run_left * (77 * (nm - 1) - 160) >= 200 * (nm - 1)) {
             // ---- GATHER RUN: R consecutive inner rows of a segment that a wide group (nm paths, one group, alpha = its lowest
             // path) runs through.  Every member follows the alpha's directions, and a direction only MOVES values (D: from
             // column c - 1 of the row above, U: from column c, L: from column c - 1 of the new row) and adds a constant that
@@ -658,12 +703,13 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
                         for (int r = 0; r < H; ++r) acc &= pk_sub_sat(bv[r], minplain2);
                     }
                     if (__any(((unsigned)acc & 0x80008000u) != 0x80008000u)) {
+                        int tkey[C];         // (not bkey: see TAIL)
 #pragma unroll
                         for (int r = 0; r < H; ++r) {
-                            bkey[r] = (int)(((unsigned)bv[r] << 16) | ((unsigned)K2[r] & 0xffffu));
-                            bkey[r + H] = (int)(((unsigned)bv[r] & 0xffff0000u) | ((unsigned)K2[r] >> 16));
+                            tkey[r] = (int)(((unsigned)bv[r] << 16) | ((unsigned)K2[r] & 0xffffu));
+                            tkey[r + H] = (int)(((unsigned)bv[r] & 0xffff0000u) | ((unsigned)K2[r] >> 16));
                         }
-                        row_end(ri, knm_row, bkey, true);
+                        row_end(ri, knm_row, tkey, true);
                     }
                 }
 #endif
@@ -719,7 +765,9 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
 #endif
             continue;
         }
-        if (KRUN > 0 && (flags & F_INNER) && nm <= KRUN) {
+        int e_i = i, e_w1 = w1, e_flags = flags;   // the row whose epilogue runs at the end of this iteration
+        bool e_adv = true;
+        if (KRUN > 0 && (flags & F_INNER) && nm <= KRUN && run_left > 0) {
             // ---- inner rows of a segment with a small group: the same paths, one group, predecessor = previous row.
             // Their rows stay in registers for the whole run: no row load/store latency, no HBM traffic.  The group
             // alpha of an inner row is its lowest path (alphas[row] == alphas[pred], rg_graph.cpp) = member 0.
@@ -736,7 +784,9 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
 #pragma unroll
                     for (int r = 0; r < H; ++r) { rr[kk][r] = 0; RG_ROW_LD(rr[kk][r], rows[(long long)mk[kk] * wrow + r * WAVE + lane]); }
                 }
-            int ri = i, rli = li, rslot = slot, rw1 = w1;
+            prefetch_rows(peek_mask(t + max(run_left, 1)), peek_mask(t + max(run_left, 1) + 1));     // what follows the run
+            int ri = i, rli = li, rslot = slot, rw1 = w1, rfl = 7;
+            bool tail = false;
             while (true) {
                 const int g_i = __builtin_amdgcn_readfirstlane(sct[rli * 6 + GAP]);
                 const int g0 = a.semi ? 0 : g_i;
@@ -749,7 +799,13 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
                 for (int kk = 1; kk < KRUN; ++kk)
                     if (kk < nm) RowOps16<C>::member(rr[kk], SEL, lane, MU, ML, lmask, src);
                 cells += (unsigned long long)nm;
-                if (track && kRec && kColmax != 1) {
+                if (kRec && kColmax != 1 && tail) {
+                    if (track) {
+                        if (rfl & F_FIRST) set_keys(bkey, rr[0], mk[0]); else fold_keys(bkey, rr[0], mk[0]);
+#pragma unroll
+                        for (int kk = 1; kk < KRUN; ++kk) if (kk < nm) fold_keys(bkey, rr[kk], mk[kk]);
+                    }
+                } else if (track && kRec && kColmax != 1) {
                     // LAZY KEYS (rows in registers): the best VALUE per column is a packed maximum over the members (8
                     // v_pk_max per member instead of 32 key instructions); it feeds the packed column maxima directly, and
                     // the (value, path) keys are only built when some column of some lane can reach its threshold
@@ -777,10 +833,11 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
                         for (int r = 0; r < H; ++r) acc &= pk_sub_sat(bv[r], minplain2);
                     }
                     if (__any(((unsigned)acc & 0x80008000u) != 0x80008000u)) {      // some half >= its threshold
-                        set_keys(bkey, rr[0], mk[0]);
+                        int tkey[C];         // (not bkey: a row with several groups may be in progress around this run, see TAIL)
+                        set_keys(tkey, rr[0], mk[0]);
 #pragma unroll
-                        for (int kk = 1; kk < KRUN; ++kk) if (kk < nm) fold_keys(bkey, rr[kk], mk[kk]);
-                        row_end(ri, knm_row, bkey, true);
+                        for (int kk = 1; kk < KRUN; ++kk) if (kk < nm) fold_keys(tkey, rr[kk], mk[kk]);
+                        row_end(ri, knm_row, tkey, true);
                     }
                 } else if (track) {
                     set_keys(bkey, rr[0], mk[0]);
@@ -794,24 +851,30 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
                     end_row_done(ri);
                 }
                 ++t;
-                if (t >= nsteps) break;
-                if (((peek_w0(t) >> 23) & 7) != 7) break;       // next record starts another segment (a HEAD or a general row)
+                if (tail || t >= nsteps) break;                 // (a tail ends its run)
+                const int pw = peek_w0(t);
+                const int nf = (pw >> 23) & 7;
+                const bool to_tail = kRec && kColmax != 1 && (nf & F_INNER) && ((pw >> 26) & 63) == 0;
+                if (!to_tail && (nf != 7 || ((pw >> 26) & 63) == 0)) break;   // next record starts another segment (a HEAD or a general row)
                 int nw0, nw1;
                 unsigned long long ngm;
                 fetch(t, nw0, nw1, ngm);
                 ri = nw0 & 0xfffff; rli = (nw0 >> 20) & 7; rslot = nw1 & 0xfffff; rw1 = nw1;
+                tail = to_tail; rfl = nf;
             }
+            retire_prefetch();
 #pragma unroll
             for (int kk = 0; kk < KRUN; ++kk)
                 if (kk < nm) {
 #pragma unroll
                     for (int r = 0; r < H; ++r) RG_ROW_ST(rows[(long long)mk[kk] * wrow + r * WAVE + lane], rr[kk][r]);
                 }
-            continue;
-        }
+            if (!tail) continue;
+            e_i = ri; e_w1 = rw1; e_flags = rfl; e_adv = false;     // the tail's row: its epilogue below when this was its last group
+        } else {
         const int g_i = __builtin_amdgcn_readfirstlane(sct[li * 6 + GAP]);
         const int g0 = a.semi ? 0 : g_i;
-        if (flags & F_FIRST) load_steps(li);
+        load_steps(li);          // (every record: register / gather runs of other rows may lie between the groups of one row)
         {
             unsigned long long rest = cont ? gmask : gmask & ~(1ull << (ga - kbase));
             cells += (unsigned long long)nm;
@@ -831,6 +894,7 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
                 int rowa[H];
 #pragma unroll
                 for (int r = 0; r < H; ++r) { rowa[r] = s[r]; RG_ROW_LD(rowa[r], rows[(long long)ga * wrow + r * WAVE + lane]); }
+                if (nm <= 8) prefetch_rows(peek_mask(t + 2), 0ull);
                 unsigned umask;
                 RowOps16<C>::alpha(rowa, s, g_i, g0, lane, MU, ML, umask, lmask, src);
                 if (nm > 1) RowOps16<C>::select_steps(SEL, s, MU, g_i, g0, lane);
@@ -861,10 +925,13 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
                 if (semi_end) end_fold(k, i, cur);
             }
         }
-        if (semi_end && (flags & F_LAST)) end_row_done(i);
-        if (track && (flags & F_LAST)) row_end(i, ((w1 >> 20) & 511) - 1, bkey);
-        ++t;
+        if (!cont && nm <= 8) retire_prefetch();
+        }
+        if (semi_end && (e_flags & F_LAST)) end_row_done(e_i);
+        if (track && (e_flags & F_LAST)) row_end(e_i, ((e_w1 >> 20) & 511) - 1, bkey);
+        if (e_adv) ++t;
     }
+    if (RG_SWEEP16_PF > 0 && !kWide) asm volatile("" :: "v"(pf_sink));
 
     // ---- outputs ----
     if (kColmax == 1 && a.colmax_out) {
@@ -1039,7 +1106,14 @@ static void launch_sweep16_c(const SweepArgs& a, int nreads, int C, hipStream_t 
     if (a.g.P > 64) launch_sweep16_w<kColmax, kRec, true>(a, nreads, C, s);
     else launch_sweep16_w<kColmax, kRec, false>(a, nreads, C, s);
 }
-void launch_sweep16(const SweepArgs& a, int nreads, int C, hipStream_t s) {
+void launch_sweep16(const SweepArgs& a_, int nreads, int C, hipStream_t s) {
+    SweepArgs a = a_;
+    // split step tables (TAIL records): the record variants with lazy keys, register runs of 4 and gather runs compiled in
+    constexpr bool split_built = RG_SWEEP16_KRUN == 4 && RG_SWEEP16_KRUN_REV == 4 && RG_SWEEP16_GATHER && RG_SWEEP16_GATHER_FWD;
+    if (split_built && a.use_split && a.fsplit && a.rsplit && a.frec && !(a.colmax_out && a.colarg_out) && a.g.P <= 64 && C <= 16) {
+        a.fsteps = a.fsplit;
+        a.rsteps = a.rsplit;
+    }
     // a sweep that writes records and is not asked for column maxima skips their tracking
     if (a.frec && !a.colmax_out) launch_sweep16_c<0, true>(a, nreads, C, s);
     else if (a.frec && !a.colarg_out) launch_sweep16_c<2, true>(a, nreads, C, s);     // maxima without their cells

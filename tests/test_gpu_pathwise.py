@@ -239,6 +239,32 @@ def test_gather_runs(oracle):
         _check(oracle, g.gfa(), rd[:6], api.MODE_RECOMBINATION, oracle.M8_ABS, R=0, r=0.1, B=0.8)
 
 
+def test_split_step_tables(oracle):
+    """k_sweep16 split step tables: a group of a several-group row whose paths are exactly the paths of a register run on its
+    predecessor row is processed as the TAIL of that run (rows in registers), the row's keys folding across its groups.
+    Allele blocks between shared segments (the shape of configs 4 / 5) with few and many alleles, with and without the
+    switch (`no_split`): byte-identical records, equal to the oracle; with the speculative bound off too (loose forward
+    thresholds: every row emits)."""
+    from recgraph_amd import api, synth
+    for P, rows, plen, shared, seed in ((32, 3000, 300, 0.3, 111), (16, 900, 250, 0.3, 112), (6, 700, 220, 0.4, 113), (40, 1500, 200, 0.15, 114)):
+        g = synth.haplotype_graph(rows, P, path_len=plen, seed=seed, shared_frac=shared)
+        rd = synth.haplotype_reads(g, 20, length=plen, seed=seed + 1, mosaic_frac=0.6) + [g.path_sequence(P - 1)[:plen - 5], "ACGT" * 6]
+        gg = api.Graph.from_gfa_text(g.gfa())
+        names = ["r%d" % i for i in range(len(rd))]
+        for mode, om in ((api.MODE_RECOMBINATION, oracle.M8_ABS), (api.MODE_PATHWISE, oracle.M4_ABS)):
+            base = _check(oracle, g.gfa(), rd, mode, om)
+            for opts in (("no_split",), ("no_spec",), ("no_split", "no_spec")):
+                try:
+                    for o in opts:
+                        api.set_option(o, 1)
+                    texts, _ = api.align_batch(gg, rd, names, mode=mode)
+                finally:
+                    for o in opts:
+                        api.set_option(o, 0)
+                assert texts == base, (P, mode, opts)
+        _check(oracle, g.gfa(), rd[:6], api.MODE_RECOMBINATION, oracle.M8_ABS, R=0, r=0.1, B=0.8)
+
+
 def test_three_sweep_pipeline(oracle):
     """The -m 8 / -m 9 pipeline the driver takes when a gap entry is positive (no path-0 lower bound for the forward
     thresholds: forward column maxima first, reverse sweep, forward again) or on request (RG_THREE_SWEEPS), with the
