@@ -70,13 +70,15 @@ __device__ __forceinline__ int dpp_shr1(int v, int identity) {
     return r;
 }
 
-__device__ __forceinline__ int dpp_incl_max(int v, int identity) {
-    v = max(v, dpp_mov<0x111, 0xf>(identity, v));   // row_shr:1
-    v = max(v, dpp_mov<0x112, 0xf>(identity, v));   // row_shr:2
-    v = max(v, dpp_mov<0x114, 0xf>(identity, v));   // row_shr:4
-    v = max(v, dpp_mov<0x118, 0xf>(identity, v));   // row_shr:8
-    v = max(v, dpp_mov<0x142, 0xa>(identity, v));   // row_bcast:15 into rows 1 and 3
-    v = max(v, dpp_mov<0x143, 0xc>(identity, v));   // row_bcast:31 into rows 2 and 3
+// (a lane without a source keeps its own value whatever the fill is; INT32_MIN is the identity the compiler's DPP combiner
+// knows for a signed max, so each step becomes ONE v_max_i32_dpp instead of constant + v_mov_dpp + v_max)
+__device__ __forceinline__ int dpp_incl_max(int v, int /*identity*/) {
+    v = max(v, dpp_mov<0x111, 0xf>(INT32_MIN, v));   // row_shr:1
+    v = max(v, dpp_mov<0x112, 0xf>(INT32_MIN, v));   // row_shr:2
+    v = max(v, dpp_mov<0x114, 0xf>(INT32_MIN, v));   // row_shr:4
+    v = max(v, dpp_mov<0x118, 0xf>(INT32_MIN, v));   // row_shr:8
+    v = max(v, dpp_mov<0x142, 0xa>(INT32_MIN, v));   // row_bcast:15 into rows 1 and 3
+    v = max(v, dpp_mov<0x143, 0xc>(INT32_MIN, v));   // row_bcast:31 into rows 2 and 3
     return v;
 }
 __device__ __forceinline__ int dpp_incl_sum(int v) {

@@ -94,7 +94,9 @@ struct RowOps16 {
         // stitch: best source inside the lane = max of both chains; left scan over the lanes in z-space is a plain
         // prefix maximum
         const int TL = lo16(run), TH = hi16(run);
-        const int ze = dpp_shr1(dpp_incl_max(max(TH, TL), NEG32), NEG32);   // best source of the lanes to the left
+        // (INT32_MIN = the identity the compiler's DPP combiner knows for a signed max: each scan step becomes ONE
+        // v_max_i32_dpp instead of constant + v_mov_dpp + v_max)
+        const int ze = dpp_shr1(dpp_incl_max(max(TH, TL), INT32_MIN), INT32_MIN);   // best source of the lanes to the left
         const int bl = max(ze, NEG16);                              // carry into the lane's first column
         const int bh = max(TL, bl);                                 // carry into column H of the lane
         int vprev = pack16(bl, bh);
@@ -171,7 +173,8 @@ struct RowOps16 {
 #endif
 
 #ifndef RG_SWEEP16_PF
-#define RG_SWEEP16_PF 0              // > 0: rolling rows of the records ahead touched early (one load per row: 16 lanes x 128 B). Measured SLOWER (fwd 39.5 -> 40.9 ms, rev 35.0 -> 36.5, config 4 15.8 -> 19.9): the sweep is bound by the fabric traffic of those rows, not by their latency
+#define RG_SWEEP16_PF 0              // 1: row touches ahead of the loads (ROW TOUCHES in k_sweep16).  Measured SLOWER by ~1 ms per sweep
+                                     // (profiles/r03_sweep_variants_4.txt: BASE = 1, NOPF = 0): see the note there
 #endif
 
 #ifndef RG_SWEEP16_KRUN_REV
@@ -185,6 +188,7 @@ struct RowOps16 {
 //   RG_SWEEP16_NOKEYS   the best-member keys are not built (row_end runs on constant keys)
 //   RG_SWEEP16_NOEMIT   row_end stops after the column maxima (no threshold tests, ballots, record / Cand stores)
 //   RG_SWEEP16_NODIRS   no direction-word stores
+//   RG_SWEEP16_KRUNNOLD / KRUNNOST   register runs without their run-start loads / run-end stores
 #ifdef RG_SWEEP16_NOROWS
 #define RG_ROW_LD(dst, expr) (dst) = (dst)
 #define RG_ROW_ST(expr, v) ((void)0)
@@ -471,13 +475,15 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
         return idx == 0 && tt > 0 ? __builtin_amdgcn_readlane(recs_next.x, 0) : __builtin_amdgcn_readlane(recs.x, idx);
     };
 
-    // ROW PREFETCH.  A register run / a general record starts with the loads of its members' rolling rows, which miss the L2
-    // (2048 resident reads x 64 KB): a full Infinity Cache / HBM latency with nothing else to issue.  The records ahead are
-    // already in registers (two batches of 64), so their members' rows are touched early: ONE load per row (lanes 0-15
-    // read one word of each of its 128-byte lines), retired into a sink when the current record / run is done.
-    constexpr int NPF = RG_SWEEP16_PF > 0 && !kWide ? RG_SWEEP16_PF : 1;
-    int pfv[NPF];
+    // ROW TOUCHES (RG_SWEEP16_PF=1; off: measured slower).  The loops below keep ONE row load in flight (the next member's), and
+    // a rolling row misses the L2 (2048 resident reads x 64 KB), so the idea was to touch rows early: one load instruction
+    // for FOUR rows (lane l reads one word of line l % 16 of row l / 16), every member of a gather run before the pass that
+    // loads them one by one, and behind a register run's own loads the rows of what follows the run.  Loads return in order
+    // on gfx9 and a wait for a load also drains every store issued before it (one vmcnt for both), so the touches only help
+    // if the waits are for load latency — they are not: with the touches both sweeps got ~1 ms slower, while dropping the
+    // register runs' run-end STORES (timing-only KRUNNOST) takes 3-9 ms off: the waits drain stores.
     int pf_sink = 0;
+    const int pf_off = ((lane & 15) * 32) & (wrow - 1);
     auto peek_mask = [&](int tt) -> unsigned long long {      // members of record tt (0: outside the batches held / past the end)
         const int d = tt - (t & ~(WAVE - 1));
         if (tt >= nsteps || d >= 2 * WAVE) return 0ull;
@@ -485,24 +491,36 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
         const unsigned w = (unsigned)(d < WAVE ? __builtin_amdgcn_readlane(recs.w, d) : __builtin_amdgcn_readlane(recs_next.w, d - WAVE));
         return ((unsigned long long)w << 32) | z;
     };
-    auto prefetch_rows = [&](unsigned long long gm, unsigned long long gm2) {
-        if (RG_SWEEP16_PF <= 0 || kWide) return;
-        const int poff = ((lane & 15) * 32) & (wrow - 1);
-#pragma unroll
-        for (int e = 0; e < NPF; ++e) {
-            pfv[e] = 0;
-            if (!gm) { gm = gm2; gm2 = 0; }
-            if (gm) {
-                const int k = __builtin_ctzll(gm);
-                gm &= gm - 1;
-                pfv[e] = rows[(long long)k * wrow + poff];
-            }
-        }
+    // up to four members of gm (lowest first), one touch
+    auto touch4 = [&](unsigned long long gm) -> int {
+        if (!gm) return 0;
+        const int k0 = __builtin_ctzll(gm);
+        gm = gm & (gm - 1) ? gm & (gm - 1) : gm;
+        const int k1 = __builtin_ctzll(gm);
+        gm = gm & (gm - 1) ? gm & (gm - 1) : gm;
+        const int k2 = __builtin_ctzll(gm);
+        gm = gm & (gm - 1) ? gm & (gm - 1) : gm;
+        const int k3 = __builtin_ctzll(gm);
+        int kk = k0;
+        kk = lane >= 16 ? k1 : kk;
+        kk = lane >= 32 ? k2 : kk;
+        kk = lane >= 48 ? k3 : kk;
+        return rows[(long long)kk * wrow + pf_off];
     };
-    auto retire_prefetch = [&]() {
+    // every member of gm (up to 32): list in LDS (lst: 64 free words), then ceil(nm / 4) touches in flight together
+    auto touch_group = [&](unsigned long long gm, int nm_, int* lst) {
         if (RG_SWEEP16_PF <= 0 || kWide) return;
+        if ((gm >> lane) & 1ull) lst[__popcll(gm & ((1ull << lane) - 1ull))] = lane;
+        __syncthreads();
+        int v[8];
 #pragma unroll
-        for (int e = 0; e < NPF; ++e) pf_sink ^= pfv[e];
+        for (int j = 0; j < 8; ++j) {
+            v[j] = 0;
+            if (4 * j < nm_) v[j] = rows[(long long)lst[min(4 * j + (lane >> 4), nm_ - 1)] * wrow + pf_off];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pf_sink ^= v[j];
+        __syncthreads();
     };
 
     // semiglobal end-row selection (see k_sweep)
@@ -615,6 +633,7 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
             const int ka = ga;
             int A[H], G[H];
             __syncthreads();
+            touch_group(gmask, nm, gT);
 #pragma unroll
             for (int r = 0; r < H; ++r) { A[r] = rows[(long long)ka * wrow + r * WAVE + lane]; gS[r * WAVE + lane] = A[r]; }   // gS: the alpha's row at the run start
             // (1) best (delta, path) per column over the members at the run start; ties -> highest path id: members in
@@ -725,6 +744,7 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
             {
                 int B[H];
                 __syncthreads();
+                touch_group(gmask, nm, gT);
 #pragma unroll
                 for (int r = 0; r < H; ++r) {
                     const int c0 = G[r] & 0xffff, c1 = (unsigned)G[r] >> 16;
@@ -782,9 +802,28 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
             for (int kk = 0; kk < KRUN; ++kk)
                 if (kk < nm) {
 #pragma unroll
-                    for (int r = 0; r < H; ++r) { rr[kk][r] = 0; RG_ROW_LD(rr[kk][r], rows[(long long)mk[kk] * wrow + r * WAVE + lane]); }
+                    for (int r = 0; r < H; ++r) {
+                        rr[kk][r] = 0;
+#ifdef RG_SWEEP16_KRUNNOLD
+                        rr[kk][r] = s[r] ^ (kk + t);     // (timing-only: no run-start loads)
+#else
+                        RG_ROW_LD(rr[kk][r], rows[(long long)mk[kk] * wrow + r * WAVE + lane]);
+#endif
+                    }
                 }
-            prefetch_rows(peek_mask(t + max(run_left, 1)), peek_mask(t + max(run_left, 1) + 1));     // what follows the run
+            int pf_next = 0;
+            if (RG_SWEEP16_PF > 0 && !kWide) {
+                // wait for the run's own rows here (the first row update would one instruction later), then touch the rows of
+                // the record behind the run (and behind its tail): that load is in flight while the run computes
+                __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0)
+                int nt = t + max(run_left, 1);
+                if (nt < nsteps && nt - (t & ~(WAVE - 1)) < 2 * WAVE) {
+                    const int pw = nt - (t & ~(WAVE - 1)) < WAVE ? __builtin_amdgcn_readlane(recs.x, (nt - (t & ~(WAVE - 1))) & (WAVE - 1))
+                                                                 : __builtin_amdgcn_readlane(recs_next.x, (nt - (t & ~(WAVE - 1))) & (WAVE - 1));
+                    if (((pw >> 23) & F_INNER) && ((pw >> 26) & 63) == 0) ++nt;       // a tail: same rows as the run
+                }
+                pf_next = touch4(peek_mask(nt));
+            }
             int ri = i, rli = li, rslot = slot, rw1 = w1, rfl = 7;
             bool tail = false;
             while (true) {
@@ -862,13 +901,18 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
                 ri = nw0 & 0xfffff; rli = (nw0 >> 20) & 7; rslot = nw1 & 0xfffff; rw1 = nw1;
                 tail = to_tail; rfl = nf;
             }
-            retire_prefetch();
+            pf_sink ^= pf_next;
+#ifdef RG_SWEEP16_KRUNNOST
+#pragma unroll
+            for (int kk = 0; kk < KRUN; ++kk) if (kk < nm) { for (int r = 0; r < H; ++r) pf_sink ^= rr[kk][r]; }      // (timing-only: no run-end stores)
+#else
 #pragma unroll
             for (int kk = 0; kk < KRUN; ++kk)
                 if (kk < nm) {
 #pragma unroll
                     for (int r = 0; r < H; ++r) RG_ROW_ST(rows[(long long)mk[kk] * wrow + r * WAVE + lane], rr[kk][r]);
                 }
+#endif
             if (!tail) continue;
             e_i = ri; e_w1 = rw1; e_flags = rfl; e_adv = false;     // the tail's row: its epilogue below when this was its last group
         } else {
@@ -894,7 +938,6 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
                 int rowa[H];
 #pragma unroll
                 for (int r = 0; r < H; ++r) { rowa[r] = s[r]; RG_ROW_LD(rowa[r], rows[(long long)ga * wrow + r * WAVE + lane]); }
-                if (nm <= 8) prefetch_rows(peek_mask(t + 2), 0ull);
                 unsigned umask;
                 RowOps16<C>::alpha(rowa, s, g_i, g0, lane, MU, ML, umask, lmask, src);
                 if (nm > 1) RowOps16<C>::select_steps(SEL, s, MU, g_i, g0, lane);
@@ -925,7 +968,6 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
                 if (semi_end) end_fold(k, i, cur);
             }
         }
-        if (!cont && nm <= 8) retire_prefetch();
         }
         if (semi_end && (e_flags & F_LAST)) end_row_done(e_i);
         if (track && (e_flags & F_LAST)) row_end(e_i, ((e_w1 >> 20) & 511) - 1, bkey);
