@@ -190,15 +190,15 @@ struct RowOps16 {
 //   RG_SWEEP16_NODIRS   no direction-word stores
 //   RG_SWEEP16_KRUNNOLD / KRUNNOST   register runs without their run-start loads / run-end stores
 #ifdef RG_SWEEP16_NOROWS
-#define RG_ROW_LD(dst, expr) (dst) = (dst)
-#define RG_ROW_ST(expr, v) ((void)0)
+#define RG_ROW_LD(k, dst) ((void)0)
+#define RG_ROW_ST(k, src) ((void)0)
 #elif defined(RG_SWEEP16_NOROWS32)
 //   RG_SWEEP16_NOROWS32 no row traffic for the steps whose group holds 16 or more paths (the rows every path visits)
-#define RG_ROW_LD(dst, expr) do { if (nm < 16) (dst) = (expr); } while (0)
-#define RG_ROW_ST(expr, v) do { if (nm < 16) (expr) = (v); } while (0)
+#define RG_ROW_LD(k, dst) do { if (nm < 16) ld_row(k, dst); } while (0)
+#define RG_ROW_ST(k, src) do { if (nm < 16) st_row(k, src); } while (0)
 #else
-#define RG_ROW_LD(dst, expr) (dst) = (expr)
-#define RG_ROW_ST(expr, v) (expr) = (v)
+#define RG_ROW_LD(k, dst) ld_row(k, dst)
+#define RG_ROW_ST(k, src) st_row(k, src)
 #endif
 
 // kColmax = 2: per-column maxima as packed VALUES only (8 v_perm + 8 v_pk_max per row instead of 48 compare / select
@@ -253,6 +253,30 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
         s2[e] = (cl < 6 && ch < 6) ? pack16(sct[li * 6 + cl] - gcost, sct[li * 6 + ch] - gcost) : 0;   // diagonal step in z-space
     }
     int* rows = a.roll + (long long)rd * P * wrow;
+    // rolling rows in HBM: [path][lane][r] — the H packed words of a lane are contiguous, so a row moves as 16-byte
+    // accesses (two per lane at C = 16; the wave covers the row's 2 KB contiguously) instead of one 4-byte access per word
+    auto ld_row = [&](int k, int (&dst)[H]) {
+        const int* p = rows + (long long)k * wrow + lane * H;
+        if constexpr (H >= 4) {
+#pragma unroll
+            for (int r4 = 0; r4 < H / 4; ++r4) {
+                const int4 v = reinterpret_cast<const int4*>(p)[r4];
+                dst[4 * r4] = v.x; dst[4 * r4 + 1] = v.y; dst[4 * r4 + 2] = v.z; dst[4 * r4 + 3] = v.w;
+            }
+        } else {
+            const int2 v = *reinterpret_cast<const int2*>(p);
+            dst[0] = v.x; dst[1] = v.y;
+        }
+    };
+    auto st_row = [&](int k, const int (&src)[H]) {
+        int* p = rows + (long long)k * wrow + lane * H;
+        if constexpr (H >= 4) {
+#pragma unroll
+            for (int r4 = 0; r4 < H / 4; ++r4) reinterpret_cast<int4*>(p)[r4] = make_int4(src[4 * r4], src[4 * r4 + 1], src[4 * r4 + 2], src[4 * r4 + 3]);
+        } else {
+            *reinterpret_cast<int2*>(p) = make_int2(src[0], src[1]);
+        }
+    };
     // per-column constants of this lane
     unsigned long long pcode[(H + 7) / 8] = {};   // 8 bits per register: code_lo | code_hi << 3
     // emission threshold << 16 per column (INT32_MAX = never; columns that do not exist).  Kept in LDS ([q][lane], read once
@@ -313,13 +337,13 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
         for (int r = 0; r < (kRec ? H : 1); ++r)
             thz[kRec ? r : 0] = pack16(THRK(kRec ? r : 0) >> 16, THRK(kRec ? r + H : 0) >> 16);
         minplain2 = pack16(minplain >> 16, minplain >> 16);
-        for (int k = 0; k < P; ++k) {
+        int row0[H];
 #pragma unroll
-            for (int r = 0; r < H; ++r) {
-                const int c0 = lane * C + r, c1 = c0 + H;
-                rows[(long long)k * wrow + r * WAVE + lane] = pack16(c0 < ncols ? 0 : NEG16, c1 < ncols ? 0 : NEG16);
-            }
+        for (int r = 0; r < H; ++r) {
+            const int c0 = lane * C + r, c1 = c0 + H;
+            row0[r] = pack16(c0 < ncols ? 0 : NEG16, c1 < ncols ? 0 : NEG16);
         }
+        for (int k = 0; k < P; ++k) st_row(k, row0);
     }
     __syncthreads();
 
@@ -483,7 +507,7 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
     // if the waits are for load latency — they are not: with the touches both sweeps got ~1 ms slower, while dropping the
     // register runs' run-end STORES (timing-only KRUNNOST) takes 3-9 ms off: the waits drain stores.
     int pf_sink = 0;
-    const int pf_off = ((lane & 15) * 32) & (wrow - 1);
+    const int pf_off = ((lane & 15) * 32) & (wrow - 1);       // one word per 128-byte line of a row
     auto peek_mask = [&](int tt) -> unsigned long long {      // members of record tt (0: outside the batches held / past the end)
         const int d = tt - (t & ~(WAVE - 1));
         if (tt >= nsteps || d >= 2 * WAVE) return 0ull;
@@ -635,7 +659,10 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
             __syncthreads();
             touch_group(gmask, nm, gT);
 #pragma unroll
-            for (int r = 0; r < H; ++r) { A[r] = rows[(long long)ka * wrow + r * WAVE + lane]; gS[r * WAVE + lane] = A[r]; }   // gS: the alpha's row at the run start
+            for (int r = 0; r < H; ++r) A[r] = 0;
+            ld_row(ka, A);
+#pragma unroll
+            for (int r = 0; r < H; ++r) gS[r * WAVE + lane] = A[r];   // gS: the alpha's row at the run start
             // (1) best (delta, path) per column over the members at the run start; ties -> highest path id: members in
             // ascending order, a later one replaces on >=.  Packed: delta = row_k - A0 (saturating: |delta| fits, gather_ok)
 #ifndef RG_G_NOPH1
@@ -648,8 +675,7 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
                 int kn = -1;
                 if (rest) {
                     kn = kbase + __builtin_ctzll(rest); rest &= rest - 1;
-#pragma unroll
-                    for (int r = 0; r < H; ++r) nx[r] = rows[(long long)kn * wrow + r * WAVE + lane];
+                    ld_row(kn, nx);
                 }
                 while (kn >= 0) {
                     const int k = kn;
@@ -658,8 +684,7 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
                     for (int r = 0; r < H; ++r) cur[r] = nx[r];
                     if (rest) {
                         kn = kbase + __builtin_ctzll(rest); rest &= rest - 1;
-#pragma unroll
-                        for (int r = 0; r < H; ++r) nx[r] = rows[(long long)kn * wrow + r * WAVE + lane];
+                        ld_row(kn, nx);
                     } else kn = -1;
                     int kk = k;
                     asm volatile("" : "+v"(kk));
@@ -752,15 +777,13 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
                     const int a0 = (c0 & 1) ? hi16(w0v) : lo16(w0v), a1 = (c1 & 1) ? hi16(w1v) : lo16(w1v);
                     B[r] = pk_sub_sat(A[r], pack16(a0, a1));
                 }
-#pragma unroll
-                for (int r = 0; r < H; ++r) rows[(long long)ka * wrow + r * WAVE + lane] = A[r];
+                st_row(ka, A);
                 unsigned long long rest = gmask & ~(1ull << (ka - kbase));
                 int nx[H];
                 int kn = -1;
                 if (rest) {
                     kn = kbase + __builtin_ctzll(rest); rest &= rest - 1;
-#pragma unroll
-                    for (int r = 0; r < H; ++r) nx[r] = rows[(long long)kn * wrow + r * WAVE + lane];
+                    ld_row(kn, nx);
                 }
                 while (kn >= 0) {
                     const int k = kn;
@@ -769,17 +792,18 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
                     for (int r = 0; r < H; ++r) gS[r * WAVE + lane] = nx[r];
                     if (rest) {
                         kn = kbase + __builtin_ctzll(rest); rest &= rest - 1;
-#pragma unroll
-                        for (int r = 0; r < H; ++r) nx[r] = rows[(long long)kn * wrow + r * WAVE + lane];
+                        ld_row(kn, nx);
                     } else kn = -1;
                     __syncthreads();
+                    int outr[H];
 #pragma unroll
                     for (int r = 0; r < H; ++r) {
                         const int c0 = G[r] & 0xffff, c1 = (unsigned)G[r] >> 16;
                         const int w0v = gS[c0 >> 1], w1v = gS[c1 >> 1];
                         const int v0 = (c0 & 1) ? hi16(w0v) : lo16(w0v), v1 = (c1 & 1) ? hi16(w1v) : lo16(w1v);
-                        rows[(long long)k * wrow + r * WAVE + lane] = pk_add(B[r], pack16(v0, v1));
+                        outr[r] = pk_add(B[r], pack16(v0, v1));
                     }
+                    st_row(k, outr);
                 }
             }
 #endif
@@ -802,14 +826,10 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
             for (int kk = 0; kk < KRUN; ++kk)
                 if (kk < nm) {
 #pragma unroll
-                    for (int r = 0; r < H; ++r) {
-                        rr[kk][r] = 0;
-#ifdef RG_SWEEP16_KRUNNOLD
-                        rr[kk][r] = s[r] ^ (kk + t);     // (timing-only: no run-start loads)
-#else
-                        RG_ROW_LD(rr[kk][r], rows[(long long)mk[kk] * wrow + r * WAVE + lane]);
+                    for (int r = 0; r < H; ++r) rr[kk][r] = s[r] ^ (kk + t);     // (only what the timing-only builds without loads keep)
+#ifndef RG_SWEEP16_KRUNNOLD
+                    RG_ROW_LD(mk[kk], rr[kk]);
 #endif
-                    }
                 }
             int pf_next = 0;
             if (RG_SWEEP16_PF > 0 && !kWide) {
@@ -908,10 +928,7 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
 #else
 #pragma unroll
             for (int kk = 0; kk < KRUN; ++kk)
-                if (kk < nm) {
-#pragma unroll
-                    for (int r = 0; r < H; ++r) RG_ROW_ST(rows[(long long)mk[kk] * wrow + r * WAVE + lane], rr[kk][r]);
-                }
+                if (kk < nm) RG_ROW_ST(mk[kk], rr[kk]);
 #endif
             if (!tail) continue;
             e_i = ri; e_w1 = rw1; e_flags = rfl; e_adv = false;     // the tail's row: its epilogue below when this was its last group
@@ -931,18 +948,17 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
             if (rest) {
                 knext = kbase + __builtin_ctzll(rest);
                 rest &= rest - 1;
-#pragma unroll
-                for (int r = 0; r < H; ++r) RG_ROW_LD(nxt[r], rows[(long long)knext * wrow + r * WAVE + lane]);
+                RG_ROW_LD(knext, nxt);
             }
             if (!cont) {
                 int rowa[H];
 #pragma unroll
-                for (int r = 0; r < H; ++r) { rowa[r] = s[r]; RG_ROW_LD(rowa[r], rows[(long long)ga * wrow + r * WAVE + lane]); }
+                for (int r = 0; r < H; ++r) rowa[r] = s[r];
+                RG_ROW_LD(ga, rowa);
                 unsigned umask;
                 RowOps16<C>::alpha(rowa, s, g_i, g0, lane, MU, ML, umask, lmask, src);
                 if (nm > 1) RowOps16<C>::select_steps(SEL, s, MU, g_i, g0, lane);
-#pragma unroll
-                for (int r = 0; r < H; ++r) RG_ROW_ST(rows[(long long)ga * wrow + r * WAVE + lane], rowa[r]);
+                RG_ROW_ST(ga, rowa);
                 if (track) { if (flags & F_FIRST) set_keys(bkey, rowa, ga); else fold_keys(bkey, rowa, ga); }
                 if (semi_end) end_fold(ga, i, rowa);
                 if (dirs) store_dirs(slot, umask, lmask);
@@ -958,12 +974,10 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
                 if (rest) {
                     knext = kbase + __builtin_ctzll(rest);
                     rest &= rest - 1;
-#pragma unroll
-                    for (int r = 0; r < H; ++r) RG_ROW_LD(nxt[r], rows[(long long)knext * wrow + r * WAVE + lane]);
+                    RG_ROW_LD(knext, nxt);
                 } else knext = -1;
                 RowOps16<C>::member(cur, SEL, lane, MU, ML, lmask, src);
-#pragma unroll
-                for (int r = 0; r < H; ++r) RG_ROW_ST(rows[(long long)k * wrow + r * WAVE + lane], cur[r]);
+                RG_ROW_ST(k, cur);
                 if (track) fold_keys(bkey, cur, k);
                 if (semi_end) end_fold(k, i, cur);
             }
@@ -1000,7 +1014,7 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
     if (!rev && !a.semi) {
         const int ql = n % C, ln = n / C;
         for (int k = lane; k < P; k += WAVE) {
-            const int pv = rows[(long long)k * wrow + (ql % H) * WAVE + ln];
+            const int pv = rows[(long long)k * wrow + ln * H + (ql % H)];
             rs->sink_val[k] = (ql >= H ? hi16(pv) : lo16(pv)) + n * gcost;
         }
     }
