@@ -666,7 +666,7 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
             // (1) best (delta, path) per column over the members at the run start; ties -> highest path id: members in
             // ascending order, a later one replaces on >=.  Packed: delta = row_k - A0 (saturating: |delta| fits, gather_ok)
 #ifndef RG_G_NOPH1
-            {
+            if (kRec && track) {         // (only the keys of the rows inside the run need it)
                 int bd[H], bk[H];
 #pragma unroll
                 for (int r = 0; r < H; ++r) { bd[r] = 0; bk[r] = pack16(ka, ka); }
