@@ -177,6 +177,9 @@ struct RowOps16 {
                                      // (profiles/r03_sweep_variants_4.txt: BASE = 1, NOPF = 0): see the note there
 #endif
 
+#ifndef RG_SWEEP16_RUNWAIT
+#define RG_SWEEP16_RUNWAIT 1
+#endif
 #ifndef RG_SWEEP16_KRUN_REV
 #define RG_SWEEP16_KRUN_REV RG_SWEEP16_KRUN     // the variant without column maxima (reverse sweep of the record pipeline)
 #endif
@@ -832,6 +835,11 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
 #endif
                 }
             int pf_next = 0;
+#if RG_SWEEP16_RUNWAIT
+            // wait for the run's rows HERE: otherwise the compiler's wait sits at the top of the row loop as vmcnt(0) (one
+            // counter for loads and stores on gfx9) and every row also waits for the direction-word store of the row before
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+#endif
             if (RG_SWEEP16_PF > 0 && !kWide) {
                 // wait for the run's own rows here (the first row update would one instruction later), then touch the rows of
                 // the record behind the run (and behind its tail): that load is in flight while the run computes
