@@ -550,6 +550,15 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
         __syncthreads();
     };
 
+    // members of record tt without consuming it (like peek_w0: tt = the record the next fetch will take)
+    auto peek_gm = [&](int tt) -> unsigned long long {
+        const int idx = tt & (WAVE - 1);
+        const bool nxt = idx == 0 && tt > 0;
+        const unsigned z = (unsigned)(nxt ? __builtin_amdgcn_readlane(recs_next.z, 0) : __builtin_amdgcn_readlane(recs.z, idx));
+        const unsigned w = (unsigned)(nxt ? __builtin_amdgcn_readlane(recs_next.w, 0) : __builtin_amdgcn_readlane(recs.w, idx));
+        return ((unsigned long long)w << 32) | z;
+    };
+
     // semiglobal end-row selection (see k_sweep)
     const bool semi_end = a.semi && !rev;
     const int ln_end = n / C, ql_end = n % C;
@@ -923,6 +932,9 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
                 const int nf = (pw >> 23) & 7;
                 const bool to_tail = kRec && kColmax != 1 && (nf & F_INNER) && ((pw >> 26) & 63) == 0;
                 if (!to_tail && (nf != 7 || ((pw >> 26) & 63) == 0)) break;   // next record starts another segment (a HEAD or a general row)
+                // ... or is an inner row of ANOTHER segment: in a split table the rows of a segment whose first row had all
+                // its groups moved away as tails can follow an unrelated run (found by test_random_dag_graphs)
+                if (peek_gm(t) != gmask) break;
                 int nw0, nw1;
                 unsigned long long ngm;
                 fetch(t, nw0, nw1, ngm);

@@ -121,6 +121,38 @@ def haplotype_graph(target_rows, n_paths, path_len=1000, seed=1234, shared_frac=
     return SynthGraph(segments, links, paths)
 
 
+def random_dag_graph(n_segments, n_paths, seed=1234, max_seg=10, max_jump=4, similar=0.5):
+    """Segments in topological id order, every path a random walk source -> sink that skips up to ``max_jump - 1``
+    segments per step: nested and overlapping bubbles, paths that share a segment and part ways after it, segments of
+    one row, groups that are proper subsets of the row's paths — everything the block-shaped haplotype graphs never
+    produce (step-table logic of the sweeps: heads, tails, gather runs, several groups per row).  ``similar``: chance that
+    a segment is a mutated copy of an earlier one (alignments with real ties)."""
+    rng = np.random.default_rng(seed)
+    segments = []
+    for i in range(1, n_segments + 1):
+        if i > 2 and rng.random() < similar:
+            base = segments[int(rng.integers(max(0, i - 6), i - 1))][1]
+            seq = _mutate(rng, base) if len(base) > 1 else _rand_seq(rng, 1)
+        else:
+            seq = _rand_seq(rng, int(rng.integers(1, max_seg + 1)))
+        segments.append((i, seq))
+    paths = []
+    for _ in range(n_paths):
+        p, cur = [1], 1
+        while cur < n_segments:
+            cur = min(n_segments, cur + int(rng.integers(1, max_jump + 1)))
+            p.append(cur)
+        paths.append(p)
+    used = {i for p in paths for i in p}
+    for i in range(2, n_segments):
+        if i not in used:           # every segment on at least one path: spliced into a random path at its place
+            p = paths[int(rng.integers(0, n_paths))]
+            at = next(t for t, x in enumerate(p) if x > i)
+            p.insert(at, i)
+    links = [(a, b) for p in paths for a, b in zip(p, p[1:])]
+    return SynthGraph(segments, links, paths)
+
+
 def linear_graph(target_rows, seed=1234):
     """Backbone with sparse bubbles (configs 2/3: ~1 002 / ~2 002 rows, >= 85 % of rows on the backbone)."""
     rng = np.random.default_rng(seed)

@@ -265,6 +265,32 @@ def test_split_step_tables(oracle):
         _check(oracle, g.gfa(), rd[:6], api.MODE_RECOMBINATION, oracle.M8_ABS, R=0, r=0.1, B=0.8)
 
 
+def test_random_dag_graphs(oracle):
+    """Graphs that are NOT blocks of alleles between shared segments: every path a random walk through segments in id order
+    (nested / overlapping bubbles, one-row segments, groups that are proper subsets of a row's paths, paths that part ways
+    after a shared segment).  Every pathwise mode against the oracle, and the step-table switches (`no_split`,
+    `no_gather`) and the i32 sweep against the default: byte-identical."""
+    from recgraph_amd import api, synth
+    for nseg, P, seed, kw in ((70, 3, 201, {}), (120, 9, 202, {"max_jump": 3}), (160, 24, 203, {"max_seg": 6}), (90, 40, 204, {"max_jump": 6, "max_seg": 14}),
+                              (200, 6, 205, {"max_jump": 2, "max_seg": 3}), (60, 64, 206, {"similar": 0.8})):
+        g = synth.random_dag_graph(nseg, P, seed=seed, **kw)
+        plen = min(len(g.path_sequence(k)) for k in range(P))
+        rd = synth.haplotype_reads(g, 10, length=plen, seed=seed + 1, mosaic_frac=0.6) + [g.path_sequence(P - 1), g.path_sequence(0)[:plen // 2], "ACGT" * 5]
+        gg = api.Graph.from_gfa_text(g.gfa())
+        names = ["r%d" % i for i in range(len(rd))]
+        for mode, om in ((api.MODE_PATHWISE, oracle.M4_ABS), (api.MODE_RECOMBINATION, oracle.M8_ABS),
+                         (api.MODE_PATHWISE_SEMI, oracle.M5_ABS), (api.MODE_RECOMBINATION_SEMI, oracle.M9_ABS)):
+            base = _check(oracle, g.gfa(), rd, mode, om)
+            for opt in ("no_split", "no_gather", "sweep_i32"):
+                try:
+                    api.set_option(opt, 1)
+                    texts, _ = api.align_batch(gg, rd, names, mode=mode)
+                finally:
+                    api.set_option(opt, 0)
+                assert texts == base, (nseg, P, mode, opt)
+        _check(oracle, g.gfa(), rd[:5], api.MODE_RECOMBINATION, oracle.M8_ABS, R=0, r=0.1, B=0.8)
+
+
 def test_three_sweep_pipeline(oracle):
     """The -m 8 / -m 9 pipeline the driver takes when a gap entry is positive (no path-0 lower bound for the forward
     thresholds: forward column maxima first, reverse sweep, forward again) or on request (RG_THREE_SWEEPS), with the
