@@ -203,6 +203,25 @@ def test_literal_and_absolute_restatements_agree(oracle):
                 assert b == g.align(oracle.M8_ABS, rd, **kw)[0]
 
 
+def test_restatements_agree_on_random_walk_graphs(oracle):
+    """The same pin on graphs that are not allele blocks (`synth.random_dag_graph`: nested / overlapping bubbles, paths
+    that part ways after a shared segment): the GPU parity tests on such graphs compare with the absolute forms."""
+    from recgraph_amd import synth
+    for seed, nseg, P, kw in ((1, 12, 3, {}), (2, 16, 5, {"max_jump": 3}), (3, 10, 4, {"max_seg": 4, "similar": 0.8}), (4, 20, 2, {"max_jump": 6})):
+        sg = synth.random_dag_graph(nseg, P, seed=400 + seed, **kw)
+        g = oracle.Graph.from_gfa_text(sg.gfa())
+        n = min(len(sg.path_sequence(k)) for k in range(P))
+        reads = synth.haplotype_reads(sg, 4, length=max(4, min(n, 40)), seed=seed, mosaic_frac=0.6) + ["ACGT", sg.path_sequence(P - 1)[:40]]
+        for rd in reads:
+            assert g.align(oracle.M4, rd)[0] == g.align(oracle.M4_ABS, rd)[0]
+            assert g.align(oracle.M5, rd[:len(rd) * 2 // 3 + 1])[0] == g.align(oracle.M5_ABS, rd[:len(rd) * 2 // 3 + 1])[0]
+            for kw2 in ({}, {"R": 2, "r": 0.7, "B": 0.5}):
+                b = g.align(oracle.M8, rd, **kw2)[0]
+                assert b == g.align(oracle.M8_PRUNED, rd, **kw2)[0]
+                assert b == g.align(oracle.M8_ABS, rd, **kw2)[0]
+                assert g.align(oracle.M9_PRUNED, rd, **kw2)[0] == g.align(oracle.M9_ABS, rd, **kw2)[0]
+
+
 def test_semiglobal_restatements_agree(oracle):
     """-m 5 / -m 9: literal vs absolute-form restatement, unpruned vs pruned search."""
     from recgraph_amd import synth
