@@ -92,3 +92,23 @@ def test_renumbered_shuffled_graphs_match_the_oracle(rg, oracle):
             for which in (0, 1, 2, 3, 4, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19):
                 assert g.dump(which) == og.dump(which), which
             assert g.dump(0) == api.Graph.from_gfa_text(sg.gfa()).dump(0)     # same linearisation as the tidy numbering
+
+
+def test_random_walk_graphs_are_well_formed():
+    """`synth.random_dag_graph` (the non-block topologies of the GPU parity tests and the fuzz campaign): ids 1..S in
+    topological order, every segment on a path, every path from segment 1 to segment S in ascending id order, links =
+    the consecutive pairs of the paths; the library takes the GFA with all its paths."""
+    from recgraph_amd import api, synth
+    for seed, nseg, P, kw in ((1, 30, 4, {}), (2, 80, 17, {"max_jump": 6}), (3, 12, 64, {"max_seg": 2}), (4, 50, 1, {})):
+        g = synth.random_dag_graph(nseg, P, seed=seed, **kw)
+        assert [i for i, _ in g.segments] == list(range(1, nseg + 1))
+        assert all(len(sq) >= 1 and set(sq) <= set("ACGT") for _, sq in g.segments)
+        used = set()
+        for p in g.paths:
+            assert p[0] == 1 and p[-1] == nseg and all(a < b for a, b in zip(p, p[1:]))
+            used.update(p)
+        assert used == set(range(1, nseg + 1))
+        assert set(g.links) == {(a, b) for p in g.paths for a, b in zip(p, p[1:])}
+        gg = api.Graph.from_gfa_text(g.gfa())
+        assert gg.paths_number == P and gg.path_error is None or gg.path_error == ""
+        assert gg.rows == g.rows
