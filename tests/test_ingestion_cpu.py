@@ -110,5 +110,5 @@ def test_random_walk_graphs_are_well_formed():
         assert used == set(range(1, nseg + 1))
         assert set(g.links) == {(a, b) for p in g.paths for a, b in zip(p, p[1:])}
         gg = api.Graph.from_gfa_text(g.gfa())
-        assert gg.paths_number == P and gg.path_error is None or gg.path_error == ""
+        assert gg.paths_number == P and not gg.path_error
         assert gg.rows == g.rows
