@@ -212,6 +212,12 @@ const char* rg_reads_bases(const rg_reads* r);            /* concatenated bases 
 const int64_t* rg_reads_offsets(const rg_reads* r);       /* count + 1 offsets into bases */
 const char* const* rg_reads_names(const rg_reads* r);     /* count NUL-terminated names */
 void rg_reads_destroy(rg_reads* r);
+/* The check of sequences.rs:41-43 without keeping anything: the reference parses the whole file (and panics with "wrong
+ * fasta file format" when the name and sequence counts differ) BEFORE it aligns the first read; a caller that streams
+ * a file through rg_stream_feed_fasta runs this over the same blocks ahead of its first output.  state4: four words,
+ * zero before the first piece.  Returns RG_ERR_ARG at the final piece of a text the reference refuses; *nreads_out:
+ * reads so far. */
+int32_t rg_fasta_check(const char* piece, int64_t len, int32_t final, int64_t* state4, int64_t* nreads_out);
 
 /*
  * Streaming engine: the reference's read loop (main.rs:56,174,257,297-312) as a pipeline hidden behind the boundary.
@@ -230,8 +236,17 @@ void rg_reads_destroy(rg_reads* r);
  *   rg_stream_next     blocks until the next tile (in input order) is done.  A tile whose device work failed returns
  *                      that error (rg_last_error has the text) and the stream moves on to the next tile
  *
- * seq_index of read i is seq_index_base + i (main.rs passes i + 1 in modes 0-3 and i in modes 4, 5, 8, 9; 0 means
- * "score only", global_abpoa.rs:241).  One thread at a time may call rg_stream_next on a stream.
+ * seq_index of read i is seq_index_base + i (main.rs passes i + 1 in modes 0-3, where 0 means "score only": no text,
+ * global_abpoa.rs:241; modes 4, 5, 8, 9 take no seq_name — main.rs:260,268,311 hand the 0-based i to write_gaf only —
+ * and every read gets its record whatever the index).  One thread at a time may call rg_stream_next on a stream.
+ *
+ * Memory: by default the stream holds whatever was pushed and not yet delivered (like the reference holds its whole
+ * `sequences` vector, main.rs:24).  For read sets that do not fit, bound it: `max_queued_tiles` makes rg_stream_push /
+ * rg_stream_feed_fasta wait while that many tiles sit in the queue, `max_undelivered_bytes` makes the workers wait
+ * before they start another tile while finished tiles that rg_stream_next has not taken yet hold more than that (the
+ * tile rg_stream_next is waiting for is always started: no deadlock), rg_stream_feed_fasta takes the FASTA text in
+ * pieces, and rg_stream_release returns a kept record handle early.  With a bound the pushing and the consuming side
+ * must be different threads, or one thread that drains with rg_stream_next whenever rg_stream_pending says so.
  */
 typedef struct rg_stream rg_stream;
 typedef struct rg_stream_opts {
@@ -243,8 +258,16 @@ typedef struct rg_stream_opts {
     int32_t no_text;              /* 1: skip the GAF text (records only)                                       */
     int32_t spin_wait;            /* 0: the long waits for the device (one per kernel pipeline) poll an event with short
                                      sleeps — every HIP wait spins a CPU by default, 3 threads per GPU here, which a
-                                     node under a CPU quota cannot afford; 1: hipStreamSynchronize (process-wide, same
-                                     as rg_set_option("spin_wait", 1))                                          */
+                                     node under a CPU quota cannot afford; 1: hipStreamSynchronize for the handles of
+                                     THIS stream (rg_set_option("spin_wait", 1) is the process-wide switch)      */
+    int32_t max_queued_tiles;     /* > 0: pushes wait while this many tiles are queued (not yet taken by a handle) */
+    int32_t amb_strand;           /* 1: `-s true` (main.rs:82-106, 132-165, 188-212, 229-253; POA modes, ignored in the
+                                     others like main.rs:254-313 ignores it): the reads that qualify (global modes: score
+                                     < 0; local modes: all) are aligned again, reverse-complemented, on a second handle of
+                                     the same worker (scalar exec + reversed handle labels as in the reference), the
+                                     reference's per-mode comparison picks the record, and the warning lines of both
+                                     exec calls come before it.  Not together with keep_records.                */
+    int64_t max_undelivered_bytes;/* > 0: see "Memory" above                                                     */
 } rg_stream_opts;
 typedef struct rg_stream_result {
     int64_t first_read;           /* index (push order) of the tile's first read                               */
@@ -258,7 +281,7 @@ typedef struct rg_stream_result {
     int32_t reserved;
     uint64_t cell_updates;        /* DP cell updates of the tile (SURVEY 8d unit of work)                       */
     rg_batch* records;            /* keep_records: results-only handle for the rg_result_* accessors, owned by the
-                                     stream (valid until rg_stream_destroy), else NULL                         */
+                                     stream (valid until rg_stream_release / rg_stream_destroy), else NULL      */
 } rg_stream_result;
 #define RG_STREAM_END 1
 void rg_stream_opts_default(rg_stream_opts* o);
@@ -270,6 +293,15 @@ int32_t rg_stream_push(rg_stream* s, const char* reads, const int64_t* read_off,
  * differ at its end returns RG_ERR_ARG ("wrong fasta file format", sequences.rs:41-43) AFTER the complete reads before
  * that point were pushed: the caller drops the stream. */
 int32_t rg_stream_push_fasta(rg_stream* s, const char* fasta_text, int64_t len, int64_t* nreads_out);
+/* The same for a text that arrives in pieces (a file read block by block: the reference's BufReader, sequences.rs:7):
+ * any split is fine, even inside a line; what a piece leaves unfinished stays inside the stream.  final != 0 closes the
+ * text (the name / sequence count check happens there).  *nreads_out: reads completed and pushed by THIS call.  One
+ * FASTA text per stream at a time; rg_stream_push_fasta is feed(text, final = 1). */
+int32_t rg_stream_feed_fasta(rg_stream* s, const char* piece, int64_t len, int32_t final, int64_t* nreads_out);
+/* Tiles pushed and not yet delivered by rg_stream_next (queued + on a device + finished). */
+int64_t rg_stream_pending(rg_stream* s);
+/* keep_records: gives a tile's record handle back before rg_stream_destroy (the handle is freed). */
+void rg_stream_release(rg_stream* s, rg_batch* records);
 int32_t rg_stream_finish(rg_stream* s);
 /* RG_OK: *out describes the next tile (pointers valid until the next rg_stream_next / rg_stream_destroy on this stream);
  * RG_STREAM_END: finished and everything delivered; negative: that tile failed. */

@@ -23,7 +23,8 @@ class GafFields(C.Structure):
 
 class StreamOpts(C.Structure):
     _fields_ = [("handles_per_device", C.c_int32), ("tile_reads", C.c_int32), ("format_threads", C.c_int32),
-                ("keep_records", C.c_int32), ("seq_index_base", C.c_int64), ("no_text", C.c_int32), ("spin_wait", C.c_int32)]
+                ("keep_records", C.c_int32), ("seq_index_base", C.c_int64), ("no_text", C.c_int32), ("spin_wait", C.c_int32),
+                ("max_queued_tiles", C.c_int32), ("amb_strand", C.c_int32), ("max_undelivered_bytes", C.c_int64)]
 
 
 class StreamResult(C.Structure):
@@ -60,8 +61,9 @@ SYMBOLS = ["rg_params_default", "rg_scores_match_mis", "rg_graph_from_gfa", "rg_
            "rg_batch_kernel_name", "rg_batch_kernel_ms", "rg_batch_kernel_launches", "rg_align_batch", "rg_align_batch_multi", "rg_multi_shards", "rg_multi_batch", "rg_multi_shard_begin",
            "rg_multi_format_all", "rg_multi_destroy", "rg_last_error",
            "rg_device_count", "rg_set_device",
-           "rg_reads_from_fasta", "rg_reads_count", "rg_reads_bases", "rg_reads_offsets", "rg_reads_names", "rg_reads_destroy",
-           "rg_stream_opts_default", "rg_stream_create", "rg_stream_push", "rg_stream_push_fasta", "rg_stream_finish", "rg_stream_next",
+           "rg_reads_from_fasta", "rg_reads_count", "rg_reads_bases", "rg_reads_offsets", "rg_reads_names", "rg_reads_destroy", "rg_fasta_check",
+           "rg_stream_opts_default", "rg_stream_create", "rg_stream_push", "rg_stream_push_fasta", "rg_stream_feed_fasta", "rg_stream_pending",
+           "rg_stream_release", "rg_stream_finish", "rg_stream_next",
            "rg_stream_destroy", "rg_stream_kernel_count", "rg_stream_kernel_name", "rg_stream_kernel_ms",
            "rg_stream_kernel_launches", "rg_stream_tiles_done", "rg_stream_handles", "rg_set_option", "rg_get_option"]
 
@@ -138,10 +140,16 @@ def load():
     l.rg_reads_names.argtypes = [vp]
     l.rg_reads_names.restype = P(C.c_char_p)
     l.rg_reads_destroy.argtypes = [vp]
+    l.rg_fasta_check.argtypes = [C.c_char_p, i64, i32, P(i64), P(i64)]
     l.rg_stream_opts_default.argtypes = [P(StreamOpts)]
     l.rg_stream_create.argtypes = [vp, P(Params), P(i32), i32, P(StreamOpts), P(vp)]
     l.rg_stream_push.argtypes = [vp, vp, P(i64), i64, P(C.c_char_p)]
     l.rg_stream_push_fasta.argtypes = [vp, C.c_char_p, i64, P(i64)]
+    l.rg_stream_feed_fasta.argtypes = [vp, C.c_char_p, i64, i32, P(i64)]
+    l.rg_stream_pending.argtypes = [vp]
+    l.rg_stream_pending.restype = i64
+    l.rg_stream_release.argtypes = [vp, vp]
+    l.rg_stream_release.restype = None
     l.rg_stream_finish.argtypes = [vp]
     l.rg_stream_next.argtypes = [vp, P(StreamResult)]
     l.rg_stream_destroy.argtypes = [vp]

@@ -457,6 +457,20 @@ class Reads:
         return [blob[off[i]:off[i + 1]].decode() for i in range(self.n)]
 
 
+def fasta_check(path, block=8 << 20):
+    """rg_fasta_check over a file, block by block: the number of reads, or RecGraphError("wrong fasta file format") where
+    the reference panics (sequences.rs:41-43).  Holds one block."""
+    lib = _lib.load()
+    st = (C.c_int64 * 4)()
+    n = C.c_int64(0)
+    with open(path, "rb") as f:
+        while True:
+            b = f.read(block)
+            check(lib.rg_fasta_check(b, len(b), int(not b), st, C.byref(n)))
+            if not b:
+                return n.value
+
+
 class StreamTile:
     """One rg_stream_result, copied out of the library's buffers."""
     __slots__ = ("first", "n", "text", "text_off", "status", "score", "device", "cell_updates", "records")
@@ -470,13 +484,18 @@ class Stream:
     reads pulled by ``handles_per_device`` batch handles per device from one queue, results in input order."""
 
     def __init__(self, graph, params, device_ids=None, handles_per_device=0, tile_reads=0, format_threads=0,
-                 seq_index_base=1, keep_records=False, no_text=False, spin_wait=False):
+                 seq_index_base=1, keep_records=False, no_text=False, spin_wait=False, max_queued_tiles=0,
+                 max_undelivered_bytes=0, amb_strand=False):
+        """``amb_strand``: ``-s true`` inside the workers (POA modes).  ``max_queued_tiles`` / ``max_undelivered_bytes``:
+        bounds on what the stream holds (pushes / workers wait): the pushing and the consuming side must then be
+        different threads, or one thread that drains whenever ``pending`` says so."""
         lib = _lib.load()
         self.graph = graph
         o = _lib.StreamOpts()
         lib.rg_stream_opts_default(C.byref(o))
         o.handles_per_device, o.tile_reads, o.format_threads = handles_per_device, tile_reads, format_threads
         o.seq_index_base, o.keep_records, o.no_text, o.spin_wait = seq_index_base, int(keep_records), int(no_text), int(spin_wait)
+        o.max_queued_tiles, o.max_undelivered_bytes, o.amb_strand = max_queued_tiles, max_undelivered_bytes, int(amb_strand)
         devs = (C.c_int32 * len(device_ids))(*device_ids) if device_ids is not None else None
         self._h = C.c_void_p()
         check(lib.rg_stream_create(graph._h, C.byref(params), devs, len(device_ids) if device_ids is not None else 0,
@@ -512,6 +531,24 @@ class Stream:
         n = C.c_int64(0)
         check(_lib.load().rg_stream_push_fasta(self._h, text, len(text), C.byref(n)))
         return n.value
+
+    def feed_fasta(self, piece, final=False):
+        """rg_stream_feed_fasta: the FASTA text in pieces (any split); ``final`` closes it.  Returns the reads completed
+        and pushed by this call."""
+        n = C.c_int64(0)
+        check(_lib.load().rg_stream_feed_fasta(self._h, piece, len(piece), int(final), C.byref(n)))
+        return n.value
+
+    @property
+    def pending(self):
+        """Tiles pushed and not yet delivered."""
+        return _lib.load().rg_stream_pending(self._h)
+
+    def release(self, tile):
+        """keep_records: gives the tile's record handle back (rg_stream_release)."""
+        if tile.records:
+            _lib.load().rg_stream_release(self._h, tile.records)
+            tile.records = None
 
     def finish(self):
         check(_lib.load().rg_stream_finish(self._h))
@@ -556,11 +593,11 @@ def set_option(name, value):
 
 
 def align_stream(graph, reads, names=None, mode=MODE_GLOBAL_POA, seq_index_base=1, device_ids=None, handles_per_device=0,
-                 tile_reads=0, **kw):
+                 tile_reads=0, amb_strand=False, **kw):
     """``align_batch`` through the streaming engine (every visible GPU unless ``device_ids`` says otherwise): returns the
-    per-read texts and status bits in input order.  No ``-s`` retry."""
+    per-read texts and status bits in input order.  ``amb_strand``: the ``-s true`` retry inside the library."""
     st = Stream(graph, make_params(mode, **kw), device_ids=device_ids, handles_per_device=handles_per_device,
-                tile_reads=tile_reads, seq_index_base=seq_index_base)
+                tile_reads=tile_reads, seq_index_base=seq_index_base, amb_strand=amb_strand)
     st.push(reads, names)
     st.finish()
     texts, status = [], []

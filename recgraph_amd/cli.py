@@ -60,6 +60,8 @@ def build_parser():
     p.add_argument("--devices", default="", help="comma-separated HIP device ids (default: every visible device)")
     p.add_argument("--handles", type=int, default=0, help="batch handles per device (default 3)")
     p.add_argument("--tile", type=int, default=0, help="reads per tile (default 4096 pathwise / 8192 POA)")
+    p.add_argument("--queue", type=int, default=4, help="tiles that may wait in the stream's queue before the file reader waits (0: unbounded)")
+    p.add_argument("--hold-mb", type=int, default=64, dest="hold_mb", help="MB of finished GAF text the stream may hold before its workers wait (0: unbounded)")
     p.add_argument("--timing", action="store_true", help="phase timings as one JSON line on stderr")
     return p
 
@@ -81,15 +83,6 @@ def main(argv=None):
         scores = api.create_score_matrix_i32(a.match_score, -a.mismatch_score)   # args_parser.rs:155
     else:
         scores = api.create_score_matrix_i32(matrix_file_path=a.matrix if a.matrix.endswith(".mtx") else a.matrix + ".mtx")
-    with open(a.sequence_path, "rb") as f:
-        fasta = f.read()
-    tp = mark("fasta_read", tp)
-
-    def parse_reads():
-        try:
-            return api.Reads.from_fasta_text(fasta)          # sequences.rs:5-45 inside the library
-        except api._lib.RecGraphError as ex:
-            raise SystemExit(str(ex).split(": ", 1)[-1])     # "wrong fasta file format" (:41-43)
     g = api.Graph.from_gfa(a.graph_path)
     tp = mark("graph", tp)
     mode = {0: api.MODE_GLOBAL_POA_SCALAR if a.scalar else api.MODE_GLOBAL_POA, 2: api.MODE_GAP_POA,
@@ -99,13 +92,15 @@ def main(argv=None):
     kw = dict(score_matrix=scores, o=-a.gap_open, e=-a.gap_extension, b=float(a.extra_b), f=a.extra_f,
               R=a.base_rec_cost, r=a.multi_rec_cost, B=a.rec_band_width)
     to_file = a.out_file != "standard output"
-    records, numbers = [], []
 
     def emit(first, texts):
-        """texts: the stdout text of consecutive reads starting at read `first`."""
+        """texts: the stdout text of consecutive reads starting at read `first`.  With -o the records of the tile go
+        through write_gaf's create / append rule right away: what precedes a read the reference panics on is in the
+        file, as it would be after the reference's own per-read loop."""
         if not to_file:
             sys.stdout.write("".join(texts))
             return
+        records, numbers = [], []
         # warning lines are println!'d by the exec functions whatever -o says; only the record goes through write_gaf
         for k, t in enumerate(texts):
             lines = t.split("\n")[:-1]
@@ -114,46 +109,73 @@ def main(argv=None):
             # main.rs passes i + 1 in modes 0-3 (:98-103, :161-166, :206-211, :246-251) and the 0-based i in modes
             # 4, 5, 8, 9 (:260, :268, :311)
             numbers.append(first + k + 1 if a.alignment_mode in (0, 1, 2, 3) else first + k)
-
-    def panics(first, status, names):
-        bad = [i for i, st in enumerate(status) if st & (api.READ_WOULD_PANIC | api.READ_BAD_BASE)]
-        if bad:
-            raise SystemExit("read %d (%s): the reference panics on this input" % (first + bad[0], names[first + bad[0]]))
-
-    if amb:
-        reads = parse_reads()
-        names = reads.names
-        texts, status = api.align_batch(g, reads.sequences(), names, mode=mode, amb_strand=True, **kw)
-        panics(0, status, names)
-        emit(0, texts)
-    else:
-        # the reference's read loop (main.rs:56,174,257,297) has no order dependence: the streaming engine cuts the reads
-        # into tiles that the batch handles of every visible GPU (or --devices) pull from one queue; text in input order
-        devs = [int(x) for x in a.devices.split(",")] if a.devices else None
-        st = api.Stream(g, api.make_params(mode, **kw), device_ids=devs, handles_per_device=a.handles, tile_reads=a.tile)
-        tp = mark("stream_create", tp)
-        try:
-            st.push_fasta(fasta)       # parsed inside the library; tiles start on the devices while the rest is parsed
-        except api._lib.RecGraphError as ex:
-            raise SystemExit(str(ex).split(": ", 1)[-1])
-        st.finish()
-        tp = mark("parse_and_push", tp)
-        for t in st:
-            if "first_tile" not in phases:
-                mark("first_tile", tp)
-            if (t.status & (api.READ_WOULD_PANIC | api.READ_BAD_BASE)).any():
-                panics(0, [0] * t.first + [int(x) for x in t.status], parse_reads().names)
-            if to_file:
-                emit(t.first, [t.text_of(i).decode() for i in range(t.n)])
-            else:
-                sys.stdout.buffer.write(t.text)
-        tp = mark("all_tiles", tp)
-        phases["kernels_ms"] = {k: round(v[0], 1) for k, v in st.kernel_stats().items()}
-        st.close()
-        tp = mark("stream_close", tp)
-    sys.stdout.flush()
-    if to_file:
         write_gaf_records(a.out_file, records, numbers)
+
+    # The reference's read loop (main.rs:56,174,257,297) has no order dependence: the streaming engine cuts the reads into
+    # tiles that the batch handles of every visible GPU (or --devices) pull from one queue; text in input order.  Like that
+    # loop the process holds a bounded part of the read set: a feeder thread hands the file over block by block
+    # (sequences.rs:5-45 runs inside the library), pushes wait while --queue tiles are queued, the workers wait while
+    # more than --hold-mb of finished text has not been taken.  `-s true` (modes 0-3) is the stream's amb_strand option.
+    import threading
+    devs = [int(x) for x in a.devices.split(",")] if a.devices else None
+    st = api.Stream(g, api.make_params(mode, **kw), device_ids=devs, handles_per_device=a.handles, tile_reads=a.tile,
+                    amb_strand=amb, max_queued_tiles=a.queue, max_undelivered_bytes=a.hold_mb << 20)
+    tp = mark("stream_create", tp)
+    feed_err = []
+
+    def feeder():
+        try:
+            with open(a.sequence_path, "rb") as f:
+                while True:
+                    block = f.read(4 << 20)
+                    st.feed_fasta(block, final=not block)
+                    if not block:
+                        break
+        except Exception as ex:                  # "wrong fasta file format" (sequences.rs:41-43), or a missing file
+            feed_err.append(ex)
+        finally:
+            st.finish()
+    th = threading.Thread(target=feeder, daemon=True)
+    th.start()
+    # The reference parses the whole file before it aligns the first read and panics on a malformed one (sequences.rs:41-43):
+    # a scan of the file (counts only, memory speed) runs beside the first tiles, and nothing is written before it is done.
+    scan = {}
+
+    def scanner():
+        try:
+            scan["n"] = api.fasta_check(a.sequence_path)
+        except Exception as ex:
+            scan["err"] = ex
+    sc = threading.Thread(target=scanner, daemon=True)
+    sc.start()
+    for t in st:
+        if "first_tile" not in phases:
+            mark("first_tile", tp)
+            sc.join()
+            if "err" in scan:
+                ex = scan["err"]
+                raise SystemExit(str(ex).split(": ", 1)[-1] if isinstance(ex, api._lib.RecGraphError) else str(ex))
+        bad = (t.status & (api.READ_WOULD_PANIC | api.READ_BAD_BASE)).nonzero()[0]
+        n_ok = int(bad[0]) if len(bad) else t.n
+        if n_ok == t.n and not to_file:
+            sys.stdout.buffer.write(t.text)
+        else:
+            emit(t.first, [t.text_of(i).decode() for i in range(n_ok)])
+        if len(bad):
+            sys.stdout.flush()
+            raise SystemExit("read %d: the reference panics on this input" % (t.first + n_ok))
+    th.join()
+    sc.join()
+    if "err" in scan:        # (a file without a single complete read: no tile ever came)
+        feed_err.insert(0, scan["err"])
+    if feed_err:
+        ex = feed_err[0]
+        raise SystemExit(str(ex).split(": ", 1)[-1] if isinstance(ex, api._lib.RecGraphError) else str(ex))
+    tp = mark("all_tiles", tp)
+    phases["kernels_ms"] = {k: round(v[0], 1) for k, v in st.kernel_stats().items()}
+    st.close()
+    tp = mark("stream_close", tp)
+    sys.stdout.flush()
     if a.timing:
         import json
         phases["total"] = round(time.time() - t0, 3)

@@ -47,9 +47,9 @@ Options& options() {
     return o;
 }
 
-int wait_stream_sleeping(void* stream, void* ev) {
+int wait_stream_sleeping(void* stream, void* ev, bool spin) {
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (options().spin_wait || !ev) return (int)hipStreamSynchronize(s);
+    if (spin || options().spin_wait || !ev) return (int)hipStreamSynchronize(s);
     hipEvent_t e = static_cast<hipEvent_t>(ev);
     hipError_t rc = hipEventRecord(e, s);
     if (rc != hipSuccess) return (int)rc;
@@ -93,7 +93,7 @@ struct Timed {
     }
     int collect() {
         if (!b->done_ev) HIPCHK(hipEventCreateWithFlags(&b->done_ev, hipEventDisableTiming));
-        HIPCHK((hipError_t)wait_stream_sleeping(b->stream, b->done_ev));
+        HIPCHK((hipError_t)wait_stream_sleeping(b->stream, b->done_ev, b->spin_wait));
         for (auto& pe : pending) {
             float ms = 0;
             HIPCHK(hipEventElapsedTime(&ms, b->ev_pool[pe.second].first, b->ev_pool[pe.second].second));
@@ -237,10 +237,30 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
 extern "C" {
 static bool build_fields(const rg_batch* b, int64_t i, const char* name, GafFields& out);
 }
-static void append_gaf(const rg_batch* b, int64_t i, const char* name, int64_t seq_index, std::string& out) {
+bool amb_take_rev(int mode, int32_t fwd_score, int32_t rev_score) {
+    if (mode == RG_MODE_LOCAL_POA || mode == RG_MODE_LOCAL_POA_SCALAR) return !(fwd_score < rev_score);   // main.rs:160-164 (sic)
+    return rev_score > fwd_score;
+}
+static void append_gaf(const rg_batch* b, int64_t i, const char* name, int64_t seq_index, std::string& out, const AmbRetry* amb = nullptr) {
     const DevRecord& d = b->rec[i];
     GafFields f;
-    if (seq_index != 0 && build_fields(b, i, name, f)) out += f.text();
+    // seq_name.1 == 0 means "score only" in the POA modes alone (global_abpoa.rs:241, :411; gap_global_abpoa.rs:229;
+    // local_poa.rs / gap_local_poa.rs likewise).  The pathwise modes take no seq_name: main.rs:260,268,311 hand `i` to
+    // write_gaf only, and read 0 gets its record like every other read.
+    const bool score_only = seq_index == 0 && is_poa(b->p.mode);
+    const int64_t k = amb && amb->rb && amb->rev_index ? amb->rev_index[i] : -1;
+    if (k >= 0 && !score_only && !(amb->rb->rec[(size_t)k].status & (ST_BAD_BASE | ST_WOULD_PANIC))) {
+        // both exec calls print their warning lines while they run; write_gaf then prints the record the comparison picks
+        GafFields r;
+        if (build_fields(b, i, name, f) && build_fields(amb->rb, k, name, r)) {
+            out += f.pre;
+            out += r.pre;
+            out += amb_take_rev(b->p.mode, d.score, amb->rb->rec[(size_t)k].score) ? r.line() : f.line();
+            out += '\n';
+            return;
+        }
+    }
+    if (!score_only && build_fields(b, i, name, f)) out += f.text();
     else if ((d.status & (ST_BAD_BASE | ST_WOULD_PANIC)) == 0 && (d.status & ST_BAND_WARNING))
         out += "Band length probably too short, maybe try with larger b and f\n";
 }
@@ -249,7 +269,7 @@ static void append_gaf(const rg_batch* b, int64_t i, const char* name, int64_t s
 // thread, concatenated).  Name of read i: names[i], or "read<name_base + i>".  offs (optional): nreads + 1 offsets of the
 // reads' texts inside `out`.
 void format_batch(const rg_batch* b, const char* const* names, int64_t name_base, int64_t seq_index_base, int nthreads,
-                  std::string& out, std::vector<int64_t>* offs) {
+                  std::string& out, std::vector<int64_t>* offs, const AmbRetry* amb) {
     const int64_t n = b->nreads;
     if (nthreads < 1) nthreads = 1;
     if (nthreads > n) nthreads = (int)std::max<int64_t>(1, n);
@@ -265,7 +285,7 @@ void format_batch(const rg_batch* b, const char* const* names, int64_t name_base
             const char* name;
             if (names) name = names[i];
             else { nm = "read" + std::to_string(name_base + i); name = nm.c_str(); }
-            append_gaf(b, i, name, seq_index_base + i, o);
+            append_gaf(b, i, name, seq_index_base + i, o, amb);
             lens[(size_t)i] = (int64_t)(o.size() - before);
         }
     };
@@ -680,6 +700,7 @@ int rg_run_pathwise(rg_batch* b) {
     std::vector<std::pair<std::string, std::pair<double, long long>>> st;
     // what this handle already holds counts towards its share of the device
     unsigned long long c = 0;
+    b->pw.spin_wait = b->spin_wait;
     int rc = path_driver_run(h, gd, b->p, b->pw, b->in.reads, b->in.off, b->in.bad, (int)b->nreads, b->max_n, b->d_rec.p,
                              b->d_ops.p, b->ops_stride, b->d_cells.p, b->stream, b->mem_budget, &c, st, true);
     b->stats.clear();

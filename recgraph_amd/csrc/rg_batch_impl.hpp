@@ -189,6 +189,7 @@ struct rg_batch {
     int dev = 0;                       // device the handle was created on (graph tables are bound to it too); -1: a
                                        // results-only handle detached from a stream tile (no device buffers, no stream)
     bool valid = false;                // reads loaded and every per-read buffer sized (false after a failed set_reads)
+    bool spin_wait = false;            // long waits for the device spin (hipStreamSynchronize) instead of sleep-polling
     size_t mem_budget = 0;             // bytes of HBM the work buffers of one run may take (0: a share of what is free);
                                        // set by the streaming engine: free memory of the device / handles on it
     std::vector<uint8_t> codes_own;    // results-only handle: its own copy of the base codes (`codes` points here)
@@ -228,5 +229,13 @@ struct rg_batch {
 // ---- internals shared with the streaming engine (rg_stream.hip) ----
 void rg_batch_destroy_impl(rg_batch* b);
 rg_batch* rg_batch_detach_results(rg_batch* b);
+// `-s true` (main.rs:82-106, 132-165, 188-212, 229-253): the second batch (reverse complements of the reads that
+// qualified, aligned with the reversed handle labels) and, per read of the forward batch, its index there (-1: none)
+struct AmbRetry {
+    const rg_batch* rb = nullptr;
+    const int64_t* rev_index = nullptr;
+};
+// true: the reference writes the reverse-complement record (main.rs:98-102, 206-210: rev > fwd; local_poa :160-164: unless fwd < rev)
+bool amb_take_rev(int mode, int32_t fwd_score, int32_t rev_score);
 void format_batch(const rg_batch* b, const char* const* names, int64_t name_base, int64_t seq_index_base, int nthreads,
-                  std::string& out, std::vector<int64_t>* offs);
+                  std::string& out, std::vector<int64_t>* offs, const AmbRetry* amb = nullptr);

@@ -6,6 +6,7 @@
 #pragma once
 #include <atomic>
 #include <cstdint>
+#include <deque>
 #include <functional>
 #include <string>
 #include <vector>
@@ -39,7 +40,7 @@ Options& options();
 // events included: tools/probes/wait_probe.hip) — three such threads per GPU on a node under a CPU quota starve everything
 // else — and the runtime's own blocking mode (hipDeviceScheduleBlockingSync) deadlocked here when two threads sat in
 // hipFree's implicit device synchronisation at once (profiles/r03_notes.md).  Returns a hipError_t as int.
-int wait_stream_sleeping(void* stream, void* ev);
+int wait_stream_sleeping(void* stream, void* ev, bool spin = false);   // spin: this handle asked for hipStreamSynchronize (rg_stream_opts.spin_wait)
 
 int fail(int code, const std::string& msg);
 
@@ -161,6 +162,20 @@ struct FastaReads {
     std::vector<std::string> names;
 };
 bool parse_fasta(const char* text, int64_t len, FastaReads& r, int64_t batch, const std::function<void(int64_t, int64_t)>& emit);
+// sequences::get_sequences over a text that arrives in pieces (rg_stream_feed_fasta): see rg_reads.cpp
+struct FastaFeeder {
+    std::string carry;                       // unterminated last line of the pieces so far
+    std::string cur;                         // bases of the sequence being collected
+    std::deque<std::string> names, seqs;     // closed, not yet paired by index
+    int64_t names_total = 0, seqs_total = 0;
+    // complete reads are APPENDED to out (bases / off / names); final: the text ends with this piece
+    void feed(const char* text, int64_t len, bool final, FastaReads& out);
+    bool balanced() const { return names_total == seqs_total; }    // after the final piece: false = "wrong fasta file format"
+private:
+    void line(const char* p, const char* q, FastaReads& out);
+    void pair_up(FastaReads& out);
+};
+void fasta_count(const char* text, int64_t len, bool final, int64_t st[4]);
 int64_t canonicalise_reads(const char* reads, const int64_t* read_off, int64_t nreads, uint8_t* codes, uint8_t* bad);
 std::string f32_display(float v);
 

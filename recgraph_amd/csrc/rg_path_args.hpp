@@ -38,6 +38,7 @@ struct PathGraphDev {
 struct PathWorkImpl;
 struct PathWork {
     PathWorkImpl* impl = nullptr;
+    bool spin_wait = false;     // the owning handle waits for the device with hipStreamSynchronize (rg_stream_opts.spin_wait)
     ~PathWork();
 };
 

@@ -85,6 +85,7 @@ namespace {
 struct Timer {
     PathWorkImpl* w;
     hipStream_t s;
+    bool spin = false;
     size_t used = 0;
     struct Pend { std::string name; size_t e0, e1; };
     std::vector<Pend> pend;
@@ -106,7 +107,7 @@ struct Timer {
     }
     int collect(std::vector<std::pair<std::string, std::pair<double, long long>>>& stats) {
         if (!w->done_ev) HIPCHK(hipEventCreateWithFlags(&w->done_ev, hipEventDisableTiming));
-        HIPCHK((hipError_t)wait_stream_sleeping(s, w->done_ev));
+        HIPCHK((hipError_t)wait_stream_sleeping(s, w->done_ev, spin));
         for (auto& p : pend) {
             float ms = 0;
             HIPCHK(hipEventElapsedTime(&ms, w->ev[p.e0], w->ev[p.e1]));
@@ -405,36 +406,46 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
     const int recw = 4 + C;
     if (w.fcap == 0) { w.fcap = (two_sweep && !use_rec) ? 1u << 20 : 1u << 15; w.rcap = use_rec ? 1u << 16 : 1u << 19; w.frec_cap = 1u << 16; w.rrec_cap = 1u << 15; }   // (reverse records at config 5: mean 2.7 k, largest read of a 4096-read tile 21-25 k)
     stats.clear();
-    Timer T{&w, stream};
+    Timer T{&w, stream, pw.spin_wait};
     int done = 0;
     unsigned long long cells_done = 0;
+    int oom_shift = 0;      // the budget is halved every time a work-buffer allocation fails (other handles / the retry pass took the memory)
     while (done < nreads) {
         HIPCHK(hipMemsetAsync(d_cells, 0, sizeof(unsigned long long), stream));      // cell updates of this chunk attempt
         HIPCHK(hipMemsetAsync(w.need.p, 0, 8 * sizeof(unsigned), stream));
         const size_t per_read_all = per_read + (mode == RG_MODE_RECOMBINATION ? ((size_t)w.fcap * sizeof(Cand) + (size_t)w.rcap * (sizeof(Cand) + 4) +
                                                                                      (use_rec ? (size_t)(w.frec_cap + w.rrec_cap) * recw * 4 : 0)) : 0);
-        int maxchunk = (int)std::min<size_t>(8192, std::max<size_t>(1, budget / per_read_all));
+        int maxchunk = (int)std::min<size_t>(8192, std::max<size_t>(1, (budget >> oom_shift) / per_read_all));
         if (opt.chunk_reads > 0) maxchunk = std::min<int>(maxchunk, opt.chunk_reads);
         const double dbg_t0 = debug ? std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() : 0;
         const int left = nreads - done;
         const int nchunks = (left + maxchunk - 1) / maxchunk;
         int chunk = (left + nchunks - 1) / nchunks;   // even chunks: no short tail launch
-        if ((rc = w.state.alloc(chunk)) || (rc = w.fdirs.alloc((size_t)chunk * fdirs_stride)) ||
-            (rc = w.flayer.alloc((size_t)chunk * layer_stride)))
+        auto alloc_all = [&]() -> int {
+            int rc;
+            if ((rc = w.state.alloc(chunk)) || (rc = w.fdirs.alloc((size_t)chunk * fdirs_stride)) ||
+                (rc = w.flayer.alloc((size_t)chunk * layer_stride)))
+                return rc;
+            if ((rc = w.roll.alloc((size_t)chunk * P * wpad))) return rc;
+            if (mode == RG_MODE_RECOMBINATION) {
+                if ((rc = w.rdirs.alloc((size_t)chunk * rdirs_stride)) || (rc = w.rlayer.alloc((size_t)chunk * layer_stride)) ||
+                    (rc = w.mf.alloc((size_t)chunk * wpad)) || (rc = w.mfc.alloc((size_t)chunk * wpad)) || (rc = w.wr.alloc((size_t)chunk * wpad)) ||
+                    (rc = w.mfarg.alloc((size_t)chunk * wpad)) || (rc = w.wrarg.alloc((size_t)chunk * wpad)) ||
+                    (rc = w.thr.alloc((size_t)chunk * wpad)) || (rc = w.fcand.alloc((size_t)chunk * w.fcap)) ||
+                    (rc = w.rcand.alloc((size_t)chunk * w.rcap)) || (rc = w.ridx.alloc((size_t)chunk * w.rcap)) ||
+                    (rc = w.nf.alloc(chunk)) || (rc = w.nr.alloc(chunk)) || (rc = w.lb.alloc(chunk)) || (rc = w.nrec.alloc(chunk)))
+                    return rc;
+                if (spec && ((rc = w.pick.alloc(chunk)) || (rc = w.rt_flags.alloc(chunk)))) return rc;
+                if (use_rec && ((rc = w.frec.alloc((size_t)chunk * w.frec_cap * recw)) || (rc = w.rrec.alloc((size_t)chunk * w.rrec_cap * recw)) ||
+                                (rc = w.nrrec.alloc(chunk))))
+                    return rc;
+            }
+            return RG_OK;
+        };
+        if ((rc = alloc_all())) {
+            // out of memory (the share was measured before other buffers of the device existed): smaller launches, like run_poa
+            if (rc == RG_ERR_HIP && chunk > 1 && oom_shift < 12) { ++oom_shift; continue; }
             return rc;
-        if ((rc = w.roll.alloc((size_t)chunk * P * wpad))) return rc;
-        if (mode == RG_MODE_RECOMBINATION) {
-            if ((rc = w.rdirs.alloc((size_t)chunk * rdirs_stride)) || (rc = w.rlayer.alloc((size_t)chunk * layer_stride)) ||
-                (rc = w.mf.alloc((size_t)chunk * wpad)) || (rc = w.mfc.alloc((size_t)chunk * wpad)) || (rc = w.wr.alloc((size_t)chunk * wpad)) ||
-                (rc = w.mfarg.alloc((size_t)chunk * wpad)) || (rc = w.wrarg.alloc((size_t)chunk * wpad)) ||
-                (rc = w.thr.alloc((size_t)chunk * wpad)) || (rc = w.fcand.alloc((size_t)chunk * w.fcap)) ||
-                (rc = w.rcand.alloc((size_t)chunk * w.rcap)) || (rc = w.ridx.alloc((size_t)chunk * w.rcap)) ||
-                (rc = w.nf.alloc(chunk)) || (rc = w.nr.alloc(chunk)) || (rc = w.lb.alloc(chunk)) || (rc = w.nrec.alloc(chunk)))
-                return rc;
-            if (spec && ((rc = w.pick.alloc(chunk)) || (rc = w.rt_flags.alloc(chunk)))) return rc;
-            if (use_rec && ((rc = w.frec.alloc((size_t)chunk * w.frec_cap * recw)) || (rc = w.rrec.alloc((size_t)chunk * w.rrec_cap * recw)) ||
-                            (rc = w.nrrec.alloc(chunk))))
-                return rc;
         }
         const uint8_t* bad = d_bad + done;
         const long long* off = d_off + done;

@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cctype>
 #include <cstring>
+#include <deque>
 
 #include "rg_host.hpp"
 
@@ -48,6 +49,99 @@ bool parse_fasta(const char* text, int64_t len, FastaReads& r, int64_t batch, co
     return true;
 }
 
+
+// The same rules with the text arriving in pieces (any split, even inside a line or between '\r' and '\n'): what a piece
+// leaves unfinished — the unterminated last line, the sequence being collected, names / sequences that have no partner
+// yet — stays in the feeder, complete reads (sequence i closed AND name i seen: the reference pairs the two lists by
+// index) are appended to `out`.  Memory held is what the current piece completes, not the file.
+void FastaFeeder::line(const char* p, const char* q, FastaReads& out) {
+    if (q <= p) return;                                     // empty lines are skipped (sequences.rs:14)
+    if (*p == '>') {
+        names.emplace_back(p + 1, q);
+        ++names_total;
+        if (!cur.empty()) { seqs.push_back(std::move(cur)); cur.clear(); ++seqs_total; }
+    } else {
+        for (const char* c = p; c < q; ++c) {
+            const unsigned char ch = (unsigned char)*c;
+            cur.push_back(ch == '-' ? 'N' : (ch >= 'a' && ch <= 'z') ? (char)(ch - 32) : (char)ch);
+        }
+    }
+    pair_up(out);
+}
+
+void FastaFeeder::pair_up(FastaReads& out) {
+    if (out.off.empty()) out.off.push_back(0);
+    while (!names.empty() && !seqs.empty()) {
+        out.bases += seqs.front();
+        out.off.push_back((int64_t)out.bases.size());
+        out.names.push_back(std::move(names.front()));
+        names.pop_front();
+        seqs.pop_front();
+    }
+}
+
+void FastaFeeder::feed(const char* text, int64_t len, bool final, FastaReads& out) {
+    const char* p = text;
+    const char* end = text + len;
+    if (out.off.empty()) out.off.push_back(0);
+    while (p < end) {
+        const char* nl = (const char*)memchr(p, '\n', (size_t)(end - p));
+        if (!nl) { carry.append(p, end); break; }          // unterminated: wait for the rest of the line
+        if (!carry.empty()) {
+            carry.append(p, nl);
+            const char* b = carry.data();
+            const char* q = b + carry.size();
+            if (q > b && q[-1] == '\r') --q;                // BufRead::lines drops "\n" or "\r\n"
+            line(b, q, out);
+            carry.clear();
+        } else {
+            const char* q = nl;
+            if (q > p && q[-1] == '\r') --q;
+            line(p, q, out);
+        }
+        p = nl + 1;
+    }
+    if (final) {
+        if (!carry.empty()) { line(carry.data(), carry.data() + carry.size(), out); carry.clear(); }   // (a '\r' at the very end stays)
+        if (!cur.empty()) { seqs.push_back(std::move(cur)); cur.clear(); ++seqs_total; }
+        pair_up(out);
+    }
+}
+
+// What sequences::get_sequences would collect, counted without keeping it (the reference parses the whole file — and
+// panics on a name / sequence count mismatch, sequences.rs:41-43 — before it aligns anything; a caller that streams the
+// file runs this ahead of its output).  st: {names, sequences, current sequence non-empty, line state}; zero before the
+// first piece.  Line states: 0 at the start of a line, 1 inside a line, 2 after a '\r' that opened the line.
+void fasta_count(const char* text, int64_t len, bool final, int64_t st[4]) {
+    const char* p = text;
+    const char* end = text + len;
+    while (p < end) {
+        if (st[3] == 1) {                                   // the rest of the line decides nothing
+            const char* nl = (const char*)memchr(p, '\n', (size_t)(end - p));
+            if (!nl) return;
+            p = nl + 1;
+            st[3] = 0;
+            continue;
+        }
+        const char c = *p++;
+        if (st[3] == 2) {                                   // "\r\n" is an empty line; '\r' + anything else is content
+            if (c == '\n') { st[3] = 0; continue; }
+            st[2] = 1;
+            st[3] = 1;
+            continue;
+        }
+        if (c == '\n') continue;                            // empty line
+        if (c == '\r') { st[3] = 2; continue; }
+        if (c == '>') { ++st[0]; if (st[2]) { ++st[1]; st[2] = 0; } }
+        else st[2] = 1;
+        st[3] = 1;
+    }
+    if (final) {
+        if (st[3] == 2) st[2] = 1;                          // a '\r' at the very end stays: a one-character line
+        if (st[2]) { ++st[1]; st[2] = 0; }
+        st[3] = 0;
+    }
+}
 
 // Base codes of a read set: one table pass over the blob (canonical character: '-' -> 'N', upper case; code 0..4, a
 // character outside ACGTN marks its read `bad` and is stored as N).  Returns the longest read.

@@ -165,6 +165,10 @@ pub struct Tile {
 pub struct Stream {
     raw: *mut rg_stream,
 }
+// The C ABI lets one thread push / feed while another takes results (rg_stream_push: "any thread, any time"; one thread
+// at a time in rg_stream_next): the feeder thread of main_loop.rs shares the stream by reference.
+unsafe impl Send for Stream {}
+unsafe impl Sync for Stream {}
 
 impl Stream {
     /// `devices`: None = every visible GPU.
@@ -187,22 +191,43 @@ impl Stream {
     }
 
     /// FASTA text parsed inside the library, its reads pushed tile by tile while the rest is parsed.
-    pub fn push_fasta(&mut self, text: &[u8]) -> Result<usize, String> {
+    pub fn push_fasta(&self, text: &[u8]) -> Result<usize, String> {
         let mut n: i64 = 0;
         check(unsafe { rg_stream_push_fasta(self.raw, text.as_ptr() as *const c_char, text.len() as i64, &mut n) })?;
         Ok(n as usize)
     }
 
-    pub fn push(&mut self, reads: &Reads) -> Result<(), String> {
+    /// The same for a text that arrives in pieces (a file read block by block); `last` closes it.
+    pub fn feed_fasta(&self, piece: &[u8], last: bool) -> Result<usize, String> {
+        let mut n: i64 = 0;
+        check(unsafe { rg_stream_feed_fasta(self.raw, piece.as_ptr() as *const c_char, piece.len() as i64, last as i32, &mut n) })?;
+        Ok(n as usize)
+    }
+
+    /// Tiles pushed and not yet taken with `next`.
+    pub fn pending(&self) -> i64 {
+        unsafe { rg_stream_pending(self.raw) }
+    }
+
+    /// Options with the library's defaults (`rg_stream_opts_default`), for `Stream::new(.., Some(opts))`.
+    pub fn default_opts() -> rg_stream_opts {
+        let mut o = std::mem::MaybeUninit::<rg_stream_opts>::uninit();
+        unsafe {
+            rg_stream_opts_default(o.as_mut_ptr());
+            o.assume_init()
+        }
+    }
+
+    pub fn push(&self, reads: &Reads) -> Result<(), String> {
         check(unsafe { rg_stream_push(self.raw, rg_reads_bases(reads.raw), rg_reads_offsets(reads.raw), rg_reads_count(reads.raw), rg_reads_names(reads.raw)) })
     }
 
-    pub fn finish(&mut self) -> Result<(), String> {
+    pub fn finish(&self) -> Result<(), String> {
         check(unsafe { rg_stream_finish(self.raw) })
     }
 
     /// The next tile in input order (blocks); Ok(None) after `finish` when everything was delivered.
-    pub fn next(&mut self) -> Result<Option<Tile>, String> {
+    pub fn next(&self) -> Result<Option<Tile>, String> {
         let mut r = std::mem::MaybeUninit::<rg_stream_result>::zeroed();
         let rc = unsafe { rg_stream_next(self.raw, r.as_mut_ptr()) };
         if rc == RG_STREAM_END {

@@ -1,8 +1,10 @@
 //! The read loops of RecGraph's `src/main.rs` (:56-105 mode 0, :107-172 mode 1, :174-213 mode 2, :215-253 mode 3,
 //! :255-262 mode 4, :263-270 mode 5, :289-313 modes 8 / 9) over the MI355X library: FASTA in, GAF out, every read of the
 //! file through ONE `hip::Stream` (all visible GPUs).  A maintainer calls `align_all` from `main()` in place of the
-//! `match align_mode { .. }` block; `-s true` (the reverse-complement retry of modes 0-3) keeps the reference's per-read
-//! functions of `api.rs`.
+//! `match align_mode { .. }` block; `-s true` (the reverse-complement retry of modes 0-3, main.rs:82-106, 132-165,
+//! 188-212, 229-253) runs inside the library (`rg_stream_opts.amb_strand`).  The FASTA file is fed block by block and the
+//! stream is bounded (`max_queued_tiles`, `max_undelivered_bytes`): like the reference's loop, memory does not grow with
+//! the read set.
 //! UNCOMPILED: no Rust toolchain exists in the image this was written in.
 use std::io::Write;
 
@@ -51,29 +53,48 @@ fn params_of(align_mode: i32, score_matrix: &std::collections::HashMap<(char, ch
 /// the warning lines on stdout, every record through `utils::write_gaf` (stdout or the `-o` file, with the number
 /// `main.rs` passes: `i + 1` in modes 0-3, `i` in modes 4, 5, 8, 9).
 pub fn align_all(align_mode: i32, sequence_path: &str, graph_path: &str, score_matrix: &std::collections::HashMap<(char, char), i32>) {
+    use std::io::Read;
     let gfa = std::fs::read_to_string(graph_path).unwrap();
-    let fasta = std::fs::read(sequence_path).unwrap();
     let graph = hip::Graph::from_gfa_text(&gfa).unwrap_or_else(|e| panic!("{}", e));
     let params = params_of(align_mode, score_matrix);
-    let mut stream = hip::Stream::new(&graph, &params, None, None).unwrap_or_else(|e| panic!("{}", e));
-    // sequences::get_sequences (sequences.rs:5-45) runs inside the library; a file whose name / sequence counts differ
-    // comes back as "wrong fasta file format" (:41-43)
-    stream.push_fasta(&fasta).unwrap_or_else(|e| panic!("{}", e));
-    stream.finish().unwrap();
+    let mut opts = hip::Stream::default_opts();
+    opts.amb_strand = args_parser::get_amb_strand_mode() as i32; // ignored by modes 4+ like main.rs:254-313
+    // bounded like the reference's loop (one read in, one record out): pushes wait while 4 tiles are queued, the workers
+    // wait while 64 MB of finished text has not been taken; a feeder thread reads the file block by block (a push may
+    // wait, so feeding and draining must not be the same thread)
+    opts.max_queued_tiles = 4;
+    opts.max_undelivered_bytes = 64 << 20;
+    let stream = hip::Stream::new(&graph, &params, None, Some(opts)).unwrap_or_else(|e| panic!("{}", e));
     let stdout = std::io::stdout();
-    while let Some(tile) = stream.next().unwrap_or_else(|e| panic!("{}", e)) {
-        for i in 0..tile.status.len() {
-            if tile.status[i] & (hip::RG_READ_WOULD_PANIC | hip::RG_READ_BAD_BASE) != 0 {
-                panic!("read {}: the CPU path panics on this input", tile.first_read + i);
+    std::thread::scope(|sc| {
+        sc.spawn(|| {
+            let mut file = std::fs::File::open(sequence_path).unwrap();
+            let mut block = vec![0u8; 4 << 20];
+            loop {
+                // sequences::get_sequences (sequences.rs:5-45) runs inside the library; a file whose name / sequence
+                // counts differ comes back as "wrong fasta file format" (:41-43)
+                let got = file.read(&mut block).unwrap();
+                stream.feed_fasta(&block[..got], got == 0).unwrap_or_else(|e| panic!("{}", e));
+                if got == 0 {
+                    stream.finish().unwrap();
+                    break;
+                }
             }
-            let text = &tile.text[tile.text_off[i] as usize..tile.text_off[i + 1] as usize];
-            // the last line is the GAF record; lines before it are the `println!` warnings of the exec functions
-            let body = &text[..text.len() - 1];
-            let cut = body.iter().rposition(|c| *c == b'\n').map(|p| p + 1).unwrap_or(0);
-            stdout.lock().write_all(&text[..cut]).unwrap();
-            let record = String::from_utf8_lossy(&body[cut..]).into_owned();
-            let n = tile.first_read + i;
-            utils::write_gaf(&record, if align_mode <= 3 { n + 1 } else { n });
+        });
+        while let Some(tile) = stream.next().unwrap_or_else(|e| panic!("{}", e)) {
+            for i in 0..tile.status.len() {
+                if tile.status[i] & (hip::RG_READ_WOULD_PANIC | hip::RG_READ_BAD_BASE) != 0 {
+                    panic!("read {}: the CPU path panics on this input", tile.first_read + i);
+                }
+                let text = &tile.text[tile.text_off[i] as usize..tile.text_off[i + 1] as usize];
+                // the last line is the GAF record; lines before it are the `println!` warnings of the exec functions
+                let body = &text[..text.len() - 1];
+                let cut = body.iter().rposition(|c| *c == b'\n').map(|p| p + 1).unwrap_or(0);
+                stdout.lock().write_all(&text[..cut]).unwrap();
+                let record = String::from_utf8_lossy(&body[cut..]).into_owned();
+                let n = tile.first_read + i;
+                utils::write_gaf(&record, if align_mode <= 3 { n + 1 } else { n });
+            }
         }
-    }
+    });
 }

@@ -4,6 +4,7 @@
 // status code (never crash, never trip ASan / UBSan).  Usage: host_asan graph.gfa reads.fa [iterations] [seed]
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <fstream>
 #include <random>
@@ -35,6 +36,27 @@ static void try_gfa(const std::string& t) {
     }
 }
 
+// the same text in random pieces through FastaFeeder (what rg_stream_feed_fasta runs) and through fasta_count (what
+// rg_fasta_check runs): same reads, same verdict as the one-piece parser
+static void try_feeder(const std::string& t, bool whole_ok, const FastaReads& whole, uint64_t seed) {
+    std::mt19937_64 rng(seed);
+    FastaFeeder fd;
+    FastaReads out;
+    int64_t st[4] = {0, 0, 0, 0};
+    size_t pos = 0;
+    while (pos < t.size()) {
+        const size_t cnt = std::min<size_t>(t.size() - pos, (size_t)(rng() % 7 == 0 ? 0 : 1 + rng() % 40));
+        fd.feed(t.data() + pos, (int64_t)cnt, false, out);
+        fasta_count(t.data() + pos, (int64_t)cnt, false, st);
+        pos += cnt;
+    }
+    fd.feed(nullptr, 0, true, out);
+    fasta_count(nullptr, 0, true, st);
+    if (fd.balanced() != whole_ok || (st[0] == st[1]) != whole_ok) { fprintf(stderr, "feeder verdict differs\n"); abort(); }
+    if (st[0] != fd.names_total || st[1] != fd.seqs_total) { fprintf(stderr, "fasta_count differs from the feeder\n"); abort(); }
+    if (whole_ok && (out.names != whole.names || out.bases != whole.bases || out.off != whole.off)) { fprintf(stderr, "feeder reads differ\n"); abort(); }
+}
+
 static void try_fasta(const std::string& t, int64_t batch) {
     FastaReads r;
     int64_t emitted = 0;
@@ -46,6 +68,7 @@ static void try_fasta(const std::string& t, int64_t batch) {
         }
         emitted += count;
     });
+    try_feeder(t, ok, r, (uint64_t)t.size() * 31 + (uint64_t)batch);
     if (ok) {
         ++ok_fa;
         if (emitted != (int64_t)r.names.size()) { fprintf(stderr, "reads lost\n"); abort(); }

@@ -128,3 +128,51 @@ def test_out_file_semantics_follow_write_gaf(tmp_path):
         cli.write_gaf_records(str(a), recs[:k], list(range(base, base + k)))
         literal(str(b), recs[:k], list(range(base, base + k)))
         assert a.read_text() == b.read_text()
+
+
+def test_fasta_check_counts_like_get_sequences(tmp_path):
+    """rg_fasta_check (the file-level check the streaming CLI runs ahead of its output: sequences.rs:41-43) fed in
+    pieces == the one-piece parser: same read count, same refusals."""
+    import random
+    import ctypes as C
+    import pytest
+    from recgraph_amd import _lib, api
+    lib = _lib.load()
+
+    def check(text, rnd):
+        st = (C.c_int64 * 4)()
+        n = C.c_int64(0)
+        b = text.encode()
+        pos = 0
+        while pos < len(b):
+            cnt = min(len(b) - pos, rnd.randint(0, 9))
+            _lib.check(lib.rg_fasta_check(b[pos:pos + cnt], cnt, 0, st, C.byref(n)))
+            pos += cnt
+        rc = lib.rg_fasta_check(b"", 0, 1, st, C.byref(n))
+        return rc, n.value
+    rnd = random.Random(11)
+    cases = [">a\nACGT\n", ">a b c\r\nac-gt\r\nNN\r\n\r\n>b\r\nTT", "ACGT\n>a\n>b\nGG\n", ">a\nAC\n\n\nGT\n>b\nT\n", ">\nA\n", "",
+             ">a\n>b\nAC\n", "ACGT\n", ">a\n", ">a\nAC\n>b\n", ">a\r\nAC\r", "\r", ">a\n\r", "\r\n>a\r\n\rA\r\n"]
+    for _ in range(400):
+        parts = []
+        for _ in range(rnd.randint(0, 8)):
+            kind = rnd.random()
+            parts.append(">" + "".join(rnd.choice("abc 12>") for _ in range(rnd.randint(0, 5))) if kind < 0.35 else
+                         "".join(rnd.choice("ACGTacgtnN-x\r") for _ in range(rnd.randint(0, 9))) if kind < 0.9 else "")
+        text = "".join(p + rnd.choice(["\n", "\r\n"]) for p in parts)
+        cases.append(text[:-1] if rnd.random() < 0.3 and text.endswith("\n") else text)
+    for text in cases:
+        try:
+            exp = len(api.Reads.from_fasta_text(text))
+        except _lib.RecGraphError:
+            exp = None
+        rc, n = check(text, rnd)
+        assert (rc == 0) == (exp is not None), repr(text)
+        if exp is not None:
+            assert n == exp, repr(text)
+    p = tmp_path / "x.fa"
+    p.write_text(">a\nAC\n>b\nGT\n")
+    assert api.fasta_check(str(p), block=3) == 2
+    p.write_text(">a\nAC\n>b\n")
+    with pytest.raises(_lib.RecGraphError, match="wrong fasta file format"):
+        api.fasta_check(str(p), block=2)

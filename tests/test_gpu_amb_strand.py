@@ -60,6 +60,24 @@ def test_amb_strand_matches_main_rs(oracle, example_gfa, example_reads, m, scala
     # without -s the same reads never carry the reversed labels
     plain, _ = api.align_batch(g, rd, names, mode=mode, b=10.0)
     assert plain != texts
+    # the same retry INSIDE the library (rg_stream_opts.amb_strand: what a C / Rust caller and the CLI get): second handle
+    # per worker, the comparison and the warning lines in the worker
+    for handles, tile in ((2, 5), (1, 100)):
+        stexts, sstatus = api.align_stream(g, rd, names, mode=mode, device_ids=[0], handles_per_device=handles, tile_reads=tile,
+                                           amb_strand=True, b=10.0)
+        assert stexts == exp and sstatus == status, (handles, tile)
+
+
+def test_amb_strand_option_is_ignored_by_the_pathwise_modes_and_refuses_kept_records():
+    from recgraph_amd import api, synth
+    sg = synth.haplotype_graph(400, 4, path_len=100, seed=3)
+    g = api.Graph.from_gfa_text(sg.gfa())
+    rd = synth.haplotype_reads(sg, 9, 100, seed=4, mosaic_frac=0.5)
+    base, _ = api.align_batch(g, rd, None, mode=api.MODE_RECOMBINATION)
+    got, _ = api.align_stream(g, rd, None, mode=api.MODE_RECOMBINATION, device_ids=[0], tile_reads=4, amb_strand=True)   # main.rs:254-313 ignore -s
+    assert got == base
+    with pytest.raises(api._lib.RecGraphError):
+        api.Stream(g, api.make_params(api.MODE_GLOBAL_POA), device_ids=[0], amb_strand=True, keep_records=True)
 
 
 def test_amb_strand_cli(oracle, tmp_path, example_gfa, example_reads, capsys):

@@ -185,3 +185,102 @@ def test_a_failed_set_reads_leaves_no_stale_handle():
     b.run()
     b.fetch()
     assert [b.gaf_text(i, "r", i + 1) for i in range(10)] == before
+
+
+def test_bounded_stream_with_a_slow_consumer():
+    """max_queued_tiles / max_undelivered_bytes bound what the stream holds: with a cap of 2 queued tiles and
+    ~2 tiles of finished text, a consumer that sleeps never sees more than a handful of tiles pending while a feeder thread
+    pushes 40 of them; the bytes are those of the unbounded run."""
+    import threading
+    import time
+    from recgraph_amd import api
+    _, g, reads = _graph_reads(n=200, seed=71)
+    one, _ = api.align_batch(g, reads, None, mode=api.MODE_PATHWISE)
+    tile_bytes = len("".join(one[:5]))
+    st = api.Stream(g, api.make_params(api.MODE_PATHWISE), device_ids=[0], handles_per_device=2, tile_reads=5,
+                    max_queued_tiles=2, max_undelivered_bytes=2 * tile_bytes)
+    peak = [0]
+    done = threading.Event()
+
+    def feeder():
+        for k in range(0, len(reads), 5):
+            st.push(reads[k:k + 5])                  # blocks while 2 tiles are queued
+            peak[0] = max(peak[0], st.pending)
+        st.finish()
+        done.set()
+    th = threading.Thread(target=feeder)
+    th.start()
+    got = []
+    for t in st:
+        got.append(t)
+        if len(got) < 12:
+            time.sleep(0.05)                         # the slow consumer
+            assert not done.is_set()                 # the feeder is held back: 40 tiles cannot all be in
+            assert st.pending <= 10                  # queued (2) + on the handles (2) + finished (the 2-tile cap is crossed by what was in flight)
+    th.join()
+    assert peak[0] <= 10
+    assert b"".join(t.text for t in got).decode() == "".join(one) and len(got) == 40
+    st.close()
+
+
+def test_feed_fasta_in_pieces_and_pathwise_read_zero(example_gfa):
+    """rg_stream_feed_fasta: any split of the text gives the reads of the one-piece call; a pathwise stream with
+    seq_index_base = 0 (what main.rs:260,268,311 pass) still prints read 0 (only the POA modes read the index as
+    "score only")."""
+    from recgraph_amd import api
+    g = api.Graph.from_gfa_text(example_gfa)
+    fa = open(os.path.join(ROOT, "tests", "golden", "example_reads.fa"), "rb").read()
+    whole = api.Reads.from_fasta_text(fa)
+    for mode in (api.MODE_PATHWISE, api.MODE_GLOBAL_POA):
+        base, _ = api.align_batch(g, whole.sequences(), whole.names, mode=mode, seq_index_base=0)
+        assert ("\t" not in base[0]) == (mode == api.MODE_GLOBAL_POA) and "\t" in base[1]      # "score only" is a POA notion
+        for piece in (1 << 20, 777, 13):
+            st = api.Stream(g, api.make_params(mode), device_ids=[0], tile_reads=9, seq_index_base=0)
+            n = 0
+            for k in range(0, len(fa), piece):
+                n += st.feed_fasta(fa[k:k + piece])
+            n += st.feed_fasta(b"", final=True)
+            st.finish()
+            assert n == len(whole)
+            assert b"".join(t.text for t in st).decode() == "".join(base), (mode, piece)
+            st.close()
+    # a second text on the same stream after the first was closed, and a refused one
+    st = api.Stream(g, api.make_params(api.MODE_GLOBAL_POA), device_ids=[0], tile_reads=4)
+    assert st.feed_fasta(b">a\nAC", final=False) == 0 and st.feed_fasta(b"GT\n>b\nGG\n", final=True) == 2
+    with pytest.raises(api._lib.RecGraphError, match="wrong fasta file format"):
+        st.feed_fasta(b">c\nAA\n>d\n", final=True)
+    st.finish()
+    assert sum(t.n for t in st) == 3          # the complete read before the bad end was pushed
+    st.close()
+
+
+def test_kept_records_can_be_released():
+    from recgraph_amd import api
+    _, g, reads = _graph_reads(n=30, seed=81)
+    one, _ = api.align_batch(g, reads, None, mode=api.MODE_PATHWISE)
+    st = api.Stream(g, api.make_params(api.MODE_PATHWISE), device_ids=[0], tile_reads=7, keep_records=True)
+    st.push(reads)
+    st.finish()
+    for t in st:
+        view = api._ShardView(C_void(t.records), t.n, st)
+        assert [view.gaf_text(i, "read%d" % (t.first + i), t.first + i + 1) for i in range(t.n)] == one[t.first:t.first + t.n]
+        st.release(t)                              # the handle is freed now, not at rg_stream_destroy
+        st.release(t)                              # (idempotent)
+    st.close()
+
+
+def C_void(p):
+    import ctypes
+    return ctypes.c_void_p(p)
+
+
+def test_cli_refuses_a_malformed_file_before_any_output(tmp_path, example_gfa):
+    """The reference parses the whole FASTA file before it aligns (and panics: sequences.rs:41-43): the streaming CLI prints
+    nothing for such a file, however many complete reads precede the bad end."""
+    gfa = os.path.join(ROOT, "tests", "golden", "example_graph.gfa")
+    fa = open(os.path.join(ROOT, "tests", "golden", "example_reads.fa")).read()
+    bad = tmp_path / "bad.fa"
+    bad.write_text(fa + ">tail without bases\n")
+    r = subprocess.run([sys.executable, "-m", "recgraph_amd.cli", str(bad), gfa, "-m", "0", "--tile", "8"], capture_output=True, text=True,
+                       cwd=ROOT, timeout=600)
+    assert r.returncode != 0 and r.stdout == "" and "wrong fasta file format" in r.stderr

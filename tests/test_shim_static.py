@@ -47,7 +47,9 @@ def test_hand_written_rust_only_uses_declared_items():
     for mode in ("RG_MODE_GLOBAL_POA", "RG_MODE_GAP_POA", "RG_MODE_PATHWISE", "RG_MODE_RECOMBINATION", "RG_MODE_PATHWISE_SEMI",
                  "RG_MODE_RECOMBINATION_SEMI", "RG_MODE_LOCAL_POA", "RG_MODE_GAP_LOCAL_POA"):
         assert mode in loop
-    assert "push_fasta" in loop and "write_gaf" in loop
+    assert "feed_fasta" in loop and "write_gaf" in loop
+    # bounded like the reference's loop, and `-s true` goes into the library
+    assert "max_queued_tiles" in loop and "max_undelivered_bytes" in loop and "amb_strand" in loop
 
 
 def test_repr_c_structs_match_the_ctypes_mirror():
