@@ -167,6 +167,9 @@ int64_t rg_batch_format_all(const rg_batch* b, const char* const* names, int64_t
 /* Measurement hooks for bench.py: DP cell-updates of the last run (SURVEY §8d unit of work) and
  * per-kernel device time measured with HIP events on the stream the kernels were launched on. */
 uint64_t rg_batch_cell_updates(const rg_batch* b);
+/* The cell updates the kernels actually performed for that workload: the same number except where k_sweep16 runs a
+ * segment's rows as a gather run (per row the alpha and a column map instead of one update per member path). */
+uint64_t rg_batch_cell_updates_performed(const rg_batch* b);
 int32_t rg_batch_kernel_count(const rg_batch* b);
 const char* rg_batch_kernel_name(const rg_batch* b, int32_t k);
 double rg_batch_kernel_ms(const rg_batch* b, int32_t k);       /* summed over launches of the last run */
@@ -282,6 +285,7 @@ typedef struct rg_stream_result {
     uint64_t cell_updates;        /* DP cell updates of the tile (SURVEY 8d unit of work)                       */
     rg_batch* records;            /* keep_records: results-only handle for the rg_result_* accessors, owned by the
                                      stream (valid until rg_stream_release / rg_stream_destroy), else NULL      */
+    uint64_t cell_updates_performed; /* rg_batch_cell_updates_performed of the tile                              */
 } rg_stream_result;
 #define RG_STREAM_END 1
 void rg_stream_opts_default(rg_stream_opts* o);

@@ -30,7 +30,8 @@ class StreamOpts(C.Structure):
 class StreamResult(C.Structure):
     _fields_ = [("first_read", C.c_int64), ("nreads", C.c_int64), ("text", C.c_void_p), ("text_len", C.c_int64),
                 ("text_off", C.POINTER(C.c_int64)), ("status", C.POINTER(C.c_uint32)), ("score", C.POINTER(C.c_int32)),
-                ("device", C.c_int32), ("reserved", C.c_int32), ("cell_updates", C.c_uint64), ("records", C.c_void_p)]
+                ("device", C.c_int32), ("reserved", C.c_int32), ("cell_updates", C.c_uint64), ("records", C.c_void_p),
+                ("cell_updates_performed", C.c_uint64)]
 
 
 class Params(C.Structure):
@@ -57,7 +58,7 @@ def build_library(force=False):
 SYMBOLS = ["rg_params_default", "rg_scores_match_mis", "rg_graph_from_gfa", "rg_graph_create_lnz",
            "rg_graph_create_path", "rg_graph_destroy", "rg_graph_path_error", "rg_graph_rows", "rg_graph_paths", "rg_graph_dump",
            "rg_batch_create", "rg_batch_set_reads", "rg_batch_run", "rg_batch_fetch", "rg_batch_destroy", "rg_batch_size",
-           "rg_result_status", "rg_result_score", "rg_result_gaf", "rg_result_fields", "rg_batch_format_all", "rg_batch_cell_updates", "rg_batch_kernel_count",
+           "rg_result_status", "rg_result_score", "rg_result_gaf", "rg_result_fields", "rg_batch_format_all", "rg_batch_cell_updates", "rg_batch_cell_updates_performed", "rg_batch_kernel_count",
            "rg_batch_kernel_name", "rg_batch_kernel_ms", "rg_batch_kernel_launches", "rg_align_batch", "rg_align_batch_multi", "rg_multi_shards", "rg_multi_batch", "rg_multi_shard_begin",
            "rg_multi_format_all", "rg_multi_destroy", "rg_last_error",
            "rg_device_count", "rg_set_device",
@@ -121,6 +122,8 @@ def load():
     l.rg_batch_format_all.restype = i64
     l.rg_batch_cell_updates.argtypes = [vp]
     l.rg_batch_cell_updates.restype = u64
+    l.rg_batch_cell_updates_performed.argtypes = [vp]
+    l.rg_batch_cell_updates_performed.restype = u64
     l.rg_batch_kernel_count.argtypes = [vp]
     l.rg_batch_kernel_name.argtypes = [vp, i32]
     l.rg_batch_kernel_name.restype = C.c_char_p

@@ -347,6 +347,10 @@ class Batch:
     def cell_updates(self):
         return _lib.load().rg_batch_cell_updates(self._h)
 
+    @property
+    def cell_updates_performed(self):
+        return _lib.load().rg_batch_cell_updates_performed(self._h)
+
     def kernel_stats(self):
         lib = _lib.load()
         return {lib.rg_batch_kernel_name(self._h, k).decode(): (lib.rg_batch_kernel_ms(self._h, k),
@@ -473,7 +477,7 @@ def fasta_check(path, block=8 << 20):
 
 class StreamTile:
     """One rg_stream_result, copied out of the library's buffers."""
-    __slots__ = ("first", "n", "text", "text_off", "status", "score", "device", "cell_updates", "records")
+    __slots__ = ("first", "n", "text", "text_off", "status", "score", "device", "cell_updates", "cell_updates_performed", "records")
 
     def text_of(self, i):
         return self.text[self.text_off[i]:self.text_off[i + 1]]
@@ -563,6 +567,7 @@ class Stream:
         check(rc)
         t = StreamTile()
         t.first, t.n, t.device, t.cell_updates, t.records = r.first_read, r.nreads, r.device, r.cell_updates, r.records
+        t.cell_updates_performed = r.cell_updates_performed
         t.text = C.string_at(r.text, r.text_len) if copy_text else (r.text, r.text_len)
         t.text_off = np.ctypeslib.as_array(r.text_off, shape=(r.nreads + 1,)).copy()
         t.status = np.ctypeslib.as_array(r.status, shape=(r.nreads,)).copy()

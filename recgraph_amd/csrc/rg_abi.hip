@@ -151,6 +151,7 @@ int run_local(rg_batch* b) {
     unsigned long long c = 0;
     HIPCHK(hipMemcpy(&c, b->d_cells.p, sizeof c, hipMemcpyDeviceToHost));
     b->cells = c;
+    b->cells_performed = c;
     return RG_OK;
 }
 
@@ -211,6 +212,7 @@ int run_poa(rg_batch* b) {
             unsigned long long c = 0;
             HIPCHK(hipMemcpy(&c, b->d_cells.p, sizeof c, hipMemcpyDeviceToHost));
             b->cells = c;
+            b->cells_performed = c;      // (the POA kernels evaluate exactly the band cells they count)
             return RG_OK;
         }
         const long long full = (long long)h.L * (b->max_n + 1);
@@ -322,6 +324,7 @@ rg_batch* rg_batch_detach_results(rg_batch* b) {
     r->oprows = std::move(b->oprows);
     r->ops_stride = b->ops_stride;
     r->cells = b->cells;
+    r->cells_performed = b->cells_performed;
     r->stats = b->stats;
     r->fetched = true;
     b->fetched = false;
@@ -458,7 +461,7 @@ static int load_reads(rg_batch* b, const char* reads, const int64_t* read_off, i
     const size_t in_bytes = o_bad + (size_t)nreads;
     int rc;
     if ((rc = b->stage.alloc(in_bytes)) || (rc = b->d_in.alloc(in_bytes + in_bytes / 4)) || (rc = b->d_rec.alloc(nreads)) ||
-        (rc = b->d_cells.alloc(1)))
+        (rc = b->d_cells.alloc(2)))
         return rc;
     b->nreads = nreads;
     b->off.resize(nreads + 1);
@@ -669,6 +672,7 @@ int64_t rg_batch_format_all(const rg_batch* b, const char* const* names, int64_t
 }
 
 uint64_t rg_batch_cell_updates(const rg_batch* b) { return b ? b->cells : 0; }
+uint64_t rg_batch_cell_updates_performed(const rg_batch* b) { return b ? b->cells_performed : 0; }
 int32_t rg_batch_kernel_count(const rg_batch* b) { return b ? (int32_t)b->stats.size() : 0; }
 const char* rg_batch_kernel_name(const rg_batch* b, int32_t k) { return b->stats[k].name.c_str(); }
 double rg_batch_kernel_ms(const rg_batch* b, int32_t k) { return b->stats[k].ms; }
@@ -699,13 +703,14 @@ int rg_run_pathwise(rg_batch* b) {
     gd.rmask = g->d_rmask.p; gd.pnwp = g->d_pnwp.p; gd.rnwp = g->d_rnwp.p;
     std::vector<std::pair<std::string, std::pair<double, long long>>> st;
     // what this handle already holds counts towards its share of the device
-    unsigned long long c = 0;
+    unsigned long long c[2] = {0, 0};
     b->pw.spin_wait = b->spin_wait;
     int rc = path_driver_run(h, gd, b->p, b->pw, b->in.reads, b->in.off, b->in.bad, (int)b->nreads, b->max_n, b->d_rec.p,
-                             b->d_ops.p, b->ops_stride, b->d_cells.p, b->stream, b->mem_budget, &c, st, true);
+                             b->d_ops.p, b->ops_stride, b->d_cells.p, b->stream, b->mem_budget, c, st, true);
     b->stats.clear();
     for (auto& s : st) b->stats.push_back(KernelStat{s.first, s.second.first, s.second.second});
     if (rc) return rc;
-    b->cells = c;
+    b->cells = c[0];
+    b->cells_performed = c[1];
     return RG_OK;
 }

@@ -214,7 +214,7 @@ struct rg_batch {
     std::vector<uint8_t> ops;
     std::vector<int32_t> oprows;
     bool fetched = false;
-    uint64_t cells = 0;
+    uint64_t cells = 0, cells_performed = 0;
     std::vector<KernelStat> stats;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
     hipEvent_t done_ev = nullptr;      // end-of-run marker polled by wait_stream_sleeping

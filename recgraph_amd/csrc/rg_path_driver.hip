@@ -136,7 +136,7 @@ struct Timer {
 int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params& p, PathWork& pw, const uint8_t* d_reads,
                     const long long* d_off, const uint8_t* d_bad, int nreads, int max_n, DevRecord* d_rec, uint8_t* d_ops,
                     long long ops_stride, unsigned long long* d_cells, hipStream_t stream, size_t mem_budget,
-                    unsigned long long* cells_out,
+                    unsigned long long* cells_out /* [2]: counted | performed */,
                     std::vector<std::pair<std::string, std::pair<double, long long>>>& stats, bool allow_spec) {
     if (!pw.impl) pw.impl = new PathWorkImpl();
     PathWorkImpl& w = *pw.impl;
@@ -408,10 +408,10 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
     stats.clear();
     Timer T{&w, stream, pw.spin_wait};
     int done = 0;
-    unsigned long long cells_done = 0;
+    unsigned long long cells_done = 0, cells_perf = 0;
     int oom_shift = 0;      // the budget is halved every time a work-buffer allocation fails (other handles / the retry pass took the memory)
     while (done < nreads) {
-        HIPCHK(hipMemsetAsync(d_cells, 0, sizeof(unsigned long long), stream));      // cell updates of this chunk attempt
+        HIPCHK(hipMemsetAsync(d_cells, 0, 2 * sizeof(unsigned long long), stream));  // cell updates of this chunk attempt (counted | performed)
         HIPCHK(hipMemsetAsync(w.need.p, 0, 8 * sizeof(unsigned), stream));
         const size_t per_read_all = per_read + (mode == RG_MODE_RECOMBINATION ? ((size_t)w.fcap * sizeof(Cand) + (size_t)w.rcap * (sizeof(Cand) + 4) +
                                                                                      (use_rec ? (size_t)(w.frec_cap + w.rrec_cap) * recw * 4 : 0)) : 0);
@@ -575,6 +575,7 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
         TIMED(T, "k_trace", launch_trace(ta, C, stream));
         // ONE read-back per chunk: cell updates + overflow summary, through pinned memory on the batch's stream
         HIPCHK(hipMemcpyAsync(w.h_sum, d_cells, sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipMemcpyAsync(w.h_sum + 5, d_cells + 1, sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
         HIPCHK(hipMemcpyAsync(w.h_sum + 1, w.need.p, 8 * sizeof(unsigned), hipMemcpyDeviceToHost, stream));
         if ((rc = T.collect(stats))) return rc;
         if (debug) fprintf(stderr, "[rg] chunk of %d reads: done after %.1f ms\n", chunk,
@@ -621,6 +622,7 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
             if (redo) continue;
         }
         const unsigned long long chunk_cells = w.h_sum[0];
+        cells_perf += w.h_sum[5];
         const unsigned nretry = spec ? reinterpret_cast<const unsigned*>(w.h_sum + 1)[4] : 0u;
         if (debug && spec) fprintf(stderr, "[rg] speculative bound (margin %d): %u of %d reads did not reach it\n", spec_margin, nretry, chunk);
         if (nretry) {
@@ -637,14 +639,14 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
             const int nr = (int)idx.size();
             if ((rc = w.rt_idx.upload(idx)) || (rc = w.rt_off.upload(so)) || (rc = w.rt_reads.alloc((size_t)so.back() + 1)) ||
                 (rc = w.rt_bad.alloc((size_t)nr)) || (rc = w.rt_rec.alloc((size_t)nr)) || (rc = w.rt_ops.alloc((size_t)nr * (size_t)ops_stride)) ||
-                (rc = w.rt_cells.alloc(1)))
+                (rc = w.rt_cells.alloc(2)))
                 return rc;
             HIPCHK(hipMemsetAsync(w.rt_bad.p, 0, (size_t)nr, stream));
             launch_gather_reads(d_reads, d_off + done, w.rt_idx.p, w.rt_off.p, w.rt_reads.p, nr, stream);
             std::vector<std::pair<std::string, std::pair<double, long long>>> st2;
-            unsigned long long c2 = 0;
+            unsigned long long c2[2] = {0, 0};
             if ((rc = path_driver_run(h, gd, p, w.retry, w.rt_reads.p, w.rt_off.p, w.rt_bad.p, nr, max_n, w.rt_rec.p, w.rt_ops.p, ops_stride,
-                                      w.rt_cells.p, stream, 0, &c2, st2, false)))
+                                      w.rt_cells.p, stream, 0, c2, st2, false)))
                 return rc;
             launch_scatter_results(w.rt_idx.p, w.rt_rec.p, w.rt_ops.p, d_rec + done, d_ops + (long long)done * ops_stride, ops_stride, nr, stream);
             HIPCHK(hipStreamSynchronize(stream));
@@ -657,7 +659,7 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
         cells_done += chunk_cells;
         done += chunk;
     }
-    if (cells_out) *cells_out = cells_done;
+    if (cells_out) { cells_out[0] = cells_done; cells_out[1] = cells_perf; }
     return RG_OK;
 }
 

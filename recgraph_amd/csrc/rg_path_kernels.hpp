@@ -54,7 +54,7 @@ struct SweepArgs {
     uint32_t* dirs;            // [reads][dirs_stride] direction words or null
     long long dirs_stride;
     int dir_words;             // u32 words per (row, group) slot
-    unsigned long long* cells;
+    unsigned long long* cells;   // [2]: member-row cell updates of the workload | cell updates the kernel performed
     int count_cells;
     int oob;                   // 1: the thresholds are tight (speculative bound): the epilogue tests the lane maximum before the columns
     // k_sweep16, two-sweep pipeline: emissions go out as one record per (row, lane) instead of one Cand per cell: (4 + C) ints = {row << 6 | lane, column mask, 0, 0, key[C]} with key = value << 16 | path

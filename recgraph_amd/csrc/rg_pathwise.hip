@@ -489,7 +489,10 @@ __global__ __launch_bounds__(kStripes ? 512 : 64, kStripes ? 1 : RG_SWEEP_WAVES)
         for (int k = wl; k < P; k += WAVE) { rs->sink_val[k] = endv[k]; rs->path_end_row[k] = endr[k]; }
         if (lane == ln_end) { rs->s0 = gbest_val; rs->end_row_best = gbest_row; rs->seed_path = gbest_path; }
     }
-    if (lane == 0 && a.count_cells) atomicAdd(a.cells, cells * (unsigned long long)(n + 1));
+    if (lane == 0 && a.count_cells) {
+        atomicAdd(a.cells, cells * (unsigned long long)(n + 1));
+        atomicAdd(a.cells + 1, cells * (unsigned long long)(n + 1));       // (every member update is performed as such here)
+    }
 }
 
 // ---------------------------------------------------------------------------------

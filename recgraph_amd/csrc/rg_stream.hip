@@ -74,7 +74,7 @@ struct Tile {
     std::vector<uint32_t> status;
     std::vector<int32_t> score;
     int device = -1;
-    uint64_t cells = 0;
+    uint64_t cells = 0, cells_performed = 0;
     int64_t out_bytes = 0;              // what the finished tile holds until rg_stream_next has delivered it
     rg_batch* records = nullptr;        // keep_records: owned by the stream once delivered
     ~Tile() { if (records) rg_batch_destroy_impl(records); }
@@ -215,6 +215,7 @@ struct rg_stream {
         bool have_rev = false;
         if (rc == RG_OK) {
             t->cells = h->cells;
+            t->cells_performed = h->cells_performed;
             t->status.resize((size_t)t->n);
             t->score.resize((size_t)t->n);
             for (int64_t i = 0; i < t->n; ++i) { t->status[(size_t)i] = h->rec[(size_t)i].status & 0xffu; t->score[(size_t)i] = h->rec[(size_t)i].score; }
@@ -224,6 +225,7 @@ struct rg_stream {
                 ar.rb = h2;
                 ar.rev_index = rev_index.data();
                 t->cells += h2->cells;
+                t->cells_performed += h2->cells_performed;
                 for (int64_t i = 0; i < t->n; ++i) {
                     const int64_t k = rev_index[(size_t)i];
                     if (k < 0) continue;
@@ -538,6 +540,7 @@ int32_t rg_stream_next(rg_stream* s, rg_stream_result* out) {
     out->status = t->status.data();
     out->score = t->score.data();
     out->cell_updates = t->cells;
+    out->cell_updates_performed = t->cells_performed;
     if (t->records) {
         std::lock_guard<std::mutex> lk(s->mu);
         s->kept.push_back(t->records);

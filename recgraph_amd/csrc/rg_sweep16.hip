@@ -357,7 +357,10 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
 #pragma unroll
     for (int r = 0; r < (kColmax == 2 ? H : 1); ++r) cmv[r] = NEGPAIR;
     unsigned ncand = 0;
-    unsigned long long cells = 0;
+    // cells: the workload's member-row updates (sum of |paths(row)| over the rows: the reference's unit of work, SURVEY
+    // 8d); done: row operators actually applied — the same number except in gather runs, which do per row the alpha and
+    // the column map, and per member one pass at each end of the run instead of one update per row
+    unsigned long long cells = 0, done = 0;
     Cand* cand = !kRec && a.cand ? a.cand + (long long)rd * a.cand_cap : nullptr;
     uint32_t* dirs = a.dirs ? a.dirs + (long long)rd * a.dirs_stride : nullptr;
     const bool track = a.track_best;
@@ -731,6 +734,7 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
                 if (dirs) store_dirs(rslot, umask, lmask);
                 RowOps16<C>::template member<true>(G, MU, lane, MU, ML, lmask, src);   // the gather follows the directions, adds nothing (SEL unused)
                 cells += (unsigned long long)nm;
+                done += 2ull;
 #ifndef RG_G_NOKEYS
                 if (kRec && track) {
                     // best member per column of this row: alpha value + best delta of the run-start column G points at (packed
@@ -776,6 +780,7 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
                 fetch(t, nw0, nw1, ngm);
                 ri = nw0 & 0xfffff; rli = (nw0 >> 20) & 7; rslot = nw1 & 0xfffff; rw1 = nw1;
             }
+            done += (unsigned long long)(nm - 1) * ((kRec && track) ? 2ull : 1ull);     // passes (1) and (3)
             // (3) every member once: row_k(end)[c] = A(end)[c] - A0[G(c)] + row_k(start)[G(c)]
 #ifndef RG_G_NOPH3
             {
@@ -875,6 +880,7 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
                 for (int kk = 1; kk < KRUN; ++kk)
                     if (kk < nm) RowOps16<C>::member(rr[kk], SEL, lane, MU, ML, lmask, src);
                 cells += (unsigned long long)nm;
+                done += (unsigned long long)nm;
                 if (kRec && kColmax != 1 && tail) {
                     if (track) {
                         if (rfl & F_FIRST) set_keys(bkey, rr[0], mk[0]); else fold_keys(bkey, rr[0], mk[0]);
@@ -959,6 +965,7 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
         {
             unsigned long long rest = cont ? gmask : gmask & ~(1ull << (ga - kbase));
             cells += (unsigned long long)nm;
+            done += (unsigned long long)nm;
             int nxt[H];
 #if defined(RG_SWEEP16_NOROWS) || defined(RG_SWEEP16_NOROWS32)
 #pragma unroll
@@ -1042,7 +1049,10 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
         for (int k = lane; k < P; k += WAVE) { rs->sink_val[k] = endv[k]; rs->path_end_row[k] = endr[k]; }
         if (lane == ln_end) { rs->s0 = gbest_val; rs->end_row_best = gbest_row; rs->seed_path = gbest_path; }
     }
-    if (lane == 0 && a.count_cells) atomicAdd(a.cells, cells * (unsigned long long)(n + 1));
+    if (lane == 0 && a.count_cells) {
+        atomicAdd(a.cells, cells * (unsigned long long)(n + 1));
+        atomicAdd(a.cells + 1, done * (unsigned long long)(n + 1));
+    }
 }
 
 // Host-side admission test: uniform read-gap cost and every absolute score provably inside the 16-bit budget.

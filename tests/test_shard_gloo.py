@@ -62,8 +62,12 @@ def _run_bench(extra, env_extra):
     env = dict(os.environ, RG_BENCH_STUB="1", **env_extra)
     env.pop("WORLD_SIZE", None)
     env.pop("RANK", None)
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "C2", "--batch", "64", "--steps", "3",
-                          "--warmup", "1", "--no-cpu"] + extra, env=env, capture_output=True, text=True, timeout=300)
+    base = ["--config", "C2", "--batch", "64", "--steps", "3", "--warmup", "1", "--no-cpu"]
+    for k in range(0, len(extra), 2):            # a flag given in `extra` replaces the default one
+        if extra[k] in base:
+            i = base.index(extra[k])
+            del base[i:i + 2]
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + base + extra, env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, out.stdout          # ONE JSON line, from rank 0
@@ -82,18 +86,38 @@ def test_bench_launcher_runs_the_world_2_path():
     per_rank = 3 * sum(len("read%d\t" % i) + 16 + 1 for i in range(64))
     assert weak["gaf_bytes_gathered"] == 2 * per_rank
     assert "64-read tiles" in weak["config"]["workload"]
-    # strong scaling deals WHOLE tiles to the ranks (rank 0: 2 of the 3 steps, rank 1: 1): reads per launch per rank are
-    # what they are at N = 1, and all 3 steps' text arrives on rank 0
+    # the stated target beside the headline, in the same run (the driver passes no flags): the 25 x 64 canonical reads split
+    # EVENLY over the ranks (reads, not tiles), even tiles of at most 64 reads
+    s100 = weak["strong_100k"]
+    assert s100["reads"] == 25 * 64 and s100["reads_per_rank"] == [800, 800] and s100["tiles_per_rank"] == [13, 13]
+    assert sum(s100["tile_reads"]) == 800 and max(s100["tile_reads"]) - min(s100["tile_reads"]) <= 1 and s100["reads_per_s"] > 0
+    # --scaling strong: the steps x batch reads of the N = 1 run split evenly: 192 reads -> 96 per rank -> two tiles of 48
+    tile = lambda k: sum(len("read%d\t" % i) + 16 + 1 for i in range(k))
     strong = _run_bench(["--gpus", "2", "--scaling", "strong"], {})
-    assert strong["n_gpus"] == 2 and strong["scaling"] == "strong"
-    assert "64 reads/step over all GPUs" in strong["config"]["workload"] and "64-read tiles" in strong["config"]["workload"]
-    assert strong["gaf_bytes_gathered"] == per_rank
-    assert "gather_ms_per_step" in strong and "gather_wait_ms" in strong
+    assert strong["n_gpus"] == 2 and strong["scaling"] == "strong" and strong["strong_100k"] is None
+    assert "64 reads/step over all GPUs" in strong["config"]["workload"] and "48-read tiles" in strong["config"]["workload"]
+    assert strong["tiles_per_rank"] == [2, 2] and strong["gaf_bytes_gathered"] == 4 * tile(48)
+    assert "gather_ms_per_step" in strong and "gather_wait_ms" in strong and strong["host_cpu_s_per_step"] >= 0
     one = _run_bench([], {})
-    assert one["n_gpus"] == 1 and one["gaf_bytes_gathered"] == per_rank
-    # more ranks than steps: some ranks hold no tile at all
-    few = _run_bench(["--gpus", "2", "--scaling", "strong", "--steps", "1"], {})
-    assert few["gaf_bytes_gathered"] == per_rank // 3
+    assert one["n_gpus"] == 1 and one["gaf_bytes_gathered"] == per_rank and one["strong_100k"] is None
+    # an odd read count: the shares differ by one read, never by a tile
+    odd = _run_bench(["--gpus", "2", "--scaling", "strong", "--steps", "1", "--batch", "65"], {})
+    assert odd["tiles_per_rank"] == [1, 1] and odd["gaf_bytes_gathered"] == tile(33) + tile(32)
+
+
+def test_even_tiles():
+    from recgraph_amd.shard import even_tiles, shard_bounds
+    assert even_tiles(12800, 4096) == [3200] * 4 and even_tiles(4096, 4096) == [4096] and even_tiles(0, 4096) == []
+    assert even_tiles(4097, 4096) == [2048, 2049]
+    for n in (1, 5, 4095, 12800, 102400, 99999):
+        for ramp in (0, 1, 3):
+            t = even_tiles(n, 4096, ramp)
+            assert sum(t) == n and max(t) <= 4096 and min(t) >= 1
+    # 102 400 reads on 8 ranks: 12 800 each, four launches each (whole 4096-read tiles would give 4/3/3/3/3/3/3/3)
+    spans = [shard_bounds(102400, r, 8) for r in range(8)]
+    assert {b - a for a, b in spans} == {12800} and {len(even_tiles(b - a, 4096)) for a, b in spans} == {4}
+    r = even_tiles(12800, 4096, ramp=2)
+    assert len(r) == 6 and r[0] < r[1] and sum(r) == 12800
 
 
 def test_bench_refuses_a_world_size_it_was_not_asked_for():
