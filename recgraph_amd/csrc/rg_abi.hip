@@ -239,6 +239,16 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
 extern "C" {
 static bool build_fields(const rg_batch* b, int64_t i, const char* name, GafFields& out);
 }
+static uint32_t public_status(uint32_t s) { return s & 0xffu; }
+// the record of read i as the host formatter takes it
+static void fill_record(const rg_batch* b, int64_t i, ReadRecord& r) {
+    const DevRecord& d = b->rec[i];
+    r.status = public_status(d.status); r.score = d.score; r.fscore = d.fscore; r.end_row = d.end_row; r.end_col = d.end_col;
+    r.stop_row = d.stop_row; r.stop_col = d.stop_col; r.best_path = d.best_path; r.rev_path = d.rev_path; r.fen = d.fen;
+    r.rsn = d.rsn; r.rec_col = d.rec_col; r.displacement = d.displacement; r.n_ops = d.n_ops; r.n_fwd_ops = d.n_fwd_ops;
+    r.ops = b->ops.data() + (size_t)i * b->ops_stride;
+    r.rows = is_poa(b->p.mode) ? b->oprows.data() + (size_t)i * b->ops_stride : nullptr;
+}
 bool amb_take_rev(int mode, int32_t fwd_score, int32_t rev_score) {
     if (mode == RG_MODE_LOCAL_POA || mode == RG_MODE_LOCAL_POA_SCALAR) return !(fwd_score < rev_score);   // main.rs:160-164 (sic)
     return rev_score > fwd_score;
@@ -261,6 +271,14 @@ static void append_gaf(const rg_batch* b, int64_t i, const char* name, int64_t s
             out += '\n';
             return;
         }
+    }
+    if (!score_only && !is_poa(b->p.mode) && !(d.status & (ST_BAD_BASE | ST_WOULD_PANIC))) {
+        // the pathwise modes: straight into the buffer (the same bytes as build_fields(..).text(): tests/test_gpu_stream.py
+        // holds the stream's text, written here, equal to rg_result_gaf's, written there)
+        ReadRecord r;
+        fill_record(b, i, r);
+        append_pathwise_text(b->g->h, b->codes + (size_t)b->off[i], (int)(b->off[i + 1] - b->off[i]), name ? name : "", r, b->p.mode, out);
+        return;
     }
     if (!score_only && build_fields(b, i, name, f)) out += f.text();
     else if ((d.status & (ST_BAD_BASE | ST_WOULD_PANIC)) == 0 && (d.status & ST_BAND_WARNING))
@@ -597,8 +615,6 @@ int32_t rg_batch_fetch(rg_batch* b) {
 void rg_batch_destroy(rg_batch* b) { rg_batch_destroy_impl(b); }
 int64_t rg_batch_size(const rg_batch* b) { return b ? b->nreads : 0; }
 
-static uint32_t public_status(uint32_t s) { return s & 0xffu; }
-
 uint32_t rg_result_status(const rg_batch* b, int64_t i) {
     if (!b || !b->fetched || i < 0 || i >= b->nreads) return RG_READ_WOULD_PANIC;
     return public_status(b->rec[i].status);
@@ -613,11 +629,7 @@ static bool build_fields(const rg_batch* b, int64_t i, const char* name, GafFiel
     const DevRecord& d = b->rec[i];
     if (d.status & (ST_BAD_BASE | ST_WOULD_PANIC)) return false;
     ReadRecord r;
-    r.status = public_status(d.status); r.score = d.score; r.fscore = d.fscore; r.end_row = d.end_row; r.end_col = d.end_col;
-    r.stop_row = d.stop_row; r.stop_col = d.stop_col; r.best_path = d.best_path; r.rev_path = d.rev_path; r.fen = d.fen;
-    r.rsn = d.rsn; r.rec_col = d.rec_col; r.displacement = d.displacement; r.n_ops = d.n_ops; r.n_fwd_ops = d.n_fwd_ops;
-    r.ops = b->ops.data() + (size_t)i * b->ops_stride;
-    r.rows = is_poa(b->p.mode) ? b->oprows.data() + (size_t)i * b->ops_stride : nullptr;
+    fill_record(b, i, r);
     std::string read((size_t)(b->off[i + 1] - b->off[i]), 'N');
     for (size_t k = 0; k < read.size(); ++k) read[k] = "ACGTN"[b->codes[(size_t)b->off[i] + k]];
     std::string nm = name ? name : "";

@@ -8,6 +8,7 @@
 //   build_cigar ................................. src/pathwise_alignment_output.rs:471-556
 #include <algorithm>
 #include <charconv>
+#include <cstring>
 
 #include "rg_codes.hpp"
 #include "rg_host.hpp"
@@ -118,6 +119,36 @@ void build_rev_ids(HostGraph& g) {
     }
 }
 
+// Row lists of the paths (HostGraph::pl_*), checked step by step against the PredHash lookups they replace in the formatter
+void build_path_lists(HostGraph& g) {
+    const int P = g.P, L = g.L;
+    g.pl_ok = false;
+    g.pl_off.assign((size_t)P + 1, 0);
+    if (!g.has_path || P < 1) return;
+    for (int i = 1; i + 1 < L; ++i)
+        for (int k = 0; k < P; ++k) if (g.row_mask[(size_t)i].test(k)) ++g.pl_off[(size_t)k + 1];
+    for (int k = 0; k < P; ++k) g.pl_off[(size_t)k + 1] += g.pl_off[(size_t)k];
+    const size_t total = (size_t)g.pl_off[(size_t)P];
+    g.pl_row.assign(total, 0); g.pl_base.assign(total, 'N'); g.pl_id.assign(total, 0);
+    std::vector<int32_t> at(g.pl_off.begin(), g.pl_off.end() - 1);
+    for (int i = 1; i + 1 < L; ++i)
+        for (int k = 0; k < P; ++k)
+            if (g.row_mask[(size_t)i].test(k)) {
+                const size_t t = (size_t)at[(size_t)k]++;
+                g.pl_row[t] = i; g.pl_base[t] = g.lnz[(size_t)i]; g.pl_id[t] = g.node_id[(size_t)i];
+            }
+    bool ok = true;
+    for (int k = 0; k < P && ok; ++k) {
+        const int32_t o = g.pl_off[(size_t)k], c = g.pl_off[(size_t)k + 1] - o;
+        for (int32_t t = 0; t < c && ok; ++t) {
+            const int row = g.pl_row[(size_t)(o + t)];
+            ok = step_on_path(g, row, k, true) == (t ? g.pl_row[(size_t)(o + t - 1)] : 0) &&
+                 step_on_path(g, row, k, false) == (t + 1 < c ? g.pl_row[(size_t)(o + t + 1)] : L - 1);
+        }
+    }
+    g.pl_ok = ok;
+}
+
 GafFields fields_m0_simd(const HostGraph& g, const std::string& read, const std::string& name,
                          const ReadRecord& r, int amb) {
     const std::vector<uint64_t>& nid = (amb & 1) ? g.node_id_rev : g.node_id;
@@ -226,111 +257,257 @@ GafFields fields_poa_banded(const HostGraph& g, const std::string& read, const s
 
 // ---------------------------------------------------------------------------------
 // m4 / m8: the device returns D/U/L ops only; rows are re-derived by walking the chosen path.
-GafFields fields_pathwise(const HostGraph& g, const std::string& read, const std::string& name,
-                          const ReadRecord& r, int mode) {
-    const int n = (int)read.size();
-    GafFields f;
-    f.name = name; f.qlen = (size_t)n; f.qstart = 0; f.qend = (size_t)(n - 1);
-    const bool rec = (mode == RG_MODE_RECOMBINATION || mode == RG_MODE_RECOMBINATION_SEMI) && r.best_path != r.rev_path;
+//
+// ONE walker (walk_pathwise) fills flat scratch buffers in their final order; two front ends read them: fields_pathwise
+// builds the GAFStruct fields (rg_result_fields / rg_result_gaf), append_pathwise_text writes the line straight into the
+// output buffer of format_batch (the streaming engine's formatter: no per-read strings, numbers through to_chars) — the
+// 12 us per read of the string-building form were 50 CPU-ms per 4096-read tile, more than an 8-GPU node under a
+// 16-CPU quota has to spare.
+namespace {
+
+// A position on one path: row + the bases / ids the walk emits, stepped towards the source (back) or the sink (ahead).
+// With the path's row list (HostGraph::pl_*) a step is an index step over sequential memory; without it (a list that
+// failed its check, or a row that is not on the path) it is the PredHash lookup of step_on_path.
+struct PathCursor {
+    const HostGraph& g;
+    int path, row;
+    long idx = -1, cnt = 0;
+    const int32_t* rows = nullptr;
+    const char* bases = nullptr;
+    const uint64_t* ids = nullptr;
+    bool fast = false;
+    PathCursor(const HostGraph& g_, int path_, int row_) : g(g_), path(path_), row(row_) {
+        if (!g.pl_ok || path < 0 || path >= g.P) return;
+        const int32_t o = g.pl_off[(size_t)path];
+        cnt = g.pl_off[(size_t)path + 1] - o;
+        rows = g.pl_row.data() + o; bases = g.pl_base.data() + o; ids = g.pl_id.data() + o;
+        const int32_t* it = std::lower_bound(rows, rows + cnt, row);
+        if (it != rows + cnt && *it == row) { idx = it - rows; fast = true; }
+    }
+    char base() const { return fast ? bases[idx] : g.lnz[(size_t)row]; }
+    uint64_t id() const { return fast ? ids[idx] : g.node_id[(size_t)row]; }
+    void back() {
+        if (!fast) { row = step_on_path(g, row, path, true); return; }
+        if (idx > 0) { --idx; row = rows[idx]; } else { fast = false; row = 0; }              // the list's first row leads back to row 0
+    }
+    void ahead() {
+        if (!fast) { row = step_on_path(g, row, path, false); return; }
+        if (idx + 1 < cnt) { ++idx; row = rows[idx]; } else { fast = false; row = g.L - 1; }  // ... its last row on to 'F'
+    }
+};
+
+struct PathwiseScratch {
+    std::vector<char> ops, pseq;
+    std::vector<uint64_t> ids;
+};
+struct PathwiseWalk {
+    const char* ops = nullptr; size_t nops = 0;       // D / d / U / L in output order
+    const char* pseq = nullptr; size_t npseq = 0;     // path bases in output order
+    const uint64_t* ids = nullptr; size_t nids = 0;   // segment ids, consecutive duplicates removed
+    size_t plen = 0, pstart = 0, pend = 0;
+    bool rec = false;
+    size_t rec_edge = 0;
+};
+
+inline char base_at(const uint8_t* codes, int n, int col) { return col == 0 ? '$' : "ACGTN"[codes[(size_t)col - 1]]; }
+
+void walk_pathwise(const HostGraph& g, const uint8_t* codes, int n, const ReadRecord& r, int mode, PathwiseScratch& sc, PathwiseWalk& w) {
+    const size_t cap = (size_t)std::max(r.n_ops, 1);
+    if (sc.ops.size() < cap) { sc.ops.resize(cap); sc.pseq.resize(cap); sc.ids.resize(cap); }
+    char* ops = sc.ops.data();
+    char* pseq = sc.pseq.data();
+    uint64_t* ids = sc.ids.data();
+    w.rec = (mode == RG_MODE_RECOMBINATION || mode == RG_MODE_RECOMBINATION_SEMI) && r.best_path != r.rev_path;
     // semiglobal walkers stop where the read is consumed: the path may start inside the graph, and the coordinate
     // helpers receive `start = i + 1` for the row i the walk stopped on (recombination_output.rs:186,331)
-    if (!rec) {
-        const int bp = r.best_path;
-        int i = r.end_row, j = n;
-        std::string ops, pseq;
-        std::vector<uint64_t> ids;
+    if (!w.rec) {
+        PathCursor pc(g, r.best_path, r.end_row);
+        int j = n;
+        const size_t N = (size_t)r.n_ops;
         size_t plen = 0;
-        for (int k = 0; k < r.n_ops; ++k) {
-            uint8_t op = r.ops[k] & 0x7f;
+        // the walk runs from the end of the alignment to its start: ops, bases and ids are written back to front
+        for (size_t k = 0; k < N; ++k) {
+            const uint8_t op = r.ops[k] & 0x7f;
             if (op == OP_D) {
-                ops.push_back(g.lnz[i] != read_at(read, j) ? 'd' : 'D');
-                ids.push_back(g.node_id[i]); pseq.push_back(g.lnz[i]);
-                i = step_on_path(g, i, bp, true); j -= 1; ++plen;
+                const char b = pc.base();
+                ops[N - 1 - k] = b != base_at(codes, n, j) ? 'd' : 'D';
+                ++plen;
+                ids[N - plen] = pc.id(); pseq[N - plen] = b;
+                pc.back(); j -= 1;
             } else if (op == OP_U) {
-                ops.push_back('U'); ids.push_back(g.node_id[i]); pseq.push_back(g.lnz[i]);
-                i = step_on_path(g, i, bp, true); ++plen;
-            } else { ops.push_back('L'); j -= 1; }
+                ops[N - 1 - k] = 'U';
+                ++plen;
+                ids[N - plen] = pc.id(); pseq[N - plen] = pc.base();
+                pc.back();
+            } else { ops[N - 1 - k] = 'L'; j -= 1; }
         }
-        std::reverse(ops.begin(), ops.end());
-        std::reverse(pseq.begin(), pseq.end());
-        dedup(ids);
-        std::reverse(ids.begin(), ids.end());
-        f.path = ids;
+        const int i = pc.row;
+        w.ops = ops; w.nops = N;
+        w.pseq = pseq + (N - plen); w.npseq = plen;
+        uint64_t* ib = ids + (N - plen);
+        w.ids = ib; w.nids = (size_t)(std::unique(ib, ib + plen) - ib);
         // utils.rs:221-254; start = 0 for the global modes (the walk pads down to row 0)
         const int start = i == 0 ? 0 : i + 1;
-        f.pstart = head_in_segment(g, start);
-        f.pend = plen > 0 ? f.pstart + plen - 1 : 0;
-        f.plen = f.pend + tail_in_segment(g, r.end_row) + 1;
-        f.comments = rle_cigar(ops) + ", best path: " + std::to_string(bp) + ", score: " + std::to_string(r.score) +
-                     "\t" + pseq;
-        return f;
+        w.pstart = head_in_segment(g, start);
+        w.pend = plen > 0 ? w.pstart + plen - 1 : 0;
+        w.plen = w.pend + tail_in_segment(g, r.end_row) + 1;
+        return;
     }
-    // recombination (recombination_output.rs:363-631)
+    // recombination (recombination_output.rs:363-631): the forward half occupies [0, F) of the buffers (written back to
+    // front), the reverse half follows it
     const int fp = r.best_path, rp = r.rev_path;
-    std::string fops, fseq, rops, rseq;
-    std::vector<uint64_t> fids, rids;
+    const size_t F = (size_t)r.n_fwd_ops, N = (size_t)r.n_ops;
     size_t flen = 0, rlen = 0;
     int fwd_stop = 0;
     {   // forward half, walked backwards from (fen, rec_col)
-        int i = r.fen, j = r.rec_col;
-        for (int k = 0; k < r.n_fwd_ops; ++k) {
-            uint8_t op = r.ops[k] & 0x7f;
+        PathCursor pc(g, fp, r.fen);
+        int j = r.rec_col;
+        for (size_t k = 0; k < F; ++k) {
+            const uint8_t op = r.ops[k] & 0x7f;
             if (op == OP_D) {
-                fops.push_back(g.lnz[i] != read_at(read, j) ? 'd' : 'D');
-                fids.push_back(g.node_id[i]); fseq.push_back(g.lnz[i]);
-                i = step_on_path(g, i, fp, true); j -= 1; ++flen;
+                const char b = pc.base();
+                ops[F - 1 - k] = b != base_at(codes, n, j) ? 'd' : 'D';
+                ++flen;
+                ids[F - flen] = pc.id(); pseq[F - flen] = b;
+                pc.back(); j -= 1;
             } else if (op == OP_U) {
-                fops.push_back('U'); fids.push_back(g.node_id[i]); fseq.push_back(g.lnz[i]);
-                i = step_on_path(g, i, fp, true); ++flen;
-            } else { fops.push_back('L'); j -= 1; }
+                ops[F - 1 - k] = 'U';
+                ++flen;
+                ids[F - flen] = pc.id(); pseq[F - flen] = pc.base();
+                pc.back();
+            } else { ops[F - 1 - k] = 'L'; j -= 1; }
         }
-        fwd_stop = i;
+        fwd_stop = pc.row;
     }
     int rev_ending = r.rsn;
     {   // reverse half, walked forwards from (rsn, rec_col); r_seq[j] = read[j+1] (get_rev_sequence)
-        int i = r.rsn, j = r.rec_col;
-        for (int k = r.n_fwd_ops; k < r.n_ops; ++k) {
+        PathCursor pc(g, rp, r.rsn);
+        int j = r.rec_col;
+        for (size_t k = F; k < N; ++k) {
             const uint8_t raw = r.ops[k];
             const uint8_t op = raw & 0x3f;
-            if (!(raw & OP_CONT)) rev_ending = i;   // ops of the main loop (recombination_output.rs:415)
+            if (!(raw & OP_CONT)) rev_ending = pc.row;   // ops of the main loop (recombination_output.rs:415)
             if (op == OP_D) {
-                char rc = j + 1 <= n ? read_at(read, j + 1) : 'F';
-                rops.push_back(g.lnz[i] != rc ? 'd' : 'D');
-                rids.push_back(g.node_id[i]); rseq.push_back(g.lnz[i]);
-                i = step_on_path(g, i, rp, false); j += 1; ++rlen;
+                const char rc = j + 1 <= n ? base_at(codes, n, j + 1) : 'F';
+                const char b = pc.base();
+                ops[k] = b != rc ? 'd' : 'D';
+                ids[F + rlen] = pc.id(); pseq[F + rlen] = b;
+                ++rlen;
+                pc.ahead(); j += 1;
             } else if (op == OP_U) {
-                rops.push_back('U'); rids.push_back(g.node_id[i]); rseq.push_back(g.lnz[i]);
-                i = step_on_path(g, i, rp, false); ++rlen;
-            } else { rops.push_back('L'); j += 1; }
+                ops[k] = 'U';
+                ids[F + rlen] = pc.id(); pseq[F + rlen] = pc.base();
+                ++rlen;
+                pc.ahead();
+            } else { ops[k] = 'L'; j += 1; }
         }
     }
-    const size_t rec_edge = fseq.size() - 1;
-    std::reverse(fops.begin(), fops.end());
-    std::reverse(fseq.begin(), fseq.end());
-    std::reverse(fids.begin(), fids.end());
-    std::string ops = fops + rops, pseq = fseq + rseq;
-    fids.insert(fids.end(), rids.begin(), rids.end());
-    dedup(fids);
-    f.path = fids;
+    w.rec_edge = flen - 1;                      // (#bases of the forward half) - 1, usize arithmetic as in the reference
+    w.ops = ops; w.nops = N;
+    w.pseq = pseq + (F - flen); w.npseq = flen + rlen;
+    uint64_t* ib = ids + (F - flen);
+    w.ids = ib; w.nids = (size_t)(std::unique(ib, ib + flen + rlen) - ib);
     // utils.rs:256-323
-    {
-        const int start = fwd_stop == 0 ? 0 : fwd_stop + 1;
-        const size_t path_start = head_in_segment(g, start);
-        size_t forw_path_end = flen > 0 ? path_start + flen - 1 : 0;
-        size_t forw_path_len = forw_path_end + tail_in_segment(g, r.fen) + 1;
-        size_t rev_path_start = head_in_segment(g, r.rsn);
-        size_t rev_path_end = rlen > 0 ? rev_path_start + rlen - 1 : 0;
-        f.pstart = path_start;
-        f.pend = forw_path_len + rev_path_end;
-        f.plen = forw_path_len + (rev_path_end + tail_in_segment(g, rev_ending) + 1);
+    const int start = fwd_stop == 0 ? 0 : fwd_stop + 1;
+    const size_t path_start = head_in_segment(g, start);
+    const size_t forw_path_end = flen > 0 ? path_start + flen - 1 : 0;
+    const size_t forw_path_len = forw_path_end + tail_in_segment(g, r.fen) + 1;
+    const size_t rev_path_start = head_in_segment(g, r.rsn);
+    const size_t rev_path_end = rlen > 0 ? rev_path_start + rlen - 1 : 0;
+    w.pstart = path_start;
+    w.pend = forw_path_len + rev_path_end;
+    w.plen = forw_path_len + (rev_path_end + tail_in_segment(g, rev_ending) + 1);
+}
+
+// text cursor over a std::string grown once per record
+struct Cursor {
+    char* p;
+    void ch(char c) { *p++ = c; }
+    void str(const char* s) { while (*s) *p++ = *s++; }
+    void mem(const char* s, size_t n) { memcpy(p, s, n); p += n; }
+    void num(unsigned long long v) { p = std::to_chars(p, p + 24, v).ptr; }
+    void snum(long long v) { p = std::to_chars(p, p + 24, v).ptr; }
+    void f32(float v) { p = std::to_chars(p, p + 64, v, std::chars_format::fixed).ptr; }
+    void cigar(const char* ops, size_t n) {                     // build_cigar: D->M, d->X, U->I, L->D, run-length
+        size_t i = 0;
+        while (i < n) {
+            size_t j = i + 1;
+            while (j < n && ops[j] == ops[i]) ++j;
+            num(j - i);
+            ch(ops[i] == 'D' ? 'M' : ops[i] == 'd' ? 'X' : ops[i] == 'U' ? 'I' : 'D');
+            i = j;
+        }
+    }
+};
+
+thread_local PathwiseScratch t_scratch;
+
+}  // namespace
+
+GafFields fields_pathwise(const HostGraph& g, const std::string& read, const std::string& name,
+                          const ReadRecord& r, int mode) {
+    const int n = (int)read.size();
+    std::vector<uint8_t> codes((size_t)n);
+    for (int k = 0; k < n; ++k) { const char c = read[(size_t)k]; codes[(size_t)k] = c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : 4; }
+    PathwiseScratch sc;
+    PathwiseWalk w;
+    walk_pathwise(g, codes.data(), n, r, mode, sc, w);
+    GafFields f;
+    f.name = name; f.qlen = (size_t)n; f.qstart = 0; f.qend = (size_t)(n - 1);
+    f.path.assign(w.ids, w.ids + w.nids);
+    f.pstart = w.pstart; f.pend = w.pend; f.plen = w.plen;
+    const std::string ops(w.ops, w.nops), pseq(w.pseq, w.npseq);
+    if (!w.rec) {
+        f.comments = rle_cigar(ops) + ", best path: " + std::to_string(r.best_path) + ", score: " + std::to_string(r.score) +
+                     "\t" + pseq;
+        return f;
     }
     auto node_off = [&](int node) { return g.node_id[node] == 0 ? 0 : g.seg_off[node] - 1; };  // get_node_offset
-    f.comments = rle_cigar(ops) + ", recombination path " + std::to_string(fp) + " " + std::to_string(rp) + ", nodes " +
+    f.comments = rle_cigar(ops) + ", recombination path " + std::to_string(r.best_path) + " " + std::to_string(r.rev_path) + ", nodes " +
                  std::to_string(g.node_id[r.fen]) + "[" + std::to_string(node_off(r.fen)) + "] " +
                  std::to_string(g.node_id[r.rsn]) + "[" + std::to_string(node_off(r.rsn)) + "], score: " +
                  f32_display(r.fscore) + ", displacement: " + std::to_string(r.displacement) + "\t" + pseq + "\t" +
-                 std::to_string(rec_edge);
+                 std::to_string(w.rec_edge);
     return f;
+}
+
+// fields_pathwise(..).text() written straight into `out` (GAFStruct::to_string, gaf_output.rs:70-94; comments as in
+// pathwise_alignment_output.rs:161-167, recombination_output.rs:598-612, 759-765)
+void append_pathwise_text(const HostGraph& g, const uint8_t* codes, int n, const char* name, const ReadRecord& r, int mode, std::string& out) {
+    PathwiseWalk w;
+    walk_pathwise(g, codes, n, r, mode, t_scratch, w);
+    const size_t nlen = strlen(name);
+    const size_t before = out.size();
+    // upper bound of the line: every number <= 20 digits; a cigar run is at least one op and prints <= 21 characters only
+    // when it is long, 2 per op at worst
+    out.resize(before + nlen + 21 * (w.nids + 16) + 2 * w.nops + w.npseq + 160);
+    Cursor c{&out[before]};
+    c.mem(name, nlen);
+    c.ch('\t'); c.num((unsigned long long)n);
+    c.str("\t0\t"); c.num((unsigned long long)(n - 1));
+    c.str("\t+\t>");
+    for (size_t i = 0; i < w.nids; ++i) { if (i) c.ch('>'); c.num(w.ids[i]); }
+    c.ch('\t'); c.num(w.plen);
+    c.ch('\t'); c.num(w.pstart);
+    c.ch('\t'); c.num(w.pend);
+    c.str("\t0\t*\t*\t");
+    c.cigar(w.ops, w.nops);
+    if (!w.rec) {
+        c.str(", best path: "); c.snum(r.best_path);
+        c.str(", score: "); c.snum(r.score);
+        c.ch('\t'); c.mem(w.pseq, w.npseq);
+    } else {
+        auto node_off = [&](int node) { return g.node_id[node] == 0 ? 0 : g.seg_off[node] - 1; };  // get_node_offset
+        c.str(", recombination path "); c.snum(r.best_path); c.ch(' '); c.snum(r.rev_path);
+        c.str(", nodes "); c.num(g.node_id[r.fen]); c.ch('['); c.snum(node_off(r.fen)); c.str("] ");
+        c.num(g.node_id[r.rsn]); c.ch('['); c.snum(node_off(r.rsn)); c.str("], score: ");
+        c.f32(r.fscore);
+        c.str(", displacement: "); c.snum(r.displacement);
+        c.ch('\t'); c.mem(w.pseq, w.npseq);
+        c.ch('\t'); c.num((unsigned long long)w.rec_edge);
+    }
+    c.ch('\n');
+    out.resize((size_t)(c.p - out.data()));
 }
 
 }  // namespace rg

@@ -197,6 +197,7 @@ int finish_path_view(HostGraph& g) {
     g.max_path_rows = 0;
     for (int32_t k = 0; k < P; ++k) g.max_path_rows = std::max(g.max_path_rows, cnt[k]);
     g.has_path = true;
+    build_path_lists(g);
     return RG_OK;
 }
 
@@ -454,6 +455,13 @@ std::string dump_graph(const HostGraph& g, int which) {
         case 3: for (int32_t i = 0; i + 1 < g.L; ++i) { if (i) s += ","; s += i == 0 ? std::string("-1") : std::to_string(g.node_id[i]); } break;
         case 4: for (int32_t i = 0; i < g.L; ++i) { if (i) s += ","; s += std::to_string((long long)(g.r_values[i] < 0 ? -1LL : (long long)g.r_values[i])); } break;
         case 11: for (int32_t i = 0; i < g.L; ++i) s += g.pnwp[i] ? '1' : '0'; break;
+        case 30:    // product only: the formatter's path row lists and whether every step of them equals the PredHash step
+            s = g.pl_ok ? "ok;" : "fallback;";
+            for (int32_t k = 0; k < g.P && !g.pl_off.empty(); ++k) {
+                for (int32_t t = g.pl_off[k]; t < g.pl_off[k + 1]; ++t) { if (t > g.pl_off[k]) s += ","; s += std::to_string(g.pl_row[t]); }
+                s += ";";
+            }
+            break;
         case 12: s = ph(g.eoff, g.epred, g.emask); break;
         case 13: for (int32_t i = 0; i < g.L; ++i) { s += bits(g.row_mask[i]); s += ";"; } break;
         case 14: s = csv(g.alphas); break;

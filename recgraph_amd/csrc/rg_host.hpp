@@ -108,6 +108,13 @@ struct HostGraph {
     std::vector<GroupDesc> fgroups, rgroups;
     int32_t fslots = 0, rslots = 0;
     int32_t max_path_rows = 0;
+    // rows of every path in order (+ their bases and segment ids), for the host formatter's walk along a path: rows of path k
+    // are pl_row[pl_off[k] .. pl_off[k + 1]); pl_ok: every step of every list equals the PredHash step it replaces
+    // (build_path_lists checks that once; the formatter falls back to the PredHash lookups otherwise)
+    std::vector<int32_t> pl_off, pl_row;
+    std::vector<char> pl_base;
+    std::vector<uint64_t> pl_id;
+    bool pl_ok = false;
 };
 
 // GFA text -> HostGraph (both views when P lines exist)
@@ -153,7 +160,10 @@ struct GafFields {
 GafFields fields_m0_simd(const HostGraph& g, const std::string& read, const std::string& name, const ReadRecord& r, int amb = 0);
 GafFields fields_poa_banded(const HostGraph& g, const std::string& read, const std::string& name, const ReadRecord& r, int amb = 0);
 GafFields fields_pathwise(const HostGraph& g, const std::string& read, const std::string& name, const ReadRecord& r, int mode);
+// fields_pathwise(..).text() appended to `out` without the intermediate strings (codes: the read's base codes 0..4)
+void append_pathwise_text(const HostGraph& g, const uint8_t* codes, int n, const char* name, const ReadRecord& r, int mode, std::string& out);
 void build_rev_ids(HostGraph& g);
+void build_path_lists(HostGraph& g);
 
 // ---- read ingestion (rg_reads.cpp) ----
 struct FastaReads {

@@ -224,3 +224,22 @@ def test_create_path_from_flat_arrays(rg):
         assert g2.paths_number == P
         for which in (10, 11, 12, 13, 14, 15, 16, 17, 18, 19):
             assert g2.dump(which) == g.dump(which), (P, which)
+
+
+def test_formatter_path_lists_replace_the_predhash_walk(rg, example_gfa):
+    """The host formatter walks a path through per-path row lists instead of PredHash lookups (rg_gaf.cpp): the lists are
+    checked step by step against those lookups when the graph is built; every graph family of the suite passes the check and
+    lists exactly the rows of each path."""
+    from recgraph_amd import api, synth
+    texts = [example_gfa, synth.haplotype_graph(900, 7, path_len=150, seed=4).gfa(), synth.random_dag_graph(60, 6, seed=5).gfa()]
+    texts += [v["gfa"] for v in VEC["path_graph"]]
+    for t in texts:
+        g = api.Graph.from_gfa_text(t)
+        if not g.paths_number:
+            continue
+        d = g.dump(30).strip(";").split(";")
+        assert d[0] == "ok"
+        masks = g.dump(13).strip(";").split(";")
+        for k, lst in enumerate(d[1:]):
+            rows = [int(x) for x in lst.split(",")] if lst else []
+            assert rows == [i for i in range(1, len(masks) - 1) if masks[i][k] == "1"]
