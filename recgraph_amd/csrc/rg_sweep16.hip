@@ -215,6 +215,7 @@ struct RowOps16 {
 template <int C, int kColmax, bool kRec, bool kWide>
 __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_WAVES) void k_sweep16(SweepArgs a) {
     constexpr int H = C / 2;
+    constexpr bool kTrack = kColmax != 0 || kRec;      // <0, false>: the -m 4 / -m 5 sweep — no best member, no thresholds, no emission
     constexpr int KRUN = C <= 16 ? (kColmax != 0 ? RG_SWEEP16_KRUN : RG_SWEEP16_KRUN_REV) : 0;   // rows kept in registers across the inner rows of a segment
     const int rd = blockIdx.x;
     const int lane = threadIdx.x;
@@ -288,8 +289,8 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
     int* thrl = lds16 + 64 + 2 * RG_MAXP;
 #define THRK(q) thrl[(q) * WAVE + lane]
 #else
-    int thrk[C];
-#define THRK(q) thrk[q]
+    int thrk[(kRec || !kTrack) ? 1 : C];        // (record variants test packed values against thz: no per-column key thresholds to keep)
+#define THRK(q) thrk[(kRec || !kTrack) ? 0 : (q)]
 #endif
     int thz[kRec ? H : 1];               // packed (threshold >> 16) pairs, see below
     int minplain2 = 0;
@@ -324,7 +325,7 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
             if (c >= 1 && c < ncols) code = rev ? read[n - c + 1] : read[c];
             const int r = q % H, hi = q / H;
             pcode[r / 8] |= (unsigned long long)code << (8 * (r % 8) + 3 * hi);
-            THRK(q) = thr_key(q, true);
+            if (!kRec && kTrack) THRK(q) = thr_key(q, true);
         }
 #pragma unroll
         for (int li = 0; li < 5; ++li) {
@@ -333,12 +334,12 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
         }
         // start rows: the gap-only row, identical for every path (uniform gap cost: A = c * gcost, z = 0)
 #pragma unroll
-        for (int q = 0; q < C; ++q) { minthrk = min(minthrk, THRK(q)); minplain = min(minplain, thr_key(q, false)); }
+        for (int q = 0; q < (kTrack ? C : 0); ++q) { minthrk = min(minthrk, thr_key(q, true)); minplain = min(minplain, thr_key(q, false)); }
         // packed 16-bit form of the thresholds for the lazy-key pretest of the register-resident rows: a key z << 16 | path
         // can reach a threshold only if z >= threshold >> 16 (INT32_MAX -> 32767: never; INT32_MIN -> -32768: always)
 #pragma unroll
         for (int r = 0; r < (kRec ? H : 1); ++r)
-            thz[kRec ? r : 0] = pack16(THRK(kRec ? r : 0) >> 16, THRK(kRec ? r + H : 0) >> 16);
+            thz[kRec ? r : 0] = pack16(thr_key(kRec ? r : 0, true) >> 16, thr_key(kRec ? r + H : 0, true) >> 16);
         minplain2 = pack16(minplain >> 16, minplain >> 16);
         int row0[H];
 #pragma unroll
@@ -363,14 +364,15 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
     unsigned long long cells = 0, done = 0;
     Cand* cand = !kRec && a.cand ? a.cand + (long long)rd * a.cand_cap : nullptr;
     uint32_t* dirs = a.dirs ? a.dirs + (long long)rd * a.dirs_stride : nullptr;
-    const bool track = a.track_best;
+    const bool track = kTrack && a.track_best;
 
     // Per-row epilogue on the packed keys bkey = value << 16 | path (non-members of the reference's matrices hold 0,
     // so a cell is usable iff its winner is a member: value > 0, or value == 0 and path > knm, or no non-member
     // exists -> bkey > kthr with kthr = knm (>= 0) or INT32_MIN).  ckey keeps the best usable key per column and the
     // row it came from; emission compares against thr << 16.
     // pre_done: the caller tracked the column maxima itself and already knows that some column reaches its threshold
-    auto row_end = [&](int i, int knm, const int (&bkey)[C], bool pre_done = false) {
+    // hit (with pre_done): this lane's packed pretest found a column at its threshold
+    auto row_end = [&](int i, int knm, const int (&bkey)[C], bool pre_done = false, bool hit = false) {
         // The column maxima ignore that rule (k_bound re-checks the recorded cell; an unusable cell has value <= 0 and
         // can only raise a non-positive maximum, which loosens thresholds, never tightens them); emissions apply it
         // (it removes most of the negative-valued cells the loose forward thresholds would let through).
@@ -394,31 +396,23 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
 #ifdef RG_SWEEP16_NOEMIT
         return;
 #endif
-        // tight thresholds (reverse sweep): most rows emit nothing; one max3 tree against the lane's lowest threshold
-        // decides for the whole wave whether the per-column test is needed
-        bool test = true;
-        if (tight && !pre_done) {
-            int mx = bkey[0];
-#pragma unroll
-            for (int q = 1; q < C; ++q) mx = max(mx, bkey[q]);
-            test = __any(mx >= (knm >= 0 ? minthrk : minplain));
-        }
         if (kRec) {
-            // One fixed-size record per (row, lane) with any column above its threshold (1 + C/4 16-byte stores);
-            // k_expand re-tests every key with the final bound and the exact member-winner rule, so no per-lane column
-            // mask is needed: the compares only feed a ballot (VALU compare + scalar OR per column).  thrk already
-            // holds the member rule's necessary condition (true key >= 1); the few rows every path visits (knm < 0:
-            // the rule is void there) test against the lane's lowest plain threshold instead (a superset).
-            unsigned long long has = 0;
-            if (test) {
-                if (knm >= 0) {
+            // One fixed-size record per (row, lane) with any column whose VALUE reaches its threshold (1 + C/4 16-byte
+            // stores): a saturating packed compare of the value halves against thz (the key thresholds >> 16, member rule's
+            // necessary condition included; the few rows every path visits — knm < 0: the rule is void there — against the
+            // lane's lowest plain threshold).  A superset of `key >= threshold`: k_expand re-tests every key with the final
+            // bound and the exact member-winner rule, so neither a per-lane column mask nor the key thresholds are kept.
+            bool lane_hit = hit;
+            if (!pre_done) {
+                int acc = -1;
 #pragma unroll
-                    for (int q = 0; q < C; ++q) has |= __ballot(bkey[q] >= THRK(q));
-                } else {
-#pragma unroll
-                    for (int q = 0; q < C; ++q) has |= __ballot(bkey[q] >= minplain);
+                for (int r = 0; r < H; ++r) {
+                    const int v2 = (int)__builtin_amdgcn_perm((unsigned)bkey[r + H], (unsigned)bkey[r], 0x07060302u);
+                    acc &= pk_sub_sat(v2, knm >= 0 ? thz[kRec ? r : 0] : minplain2);
                 }
+                lane_hit = ((unsigned)acc & 0x80008000u) != 0x80008000u;
             }
+            const unsigned long long has = __ballot(lane_hit);
             if (has) {
                 const unsigned before = __builtin_amdgcn_mbcnt_hi((unsigned)(has >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)has, 0u));
                 const unsigned pos = ncand + before;
@@ -431,6 +425,15 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
                 ncand += (unsigned)__popcll(has);
             }
             return;
+        }
+        // tight thresholds (reverse sweep): most rows emit nothing; one max3 tree against the lane's lowest threshold
+        // decides for the whole wave whether the per-column test is needed
+        bool test = true;
+        if (tight && !pre_done) {
+            int mx = bkey[0];
+#pragma unroll
+            for (int q = 1; q < C; ++q) mx = max(mx, bkey[q]);
+            test = __any(mx >= (knm >= 0 ? minthrk : minplain));
         }
         if (test) {
             // Cand entries go to k_search unfiltered: the exact member-winner rule (true key > knm) applies here
@@ -762,14 +765,15 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
 #pragma unroll
                         for (int r = 0; r < H; ++r) acc &= pk_sub_sat(bv[r], minplain2);
                     }
-                    if (__any(((unsigned)acc & 0x80008000u) != 0x80008000u)) {
+                    const bool lhit = ((unsigned)acc & 0x80008000u) != 0x80008000u;
+                    if (__any(lhit)) {
                         int tkey[C];         // (not bkey: see TAIL)
 #pragma unroll
                         for (int r = 0; r < H; ++r) {
                             tkey[r] = (int)(((unsigned)bv[r] << 16) | ((unsigned)K2[r] & 0xffffu));
                             tkey[r + H] = (int)(((unsigned)bv[r] & 0xffff0000u) | ((unsigned)K2[r] >> 16));
                         }
-                        row_end(ri, knm_row, tkey, true);
+                        row_end(ri, knm_row, tkey, true, lhit);
                     }
                 }
 #endif
@@ -914,12 +918,13 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
 #pragma unroll
                         for (int r = 0; r < H; ++r) acc &= pk_sub_sat(bv[r], minplain2);
                     }
-                    if (__any(((unsigned)acc & 0x80008000u) != 0x80008000u)) {      // some half >= its threshold
+                    const bool lhit = ((unsigned)acc & 0x80008000u) != 0x80008000u;
+                    if (__any(lhit)) {      // some half >= its threshold
                         int tkey[C];         // (not bkey: a row with several groups may be in progress around this run, see TAIL)
                         set_keys(tkey, rr[0], mk[0]);
 #pragma unroll
                         for (int kk = 1; kk < KRUN; ++kk) if (kk < nm) fold_keys(tkey, rr[kk], mk[kk]);
-                        row_end(ri, knm_row, tkey, true);
+                        row_end(ri, knm_row, tkey, true, lhit);
                     }
                 } else if (track) {
                     set_keys(bkey, rr[0], mk[0]);
@@ -1204,6 +1209,9 @@ void launch_sweep16(const SweepArgs& a_, int nreads, int C, hipStream_t s) {
     if (a.frec && !a.colmax_out) launch_sweep16_c<0, true>(a, nreads, C, s);
     else if (a.frec && !a.colarg_out) launch_sweep16_c<2, true>(a, nreads, C, s);     // maxima without their cells
     else if (a.frec) launch_sweep16_c<1, true>(a, nreads, C, s);
+    // -m 4 / -m 5: no best-member tracking at all (the variant below carries the column-maxima / threshold registers it
+    // would never use and spilled 57 of them)
+    else if (!a.track_best && !a.colmax_out && !a.cand) launch_sweep16_c<0, false>(a, nreads, C, s);
     else launch_sweep16_c<1, false>(a, nreads, C, s);
 }
 

@@ -27,7 +27,7 @@ def report(src, defines=()):
         err = subprocess.run(cmd, capture_output=True, text=True, cwd=CSRC).stderr
     kernels, cur = [], None
     for line in err.splitlines():
-        m = re.search(r"remark: [^:]+:\d+:\d+:\s+(.*?)\s+\[-Rpass-analysis", line)
+        m = re.search(r"remark:\s+(.*?)\s+\[-Rpass-analysis", line)
         if not m:
             continue
         body = m.group(1)
@@ -53,7 +53,7 @@ def main():
         for k in report(f, defs):
             print("%-52s VGPRs %3d  spill V %3d S %3d  scratch %4d B/lane  occupancy %d  SGPRs %3d  LDS %d" % (
                 k["name"][:52], k.get("VGPRs", -1), k.get("VGPRs Spill", -1), k.get("SGPRs Spill", -1),
-                k.get("ScratchSize [bytes/lane]", -1), k.get("Occupancy [waves/SIMD]", -1), k.get("SGPRs", -1), k.get("LDS Size [bytes/block]", -1)))
+                k.get("ScratchSize [bytes/lane]", -1), k.get("Occupancy [waves/SIMD]", -1), k.get("TotalSGPRs", -1), k.get("LDS Size [bytes/block]", -1)))
 
 
 if __name__ == "__main__":
