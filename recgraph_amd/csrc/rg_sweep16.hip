@@ -180,6 +180,13 @@ struct RowOps16 {
 #ifndef RG_SWEEP16_RUNWAIT
 #define RG_SWEEP16_RUNWAIT 1
 #endif
+#ifndef RG_SWEEP16_CHAIN
+// chained register runs: next run's loads before this run's stores (see CHAINED RUNS).  1: in the -m 4 / -m 5 variant only
+// (config 4: 17.2 -> 14.8 ms per 4096-read sweep); 2: in the record variants of -m 8 too — measured neutral in the forward
+// sweep (37.4 vs 37.5 ms, and the variant spills 48 registers with it) and 0.7 ms SLOWER in the reverse one (34.3 vs
+// 33.6): their runs end in tails, whose epilogue separates the loads from the stores anyway (profiles/r04_notes.md)
+#define RG_SWEEP16_CHAIN 1
+#endif
 #ifndef RG_SWEEP16_KRUN_REV
 #define RG_SWEEP16_KRUN_REV RG_SWEEP16_KRUN     // the variant without column maxima (reverse sweep of the record pipeline)
 #endif
@@ -836,16 +843,24 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
             // ---- inner rows of a segment with a small group: the same paths, one group, predecessor = previous row.
             // Their rows stay in registers for the whole run: no row load/store latency, no HBM traffic.  The group
             // alpha of an inner row is its lowest path (alphas[row] == alphas[pred], rg_graph.cpp) = member 0.
+            // (CHAINED RUNS, RG_SWEEP16_CHAIN: when the record behind a run — behind its tail — starts another register run on
+            // OTHER paths, the block goes on with it instead of returning to the record loop, and it loads the next run's rows
+            // BEFORE it stores this run's: gfx9 has one vmcnt for loads and stores, so a wait for freshly loaded rows also
+            // drains every store issued before them — in the old order (stores, next record, loads, wait) that was the whole
+            // run's rows on every run boundary.  Here the wait covers loads only and the stores drain behind the next run's
+            // arithmetic.  rnm / rgm / mk: the run in progress.)
+            int rnm = nm;
+            unsigned long long rgm = gmask;
             int mk[KRUN > 0 ? KRUN : 1];
             {
-                unsigned long long tm = gmask;
+                unsigned long long tm = rgm;
 #pragma unroll
                 for (int kk = 0; kk < KRUN; ++kk) { mk[kk] = tm ? kbase + __builtin_ctzll(tm) : 0; tm = tm ? (tm & (tm - 1)) : 0; }
             }
             int rr[KRUN > 0 ? KRUN : 1][H];
 #pragma unroll
             for (int kk = 0; kk < KRUN; ++kk)
-                if (kk < nm) {
+                if (kk < rnm) {
 #pragma unroll
                     for (int r = 0; r < H; ++r) rr[kk][r] = s[r] ^ (kk + t);     // (only what the timing-only builds without loads keep)
 #ifndef RG_SWEEP16_KRUNNOLD
@@ -872,24 +887,26 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
             }
             int ri = i, rli = li, rslot = slot, rw1 = w1, rfl = 7;
             bool tail = false;
+            for (;;) {          // (chained runs)
+            tail = false; rfl = 7;
             while (true) {
                 const int g_i = __builtin_amdgcn_readfirstlane(sct[rli * 6 + GAP]);
                 const int g0 = a.semi ? 0 : g_i;
                 load_steps(rli);
                 unsigned umask;
                 RowOps16<C>::alpha(rr[0], s, g_i, g0, lane, MU, ML, umask, lmask, src);
-                if (nm > 1) RowOps16<C>::select_steps(SEL, s, MU, g_i, g0, lane);
+                if (rnm > 1) RowOps16<C>::select_steps(SEL, s, MU, g_i, g0, lane);
                 if (dirs) store_dirs(rslot, umask, lmask);
 #pragma unroll
                 for (int kk = 1; kk < KRUN; ++kk)
-                    if (kk < nm) RowOps16<C>::member(rr[kk], SEL, lane, MU, ML, lmask, src);
-                cells += (unsigned long long)nm;
-                done += (unsigned long long)nm;
+                    if (kk < rnm) RowOps16<C>::member(rr[kk], SEL, lane, MU, ML, lmask, src);
+                cells += (unsigned long long)rnm;
+                done += (unsigned long long)rnm;
                 if (kRec && kColmax != 1 && tail) {
                     if (track) {
                         if (rfl & F_FIRST) set_keys(bkey, rr[0], mk[0]); else fold_keys(bkey, rr[0], mk[0]);
 #pragma unroll
-                        for (int kk = 1; kk < KRUN; ++kk) if (kk < nm) fold_keys(bkey, rr[kk], mk[kk]);
+                        for (int kk = 1; kk < KRUN; ++kk) if (kk < rnm) fold_keys(bkey, rr[kk], mk[kk]);
                     }
                 } else if (track && kRec && kColmax != 1) {
                     // LAZY KEYS (rows in registers): the best VALUE per column is a packed maximum over the members (8
@@ -901,7 +918,7 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
                     for (int r = 0; r < H; ++r) bv[r] = rr[0][r];
 #pragma unroll
                     for (int kk = 1; kk < KRUN; ++kk)
-                        if (kk < nm) {
+                        if (kk < rnm) {
 #pragma unroll
                             for (int r = 0; r < H; ++r) bv[r] = pk_max(bv[r], rr[kk][r]);
                         }
@@ -923,18 +940,18 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
                         int tkey[C];         // (not bkey: a row with several groups may be in progress around this run, see TAIL)
                         set_keys(tkey, rr[0], mk[0]);
 #pragma unroll
-                        for (int kk = 1; kk < KRUN; ++kk) if (kk < nm) fold_keys(tkey, rr[kk], mk[kk]);
+                        for (int kk = 1; kk < KRUN; ++kk) if (kk < rnm) fold_keys(tkey, rr[kk], mk[kk]);
                         row_end(ri, knm_row, tkey, true, lhit);
                     }
                 } else if (track) {
                     set_keys(bkey, rr[0], mk[0]);
 #pragma unroll
-                    for (int kk = 1; kk < KRUN; ++kk) if (kk < nm) fold_keys(bkey, rr[kk], mk[kk]);
+                    for (int kk = 1; kk < KRUN; ++kk) if (kk < rnm) fold_keys(bkey, rr[kk], mk[kk]);
                     row_end(ri, ((rw1 >> 20) & 511) - 1, bkey);
                 }
                 if (semi_end) {
 #pragma unroll
-                    for (int kk = 0; kk < KRUN; ++kk) if (kk < nm) end_fold(mk[kk], ri, rr[kk]);
+                    for (int kk = 0; kk < KRUN; ++kk) if (kk < rnm) end_fold(mk[kk], ri, rr[kk]);
                     end_row_done(ri);
                 }
                 ++t;
@@ -945,24 +962,69 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
                 if (!to_tail && (nf != 7 || ((pw >> 26) & 63) == 0)) break;   // next record starts another segment (a HEAD or a general row)
                 // ... or is an inner row of ANOTHER segment: in a split table the rows of a segment whose first row had all
                 // its groups moved away as tails can follow an unrelated run (found by test_random_dag_graphs)
-                if (peek_gm(t) != gmask) break;
+                if (peek_gm(t) != rgm) break;
                 int nw0, nw1;
                 unsigned long long ngm;
                 fetch(t, nw0, nw1, ngm);
                 ri = nw0 & 0xfffff; rli = (nw0 >> 20) & 7; rslot = nw1 & 0xfffff; rw1 = nw1;
                 tail = to_tail; rfl = nf;
             }
+            // ---- the run (and its tail) is over: rows in rr, t = the next record
+            // the tail's row: its epilogue when this was its last group
+            if (tail) {
+                if (semi_end && (rfl & F_LAST)) end_row_done(ri);
+                if (track && (rfl & F_LAST)) row_end(ri, ((rw1 >> 20) & 511) - 1, bkey);
+            }
+            bool chain = false;
+            unsigned long long gm2 = 0;
+            if ((RG_SWEEP16_CHAIN == 2 || (RG_SWEEP16_CHAIN == 1 && !kTrack)) && !kWide && !semi_end && t < nsteps) {
+                const int pw = peek_w0(t);
+                // a HEAD (4 alone) or an inner row (7) with rows left starts a register / gather run; <= KRUN paths: a register run
+                if ((((pw >> 23) & 7) & F_INNER) && ((pw >> 26) & 63) != 0) {
+                    gm2 = peek_gm(t);
+                    chain = __popcll(gm2) <= KRUN && (gm2 & rgm) == 0;
+                }
+            }
+            if (!chain) break;
+            int rn[KRUN > 0 ? KRUN : 1][H];
+            int mk2[KRUN > 0 ? KRUN : 1];
+            {
+                unsigned long long tm = gm2;
+#pragma unroll
+                for (int kk = 0; kk < KRUN; ++kk) { mk2[kk] = tm ? kbase + __builtin_ctzll(tm) : 0; tm = tm ? (tm & (tm - 1)) : 0; }
+#pragma unroll
+                for (int kk = 0; kk < KRUN; ++kk)
+                    if (kk < __popcll(gm2)) RG_ROW_LD(mk2[kk], rn[kk]);
+            }
+            __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): the next run's rows (every older store is long done)
+#pragma unroll
+            for (int kk = 0; kk < KRUN; ++kk)
+                if (kk < rnm) RG_ROW_ST(mk[kk], rr[kk]);
+            rnm = __popcll(gm2);
+            rgm = gm2;
+#pragma unroll
+            for (int kk = 0; kk < KRUN; ++kk) {
+                mk[kk] = mk2[kk];
+#pragma unroll
+                for (int r = 0; r < H; ++r) rr[kk][r] = rn[kk][r];
+            }
+            {
+                int nw0, nw1;
+                unsigned long long ngm;
+                fetch(t, nw0, nw1, ngm);
+                ri = nw0 & 0xfffff; rli = (nw0 >> 20) & 7; rslot = nw1 & 0xfffff; rw1 = nw1;
+            }
+            }                   // (chained runs)
             pf_sink ^= pf_next;
 #ifdef RG_SWEEP16_KRUNNOST
 #pragma unroll
-            for (int kk = 0; kk < KRUN; ++kk) if (kk < nm) { for (int r = 0; r < H; ++r) pf_sink ^= rr[kk][r]; }      // (timing-only: no run-end stores)
+            for (int kk = 0; kk < KRUN; ++kk) if (kk < rnm) { for (int r = 0; r < H; ++r) pf_sink ^= rr[kk][r]; }      // (timing-only: no run-end stores)
 #else
 #pragma unroll
             for (int kk = 0; kk < KRUN; ++kk)
-                if (kk < nm) RG_ROW_ST(mk[kk], rr[kk]);
+                if (kk < rnm) RG_ROW_ST(mk[kk], rr[kk]);
 #endif
-            if (!tail) continue;
-            e_i = ri; e_w1 = rw1; e_flags = rfl; e_adv = false;     // the tail's row: its epilogue below when this was its last group
+            continue;           // (a tail's epilogue ran above)
         } else {
         const int g_i = __builtin_amdgcn_readfirstlane(sct[li * 6 + GAP]);
         const int g0 = a.semi ? 0 : g_i;

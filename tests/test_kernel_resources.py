@@ -1,0 +1,24 @@
+"""CPU: the headline variants of k_sweep16 use no scratch.  hipcc cross-compiles gfx950 without a GPU;
+`-Rpass-analysis=kernel-resource-usage` reports registers, spills and scratch per kernel (tools/kernel_resources.py)."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_headline_sweep_variants_use_no_scratch():
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import kernel_resources
+    ks = {k["name"]: k for k in kernel_resources.report("rg_sweep16.hip")}
+    headline = ["rg::k_sweep16<16, 2, true, false>",     # -m 8 forward: records + packed column maxima
+                "rg::k_sweep16<16, 0, true, false>",     # -m 8 reverse: records
+                "rg::k_sweep16<16, 0, false, false>"]    # -m 4 / -m 5: no tracking at all
+    for name in headline:
+        k = ks[name]
+        assert k["ScratchSize [bytes/lane]"] == 0 and k["VGPRs Spill"] == 0, (name, k)
+        assert k["VGPRs"] <= 256 and k["Occupancy [waves/SIMD]"] >= 2, (name, k)
+    # the narrower instantiations of the same variants (shorter reads) do not spill either
+    for c in (4, 8):
+        for v in ("2, true, false", "0, true, false", "0, false, false"):
+            k = ks["rg::k_sweep16<%d, %s>" % (c, v)]
+            assert k["ScratchSize [bytes/lane]"] == 0, (c, v, k)
