@@ -82,6 +82,15 @@ def test_c5_m8_properties(oracle, c5):
     _, _, exp = og.bench_text(oracle.M8_ABS, reads, nthreads=min(os.cpu_count() or 1, 96), name_prefix="r", idx_base=1)
     bad = [i for i in range(len(reads)) if texts[i].encode() != exp[i]]
     assert not bad, (len(bad), bad[:5], texts[bad[0]][-200:], exp[bad[0]][-200:])
+    # the same reads with a ZERO speculation margin (k_verify sends every read whose optimum is not its picked path's score
+    # through the second pass with the provable bound) and with the plain step tables: the same bytes
+    for name, val in (("spec_margin", 0), ("no_split", 1)):
+        try:
+            api.set_option(name, val)
+            again, _ = api.align_batch(g, reads[:64], names[:64], mode=api.MODE_RECOMBINATION)
+        finally:
+            api.set_option(name, 160 if name == "spec_margin" else 0)
+        assert again == texts[:64], name
 
 
 def test_c5_huge_recombination_cost_equals_best_single_path(c5):

@@ -291,6 +291,65 @@ def test_random_dag_graphs(oracle):
         _check(oracle, g.gfa(), rd[:5], api.MODE_RECOMBINATION, oracle.M8_ABS, R=0, r=0.1, B=0.8)
 
 
+def test_random_dag_graphs_in_every_switch_family(oracle):
+    """the round-3 split-table bug produced wrong scores on random-walk graphs only, while every test family
+    that exercises a kernel switch ran on block-shaped haplotype graphs.  Here random-walk graphs (nested / overlapping
+    bubbles, one-row segments, proper-subset groups) go through EVERY switch of the pathwise pipeline — i32 sweep, Cand-list
+    emission, three sweeps, speculation off / zero margin / forced second pass, no gather, no split, small chunks, and
+    pairs of them — in all four pathwise modes: byte-identical to the default, which equals the oracle."""
+    from recgraph_amd import api, synth
+    cases = ((150, 12, 301, {"max_jump": 3, "max_seg": 8}), (110, 32, 302, {"max_jump": 5, "max_seg": 12, "similar": 0.7}),
+             (240, 5, 303, {"max_jump": 2, "max_seg": 4}))
+    switches = (("sweep_i32", 1), ("no_frec", 1), ("three_sweeps", 1), ("no_spec", 1), ("spec_margin", 0), ("spec_margin", -1000000),
+                ("no_gather", 1), ("no_split", 1), ("chunk_reads", 5))
+    pairs = ((("three_sweeps", 1), ("sweep_i32", 1)), (("no_split", 1), ("no_gather", 1)), (("spec_margin", -1000000), ("chunk_reads", 4)),
+             (("no_frec", 1), ("no_spec", 1)))
+    defaults = {"spec_margin": 160}
+    for nseg, P, seed, kw in cases:
+        g = synth.random_dag_graph(nseg, P, seed=seed, **kw)
+        plen = min(len(g.path_sequence(k)) for k in range(P))
+        rd = synth.haplotype_reads(g, 12, length=plen, seed=seed + 1, mosaic_frac=0.7) + [g.path_sequence(P - 1), g.path_sequence(1)[:plen * 2 // 3], "ACGT" * 4]
+        gg = api.Graph.from_gfa_text(g.gfa())
+        names = ["r%d" % i for i in range(len(rd))]
+        for mode, om in ((api.MODE_RECOMBINATION, oracle.M8_ABS), (api.MODE_PATHWISE, oracle.M4_ABS),
+                         (api.MODE_RECOMBINATION_SEMI, oracle.M9_ABS), (api.MODE_PATHWISE_SEMI, oracle.M5_ABS)):
+            base = _check(oracle, g.gfa(), rd, mode, om)
+            for combo in [(sw,) for sw in switches] + list(pairs):
+                try:
+                    for name, val in combo:
+                        api.set_option(name, val)
+                    texts, _ = api.align_batch(gg, rd, names, mode=mode)
+                finally:
+                    for name, _ in combo:
+                        api.set_option(name, defaults.get(name, 0))
+                assert texts == base, (nseg, P, mode, combo)
+        for R, r, B in ((0, 0.1, 0.8), (9, 0.5, 1.0), (1, 0.0, 0.5)):
+            _check(oracle, g.gfa(), rd[:8], api.MODE_RECOMBINATION, oracle.M8_ABS, R=R, r=r, B=B)
+
+
+def test_kilobase_reads_on_nested_bubbles(oracle):
+    """Reads of 1 kbp and more (the 16-columns-per-lane kernels of the headline configuration) on random-walk graphs with
+    32 and 60 paths — the shape the block-built config-5 graph does not have — against the absolute-form oracle, default
+    pipeline, a zero speculation margin, and the plain step tables."""
+    from recgraph_amd import api, synth
+    for nseg, P, seed, kw in ((620, 32, 311, {"max_jump": 4, "max_seg": 10}), (560, 60, 312, {"max_jump": 3, "max_seg": 9, "similar": 0.6})):
+        g = synth.random_dag_graph(nseg, P, seed=seed, **kw)
+        plen = min(len(g.path_sequence(k)) for k in range(P))
+        assert 1000 <= plen <= 2047, plen
+        rd = synth.haplotype_reads(g, 5, length=plen, seed=seed + 1, mosaic_frac=0.8) + [g.path_sequence(P - 1)[:plen]]
+        gg = api.Graph.from_gfa_text(g.gfa())
+        names = ["r%d" % i for i in range(len(rd))]
+        base = _check(oracle, g.gfa(), rd, api.MODE_RECOMBINATION, oracle.M8_ABS)
+        _check(oracle, g.gfa(), rd[:3], api.MODE_PATHWISE, oracle.M4_ABS)
+        for name, val in (("spec_margin", 0), ("no_split", 1), ("no_gather", 1)):
+            try:
+                api.set_option(name, val)
+                texts, _ = api.align_batch(gg, rd, names, mode=api.MODE_RECOMBINATION)
+            finally:
+                api.set_option(name, 160 if name == "spec_margin" else 0)
+            assert texts == base, (P, name)
+
+
 def test_three_sweep_pipeline(oracle):
     """The -m 8 / -m 9 pipeline the driver takes when a gap entry is positive (no path-0 lower bound for the forward
     thresholds: forward column maxima first, reverse sweep, forward again) or on request (RG_THREE_SWEEPS), with the

@@ -18,11 +18,11 @@ done
 for cfg in $CFGS; do
   c=$(echo $cfg | tr A-Z a-z)
   B=""; [ $cfg = C5 ] && B="--batch 2048"; [ $cfg = C4 ] && B="--batch 2048"
-  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$c -o $TAG -- python3 bench.py --config $cfg --steps 4 --warmup 1 --no-cpu --handles 1 > $O/${TAG}_${c}_bench_under_rocprof.json 2>> $O/bench.err
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$c -o $TAG -- python3 bench.py --config $cfg --steps 4 --warmup 1 --no-cpu --no-strong --no-probe --handles 1 > $O/${TAG}_${c}_bench_under_rocprof.json 2>> $O/bench.err
   i=0
   for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SMEM" "SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_SALU SQ_WAVES"; do
     i=$((i+1))
-    timeout 600 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $O/pmc_${c}_$i -o p -- python3 bench.py --config $cfg $B --steps 2 --warmup 0 --no-cpu --handles 1 > $O/pmc_${c}_bench.json 2> $O/pmc_${c}_$i.log
+    timeout 600 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $O/pmc_${c}_$i -o p -- python3 bench.py --config $cfg $B --steps 2 --warmup 0 --no-cpu --no-strong --no-probe --handles 1 > $O/pmc_${c}_bench.json 2> $O/pmc_${c}_$i.log
   done
 done
 python3 tools/make_counters.py $O $TAG
