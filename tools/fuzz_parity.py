@@ -30,8 +30,8 @@ while time.time() < t_end and not fails:
     if plen > 2047:
         P = min(P, 5)        # striped long reads: keep the oracle's L x n x P affordable
     rows = int(plen * rng.uniform(1.5, 6.0))
-    if it % 3 == 2 and plen <= 1300:
-        # every third configuration: random walks through segments in id order (nested / overlapping bubbles) instead of
+    if it % 2 == 1 and plen <= 1300:
+        # every second configuration: random walks through segments in id order (nested / overlapping bubbles) instead of
         # allele blocks; the shortest path sets the read length
         sg = synth.random_dag_graph(max(8, int(plen / rng.uniform(1.5, 4.0))), P, seed=int(rng.integers(1, 10**6)),
                                     max_seg=int(rng.integers(2, 14)), max_jump=int(rng.integers(2, 7)), similar=float(rng.uniform(0, 0.9)))
