@@ -396,13 +396,18 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
         gaps_nonpos = gaps_nonpos && p.scores[x * 6 + 5] <= 0 && p.scores[5 * 6 + x] <= 0;
         for (int y = 0; y < 5; ++y) maxmatch = std::max(maxmatch, p.scores[x * 6 + y]);
     }
-    const bool two_sweep = mode == RG_MODE_RECOMBINATION && gaps_nonpos && nwv == 1 && !opt.three_sweeps;
+    // (striped long reads, nwv > 1, take it too since round 4: k_opt0_striped gives them the forward bound)
+    const bool two_sweep = mode == RG_MODE_RECOMBINATION && gaps_nonpos && !opt.three_sweeps;
     // forward emissions of the two-sweep pipeline are loose (threshold from the path-0 score): k_sweep16 writes them as
     // (row, lane) records that k_expand filters with the final bound; k_sweep writes plain Cand entries
     const bool use_rec = two_sweep && use16 && !opt.no_frec;
     // speculative forward bound (PickArgs in rg_path_kernels.hpp): checked by k_verify, failed reads aligned again below
-    const bool spec = use_rec && allow_spec && !semi && P <= 64 && !opt.no_spec;
-    const int spec_margin = opt.spec_margin;
+    // (long reads emit Cand entries, not records: without the speculation their forward lists would hold every cell within
+    // ~(seed - path-0 score) / 10 columns of a diagonal — millions per read at 5 kbp)
+    const bool spec = (use_rec || (two_sweep && nwv > 1)) && allow_spec && !semi && P <= 64 && !opt.no_spec;
+    // (a follower path's sink value lies below its own NW optimum — measured up to 72 at 1 kbp — and the gap grows with the
+    // read: long reads scale the margin with their length, or every read would fail the check and run again)
+    const int spec_margin = nwv > 1 ? opt.spec_margin * ((max_n + 999) / 1000) : (int)opt.spec_margin;
     const int recw = 4 + C;
     if (w.fcap == 0) { w.fcap = (two_sweep && !use_rec) ? 1u << 20 : 1u << 15; w.rcap = use_rec ? 1u << 16 : 1u << 19; w.frec_cap = 1u << 16; w.rrec_cap = 1u << 15; }   // (reverse records at config 5: mean 2.7 k, largest read of a 4096-read tile 21-25 k)
     stats.clear();
@@ -480,7 +485,7 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
             TIMED(T, "k_seed", launch_seed(se, stream));
         } else {
             if (two_sweep) {
-                Opt0Args oa{gd, sa.sc, d_reads, off, bad, w.fpoff.p, w.fprow.p, w.lb.p, semi ? 1 : 0, nullptr, 0};
+                Opt0Args oa{gd, sa.sc, d_reads, off, bad, w.fpoff.p, w.fprow.p, w.lb.p, semi ? 1 : 0, nullptr, 0, nwv};
                 if (spec) {
                     PickArgs pa{d_reads, off, bad, w.kmer_keys.p, w.kmer_masks.p, w.kmer_mask, P, w.pick.p};
                     TIMED(T, "k_pick", launch_pick(pa, chunk, stream));

@@ -126,6 +126,7 @@ struct Opt0Args {
     int semi;
     const int* pick;           // ... or against path pick[rd], minus `margin`: the SPECULATIVE bound (see k_pick)
     int margin;
+    int nwv;                   // column stripes per read (> 1: k_opt0_striped)
 };
 
 // Speculative lower bound of the -m 8 search maximum.  The forward sweep of the two-sweep pipeline emits every cell that

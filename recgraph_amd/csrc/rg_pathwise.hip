@@ -571,6 +571,69 @@ __global__ __launch_bounds__(64) void k_opt0(Opt0Args a) {
     if (lane == ln) a.lb[rd] = (a.semi ? semibest : v) - (a.pick ? a.margin : 0);
 }
 
+// The same for reads longer than 2047 bases: a.nwv waves per read, wave w owns columns [w * 64 * C, (w + 1) * 64 * C) and runs
+// the path's rows on its stripe a few steps behind wave w - 1 (StripeFifo / StripeIO as in k_sweep<C, true, true>: per row
+// the old value of the left stripe's last column and the running z-maximum).  Uniform read-gap cost (checked by the
+// driver for every striped batch).  This is what opens the two-sweep pipeline — and the speculative bound — for long
+// reads, which ran three i32 sweeps until round 4.
+template <int C>
+__global__ __launch_bounds__(512) void k_opt0_striped(Opt0Args a) {
+    const int rd = blockIdx.x;
+    const int wl = (int)(threadIdx.x & (WAVE - 1)), wv = (int)(threadIdx.x >> 6), nwv = a.nwv;
+    const int lane = wv * WAVE + wl;
+    const PathGraphDev& g = a.g;
+    const long long ro = a.read_off[rd];
+    const int n = (int)(a.read_off[rd + 1] - ro);
+    if (a.bad[rd] || n + 1 > nwv * C * WAVE) { if (threadIdx.x == 0) a.lb[rd] = INT32_MIN / 2; return; }
+    const uint8_t* read = a.reads + ro - 1;
+    const int ncols = n + 1, GAP = 5;
+    __shared__ int sct[36];
+    __shared__ int fifo_lds[8 * (FIFO_WORDS + 2)];
+    if (lane < 36) sct[lane] = a.sc.t[lane];
+    constexpr int QW = FIFO_WORDS + 2;
+    if (lane < nwv) { fifo_lds[lane * QW + FIFO_WORDS] = 0; fifo_lds[lane * QW + FIFO_WORDS + 1] = 0; }
+    StripeFifo fin{fifo_lds + wv * QW, (unsigned*)(fifo_lds + wv * QW + FIFO_WORDS), (unsigned*)(fifo_lds + wv * QW + FIFO_WORDS + 1), 0u};
+    const int nx = wv + 1 < nwv ? wv + 1 : 0;
+    StripeFifo fout{fifo_lds + nx * QW, (unsigned*)(fifo_lds + nx * QW + FIFO_WORDS), (unsigned*)(fifo_lds + nx * QW + FIFO_WORDS + 1), 0u};
+    __syncthreads();
+    const int gcost = sct[GAP];
+    int er[C], row[C], s[C];
+    const int GP[1] = {0};
+#pragma unroll
+    for (int q = 0; q < C; ++q) {
+        const int c = lane * C + q;
+        er[q] = (c >= 1 && c < ncols) ? read[c] : 4;
+        row[q] = c < ncols ? c * gcost : NEG;               // the gap-only start row
+    }
+    const int pk = a.pick ? a.pick[rd] : 0;      // (only path 0's score is a provable bound: see PickArgs)
+    const int beg = a.fpoff[pk], cnt = a.fpoff[pk + 1] - beg;
+    int semibest = NEG;
+    StripeIO io{NEG, NEG, NEG, NEG};
+    for (int t = 0; t < cnt; ++t) {
+        const int i = a.fprow[beg + t];
+        const int li = g.lnz[i];
+        const int g_i = sct[li * 6 + GAP];
+#pragma unroll
+        for (int q = 0; q < C; ++q) s[q] = sct[li * 6 + er[q]];
+        io.in_prev = NEG; io.in_carry = NEG;
+        if (wv > 0) fin.pop2(io.in_prev, io.in_carry, wl);
+        unsigned dmask, lmask;
+        int src;
+        RowOps<C, true, true>::alpha(row, s, GP, gcost, g_i, a.semi ? 0 : g_i, lane, ncols, dmask, lmask, src, wl, &io);
+        if (wv + 1 < nwv) fout.push2(io.out_prev, io.out_carry, wl);
+        if (a.semi) {   // free end row: best last-column value over the rows of the path
+            int v = NEG;
+#pragma unroll
+            for (int q = 0; q < C; ++q) if (q == n % C) v = row[q];
+            semibest = max(semibest, v);
+        }
+    }
+    int v = NEG;
+#pragma unroll
+    for (int q = 0; q < C; ++q) if (q == n % C) v = row[q];
+    if (lane == n / C) a.lb[rd] = (a.semi ? semibest : v) - (a.pick ? a.margin : 0);
+}
+
 // ---------------------------------------------------------------------------------
 // Path vote for the speculative bound (PickArgs): one wave per read samples up to 256 12-mers of the read, looks each up
 // in the table of the paths' 12-mers and gives one vote to every path that contains it; lane b counts the votes of path b.
@@ -1190,6 +1253,14 @@ void launch_seed(const SeedArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(k_seed, dim3((a.nreads + 63) / 64), dim3(64), 0, s, a);
 }
 void launch_opt0(const Opt0Args& a, int nreads, int C, hipStream_t s) {
+    if (a.nwv > 1) {
+        switch (C) {
+            case 8: hipLaunchKernelGGL((k_opt0_striped<8>), dim3(nreads), dim3(64 * a.nwv), 0, s, a); break;
+            case 16: hipLaunchKernelGGL((k_opt0_striped<16>), dim3(nreads), dim3(64 * a.nwv), 0, s, a); break;
+            default: hipLaunchKernelGGL((k_opt0_striped<32>), dim3(nreads), dim3(64 * a.nwv), 0, s, a); break;
+        }
+        return;
+    }
     switch (C) {
         case 4: hipLaunchKernelGGL((k_opt0<4>), dim3(nreads), dim3(64), 0, s, a); break;
         case 8: hipLaunchKernelGGL((k_opt0<8>), dim3(nreads), dim3(64), 0, s, a); break;

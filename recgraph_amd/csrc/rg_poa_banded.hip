@@ -47,6 +47,8 @@ enum : uint32_t { PD_O = 0, PD_D = 1, PD_d = 2, PD_L = 3, PD_U = 4 };
 // kGap = false: scalar -m 0;  kGap = true: -m 2.
 // Arena planes per read (cap_cells each): m | y (m2) ; path words: w0 = pred<<3 | dir | X<<31, w1 = predY<<1 | Y.
 template <bool kGap, bool kLdsRead>
+// (8 waves per SIMD — 64 VGPRs — were tried like in rg_poa.hip: 6 registers spill and config 3 loses 2-8 %: not bound by
+// occupancy either.  profiles/r04_notes.md)
 __global__ __launch_bounds__(64) void k_poa_banded(PoaArgs a) {
     const int slot = blockIdx.x;              // arena slot of this launch
     const int rd = a.read_base + slot;        // read of the batch
