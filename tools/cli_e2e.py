@@ -9,6 +9,7 @@ line: wall seconds of the whole process (interpreter start, FASTA parse, graph b
 streaming engine, GAF text to the file), reads/s, bytes written, the CLI's own "Done in" line."""
 import json
 import os
+import resource
 import subprocess
 import sys
 import time
@@ -40,8 +41,12 @@ with open(out, "wb") as fo:
     p = subprocess.run([sys.executable, "-m", "recgraph_amd.cli", fa, gfa, "-m", "8", "-R", "4", "-r", "0.1", "-B", "1", "--timing"], stdout=fo,
                        stderr=subprocess.PIPE, cwd=ROOT)
 wall = time.time() - t0
+# peak resident set of the CLI process (the only child so far): the stream is bounded (--queue / --hold-mb) and the file is
+# fed block by block, so it must not grow with the read set
+rss_mb = resource.getrusage(resource.RUSAGE_CHILDREN).ru_maxrss / 1024.0
 lines = sum(1 for _ in open(out, "rb"))
 print(json.dumps({"what": "python -m recgraph_amd.cli reads.fa graph.gfa -m 8 -R 4 -r 0.1 -B 1 > out.gaf (BASELINE configs[4])",
                   "reads": n, "wall_s": round(wall, 3), "reads_per_s": round(n / wall, 1), "gaf_lines": lines,
                   "gaf_bytes": os.path.getsize(out), "fasta_bytes": os.path.getsize(fa), "rc": p.returncode,
+                  "cli_peak_rss_mb": round(rss_mb, 1),
                   "stderr": p.stderr.decode()[-1500:], "fasta_generation_s": round(gen_s, 1)}))
