@@ -70,13 +70,6 @@ __device__ __forceinline__ int dpp_shr1(int v, int identity) {
     return r;
 }
 
-// value of lane+1 (lane 63 gets `identity`): wave_shl:1, pinned like dpp_shr1
-__device__ __forceinline__ int dpp_shl1(int v, int identity) {
-    int r = dpp_mov<0x130, 0xf>(identity, v);
-    asm volatile("" : "+v"(r));
-    return r;
-}
-
 // (a lane without a source keeps its own value whatever the fill is; INT32_MIN is the identity the compiler's DPP combiner
 // knows for a signed max, so each step becomes ONE v_max_i32_dpp instead of constant + v_mov_dpp + v_max)
 __device__ __forceinline__ int dpp_incl_max(int v, int /*identity*/) {

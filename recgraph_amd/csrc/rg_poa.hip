@@ -215,24 +215,9 @@ __global__ __launch_bounds__(64, RG_POA_WAVES) void k_m0_simd(PoaArgs a) {
                 // columns cb-1 .. cb+63 of the row above lie in at most two of its chunks: k0 and k0 + 1
                 const int k0 = (cb - 1 - p_start) >> 6;             // arithmetic shift: -1 when cb - 1 < p_start
                 const int lo = pv_chunk(k0 < 0 ? 0 : k0), hi = pv_chunk(k0 + 1 < KC ? k0 + 1 : KC - 1);
-                // Column cb + lane of the row above sits at register index e + lane.  Along an alignment the band moves by
-                // one column per row or not at all, i.e. e = 1 or 0 (mod 64): the value is then the lane's own register or
-                // its right neighbour's (one DPP move + the first lane of the next chunk) instead of two ds_bpermute round
-                // trips per chunk; any other shift takes the general shuffles.
-                const int e = cb - p_start;
-                if (e >= 0 && (e & (WAVE - 1)) == 0) {
-                    const int own = pv_chunk(min(e >> 6, KC - 1));
-                    bu = (c >= p_start && c < p_right) ? own : cx.min_score;
-                } else if (e >= 0 && (e & (WAVE - 1)) == 1) {
-                    const int ka = e >> 6;
-                    const int ca = pv_chunk(min(ka, KC - 1)), cn = pv_chunk(min(ka + 1, KC - 1));
-                    const int nx0 = __builtin_amdgcn_readlane(cn, 0);
-                    const int sh = dpp_shl1(ca, 0);
-                    const int v = lane == WAVE - 1 ? nx0 : sh;
-                    bu = (c >= p_start && c < p_right) ? v : cx.min_score;
-                } else {
-                    bu = prev_at(c, k0, lo, hi);                  // (the shuffles inside must run with all lanes enabled)
-                }
+                // (tried in round 4: the lane's own register / its right neighbour's through one DPP move when the band moved by
+                // 0 / 1 columns — the common cases — instead of the two shuffles: 8.55 vs 8.35 ms per 10 000 reads, no gain)
+                bu = prev_at(c, k0, lo, hi);                      // (the shuffles inside must run with all lanes enabled)
                 // m[i-1][c-1] is the lane to the left's m[i-1][c]; lane 0 takes column cb - 1 straight from the registers
                 // of the row above (a wave-uniform position: v_readlane, no second pair of shuffles)
                 const int i0 = cb - 1 - p_start;
