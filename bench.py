@@ -48,6 +48,9 @@ BYTES_PER_CELL_UPDATE = {0: 12, 2: 32, 4: 8, 8: 12}   # SURVEY §8d algorithmic 
 HBM_PEAK_GBS = 8000.0                                 # MI355X_MICROARCH.md: 8.0 TB/s spec
 VALU_NOMINAL_CYCLES = 2.0                             # MI355X_MICROARCH.md: one wave64 VALU instruction per SIMD every 2 cycles
 DISTINCT_BATCHES = 25                                 # 25 x 4096 = 102 400 distinct reads per GPU
+# Tiles of a rank's share in the strong regions: a short sequence of tiles (12 800 reads per rank at N = 8) ends with its
+# last tiles running alone on the GPU; smaller tiles keep every handle busy to the end (measured: profiles/r04_notes.md)
+STRONG_TILE = {"C4": 4096, "C5": 4096}
 DEFAULT_BATCH = {"C2": 10000, "C3": 10000, "C4": 4096, "C5": 4096}
 
 
@@ -65,6 +68,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-probe", action="store_true", help="skip the probe steps (kernel durations then come from the timed region)")
     ap.add_argument("--sweep-i32", action="store_true", help="force the i32 sweep kernel (rg_set_option sweep_i32)")
     ap.add_argument("--no-strong", action="store_true", help="skip the strong_100k region (N > 1) / the strong_proxy region (N = 1)")
+    ap.add_argument("--strong-ramp", type=int, default=0, help="first tiles of a share cut in two, a short one first (shard.even_tiles)")
+    ap.add_argument("--strong-tile", type=int, default=0, help="largest tile of a rank's share in the strong regions (default: see STRONG_TILE)")
     return ap.parse_args(argv)
 
 
@@ -428,16 +433,19 @@ def cpu_limit():
     return n, why
 
 
-KERNEL_SOURCES = ("rg_sweep16.hip", "rg_pathwise.hip", "rg_path_driver.hip", "rg_poa.hip", "rg_poa_banded.hip", "rg_poa_local.hip",
-                  "rg_device.hpp", "rg_codes.hpp", "rg_path_kernels.hpp", "rg_path_args.hpp", "rg_poa_args.hpp")
+_COMMON_SOURCES = ("rg_device.hpp", "rg_codes.hpp")
+_PATH_SOURCES = ("rg_sweep16.hip", "rg_pathwise.hip", "rg_path_driver.hip", "rg_path_kernels.hpp", "rg_path_args.hpp") + _COMMON_SOURCES
+KERNEL_SOURCES = {"C2": ("rg_poa.hip", "rg_poa_args.hpp") + _COMMON_SOURCES, "C3": ("rg_poa_banded.hip", "rg_poa_args.hpp") + _COMMON_SOURCES,
+                  "C4": _PATH_SOURCES, "C5": _PATH_SOURCES}
 
 
-def code_hash():
-    """sha256 over the kernel sources and the pipeline driver: profiles/counters_*.json carry the hash of the tree they
-    were measured on (host-side files — ABI, stream, parsers — do not change what the counters count)."""
+def code_hash(config="C5"):
+    """sha256 over the sources of the kernels a configuration runs (and, for the pathwise modes, the pipeline driver):
+    profiles/counters_<config>.json carries the hash of the tree it was measured on (host-side files — ABI, stream, parsers —
+    and the other modes' kernels do not change what its counters count)."""
     h = hashlib.sha256()
     d = os.path.join(ROOT, "recgraph_amd", "csrc")
-    for f in KERNEL_SOURCES:
+    for f in KERNEL_SOURCES[config]:
         h.update(f.encode())
         h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
@@ -532,12 +540,14 @@ def main():
         pack = api.Batch.pack_reads          # the C ABI's input form, built once per read set (not part of the hot path)
         slice_set = slice_packed
 
-    def share_tiles(total_batches, lo, hi, ramp=0):
+    strong_tile = args.strong_tile or min(batch, STRONG_TILE.get(args.config, batch))
+
+    def share_tiles(total_batches, lo, hi, ramp=0, max_tile=None):
         """Reads [lo, hi) of the canonical read set of `total_batches` batches, as packed tiles of even size (<= batch):
         (tiles, [(batch index, first read in the batch, reads)] per tile for the parity gate)."""
         tiles, where = [], []
         pos = lo
-        for sz in even_tiles(hi - lo, batch, ramp):
+        for sz in even_tiles(hi - lo, max_tile or batch, ramp):
             parts, w = [], []
             need = sz
             while need:
@@ -641,8 +651,8 @@ def main():
     if args.scaling == "weak" and dist_on and not args.no_strong:
         tb = DISTINCT_BATCHES
         spans = [shard_bounds(tb * batch, r, world) for r in range(world)]
-        tpr = [len(even_tiles(b - a, batch)) for a, b in spans]
-        s_tiles, _ = share_tiles(tb, *spans[rank])
+        tpr = [len(even_tiles(b - a, strong_tile)) for a, b in spans]
+        s_tiles, _ = share_tiles(tb, *spans[rank], ramp=args.strong_ramp, max_tile=strong_tile)
         sres = timed_region(s_tiles, max(tpr))
         strong = {"reads": sres["reads_all"], "reads_per_s": round(sres["reads_all"] / sres["dt"], 2), "ms": round(sres["dt"] * 1e3, 2),
                   "reads_per_rank": [b - a for a, b in spans], "tiles_per_rank": tpr,
@@ -656,7 +666,7 @@ def main():
     proxy = None
     if args.scaling == "weak" and not dist_on and not stub and not args.no_strong and args.config in ("C4", "C5"):
         share = DISTINCT_BATCHES * batch // 8
-        p_tiles, _ = share_tiles(DISTINCT_BATCHES, 0, share)
+        p_tiles, _ = share_tiles(DISTINCT_BATCHES, 0, share, ramp=args.strong_ramp, max_tile=strong_tile)
         best = None
         for _ in range(2):                 # two passes, the better one (a single short region is noisy)
             pres = timed_region(p_tiles, len(p_tiles))
@@ -742,7 +752,7 @@ def main():
                 # NOT a fraction of anything this design moves or does — rows stay packed in registers / cache and gather
                 # runs do not perform the member updates they stand for — so it exceeds the HBM peak by construction
                 "algorithmic_equiv_GBps": round(algo, 1),
-                "code_hash": code_hash()}        # of recgraph_amd/csrc: counters collected on another tree are flagged stale
+                "code_hash": code_hash(args.config)}   # of this configuration's kernel sources: counters collected on another tree are flagged stale
         cj = os.path.join(ROOT, "profiles", "counters_%s.json" % args.config)
         vj = os.path.join(ROOT, "profiles", "valu_calib.json")
         if os.path.exists(cj):

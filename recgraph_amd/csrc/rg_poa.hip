@@ -66,11 +66,10 @@ __device__ __forceinline__ int m_at(const M0Ctx& x, int p, int c) {
 // prefix sum G of the left sweep's gap costs is then (columns so far) * g and needs neither its DPP scan nor the two
 // dependent LDS lookups of the chunk head's base.
 template <bool kLdsRead, bool kUniGap>
-#ifndef RG_POA_WAVES
-#define RG_POA_WAVES 8          // 8 waves per SIMD (34 VGPRs; the compiler's default allocation was 77 = 6 waves).  Measured: no
-#endif                          // change (1.40 M reads/s either way, profiles/r04_notes.md) — 12 % VALU-active PER WAVE times 6-8
-                                // waves is a SIMD that issues most of the time: the kernel is bound by its instruction count
-__global__ __launch_bounds__(64, RG_POA_WAVES) void k_m0_simd(PoaArgs a) {
+// (8 waves per SIMD instead of the 6 the compiler's default register allocation gives — `__launch_bounds__(64, 8)`: 34 VGPRs
+// instead of 77 — were tried in round 4: the same 1.40 M reads/s with 16 % MORE instructions (rematerialisation): 12 %
+// VALU-active per wave at 6-8 waves is a SIMD that issues most of the time; the kernel is bound by its instruction count.)
+__global__ __launch_bounds__(64) void k_m0_simd(PoaArgs a) {
     const int slot = blockIdx.x;              // arena slot of this launch
     const int rd = a.read_base + slot;        // read of the batch
     const int lane = threadIdx.x;

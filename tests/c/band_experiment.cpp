@@ -57,9 +57,11 @@ std::vector<std::vector<Group>> program(const PathGraph& g) {
 
 // forward sweep; w < 0: full width.  layer[i][k]: the row of path k after row i (members only)
 void sweep(const PathGraph& g, const std::vector<std::vector<Group>>& pr, const std::vector<std::vector<int>>& tk, const std::string& seq,
-           const Scores& sc, int w, std::vector<std::vector<std::vector<int>>>& layer) {
+           const Scores& sc, int w, std::vector<std::vector<std::vector<int>>>& layer,
+           std::vector<std::vector<std::vector<uint8_t>>>* dirs_out = nullptr) {
     const size_t L = g.lnz.size(), W = seq.size(), P = g.paths_number;
     layer.assign(L, std::vector<std::vector<int>>(P));
+    if (dirs_out) dirs_out->assign(L, {});
     std::vector<std::vector<int>> roll(P, std::vector<int>(W, 0));
     auto inwin = [&](size_t i, size_t k, size_t j) { return w < 0 || std::abs((long)j - (long)tk[i][k]) <= w; };
     {
@@ -97,9 +99,138 @@ void sweep(const PathGraph& g, const std::vector<std::vector<Group>>& pr, const 
                 rk.swap(tmp);
             }
             ra.swap(na);
+            if (dirs_out) (*dirs_out)[i].push_back(dir);
         }
         for (size_t k = 0; k < P; ++k) if (g.paths_nodes[i][k]) layer[i][k] = roll[k];
     }
+}
+
+
+// ---- the certificate that would make a band exact, simulated on the full DP ----------------------------------
+// Per path: the interval [cl, ch] of columns of its current row that are PROVABLY the full DP's, and upper bounds psiL / psiR
+// of every value of that row left / right of it.  A group's alpha cell is certified iff its decision is provably the full
+// DP's: every option whose source is not certified is dominated by the best certified option (strictly, or equal with a
+// lower priority: D > U > L); a follower cell iff the alpha's decision there is certified and the follower's chosen source
+// is.  psi' = what any uncertified cell of the new row can reach: its chain predecessor's bound plus the best step.
+// Returns, per read, the smallest distance from a path's diagonal to the boundary of its certified interval on either side
+// (over all rows and paths), and checks the certificate against the banded DP: every certified cell must hold the full
+// DP's value there (soundness on data).
+struct Zone { int cl = 0, ch = -1; long psiL = NEGV, psiR = NEGV; };
+
+struct CertResult { int min_left = INT_MAX, min_right = INT_MAX; long unsound = 0; long certified_cells = 0; };
+
+CertResult certify(const PathGraph& g, const std::vector<std::vector<Group>>& pr, const std::vector<std::vector<int>>& tk, const std::string& seq,
+                   const Scores& sc, int w, const std::vector<std::vector<std::vector<int>>>& full,
+                   const std::vector<std::vector<std::vector<uint8_t>>>& dirs, const std::vector<std::vector<std::vector<int>>>& band) {
+    const size_t L = g.lnz.size(), W = seq.size(), P = g.paths_number;
+    const int n = (int)W - 1;
+    int mm = 0;
+    for (char a : std::string("ACGT")) for (char b : std::string("ACGT")) mm = std::max(mm, sc.get(a, b));
+    const int gr = sc.get('A', '-');        // uniform read-gap cost (CLI matrices)
+    std::vector<Zone> z(P);
+    std::vector<int> row0(W, 0);
+    for (size_t j = 1; j < W; ++j) row0[j] = row0[j - 1] + gr;
+    for (size_t k = 0; k < P; ++k) { z[k].cl = 0; z[k].ch = std::min(n, w); z[k].psiL = NEGV; z[k].psiR = z[k].ch < n ? row0[(size_t)z[k].ch + 1] : NEGV; }
+    CertResult res;
+    std::vector<std::vector<int>> prev(P, row0);    // exact previous rows (the full DP's)
+    auto in = [](const Zone& q, int j) { return j >= q.cl && j <= q.ch; };
+    for (size_t i = 1; i + 1 < L; ++i) {
+        const int g_i = sc.get(g.lnz[i], '-');
+        std::vector<Zone> nz = z;
+        for (size_t gi = 0; gi < pr[i].size(); ++gi) {
+            const Group& grp = pr[i][gi];
+            const size_t a = grp.ga;
+            const Zone& za = z[a];
+            const std::vector<int>& pa = prev[a];
+            const std::vector<int>& na = full[i][a];
+            const int lo = std::max(0, tk[i][a] - w), hi = std::min(n, tk[i][a] + w);
+            // alpha: certified flags per column of the window
+            std::vector<uint8_t> cert((size_t)W, 0);
+            for (int j = lo; j <= hi; ++j) {
+                long opt[3]; bool ex[3];
+                // D from (p, j-1), U from (p, j), L from (i, j-1)
+                if (j == 0) { opt[0] = NEGV; ex[0] = true; } else if (in(za, j - 1)) { opt[0] = (long)pa[(size_t)j - 1] + sc.get(g.lnz[i], seq[(size_t)j]); ex[0] = true; }
+                else { opt[0] = (j - 1 < za.cl ? za.psiL : za.psiR) + sc.get(g.lnz[i], seq[(size_t)j]); ex[0] = false; }
+                if (in(za, j)) { opt[1] = (long)pa[(size_t)j] + g_i; ex[1] = true; } else { opt[1] = (j < za.cl ? za.psiL : za.psiR) + g_i; ex[1] = false; }
+                if (j == 0) { opt[2] = NEGV; ex[2] = true; } else if (cert[(size_t)j - 1]) { opt[2] = (long)na[(size_t)j - 1] + gr; ex[2] = true; }
+                else { opt[2] = NEGV; ex[2] = false; }      // bound of the uncertified left neighbour: filled below
+                if (j > 0 && !cert[(size_t)j - 1]) {
+                    // everything left of the first certified column of the NEW row: bounded by what its own options can reach
+                    const long src = std::max(za.psiL, (long)NEGV);
+                    long ub = src + std::max(mm, g_i);
+                    for (int c = za.cl; c <= std::min(za.ch, j - 1); ++c) ub = std::max(ub, (long)pa[(size_t)c] + std::max(mm, g_i));
+                    opt[2] = ub + gr;
+                    if (j - 1 > za.ch) opt[2] = NEGV / 4 * -1;    // a gap in the interval to the right: give up (treated as unbounded)
+                }
+                long bc = NEGV * 2L; int bw = -1;
+                for (int o = 0; o < 3; ++o) if (ex[o] && opt[o] > bc) { bc = opt[o]; bw = o; }
+                bool ok = bw >= 0 && bc > NEGV / 2;
+                for (int o = 0; o < 3 && ok; ++o)
+                    if (!ex[o] && opt[o] > NEGV / 2) ok = opt[o] < bc || (opt[o] == bc && o > bw);
+                cert[(size_t)j] = ok;
+            }
+            // contiguous certified run around the diagonal
+            auto run_around = [&](const std::vector<uint8_t>& c, int centre, int& rl, int& rh) {
+                int m = std::min(std::max(centre, lo), hi);
+                if (!c[(size_t)m]) {      // nearest certified column
+                    int best = -1;
+                    for (int d = 1; d <= 2 * w && best < 0; ++d) { if (m - d >= lo && c[(size_t)(m - d)]) best = m - d; else if (m + d <= hi && c[(size_t)(m + d)]) best = m + d; }
+                    if (best < 0) { rl = 0; rh = -1; return; }
+                    m = best;
+                }
+                rl = rh = m;
+                while (rl - 1 >= lo && c[(size_t)rl - 1]) --rl;
+                while (rh + 1 <= hi && c[(size_t)rh + 1]) ++rh;
+            };
+            int al, ah;
+            run_around(cert, tk[i][a], al, ah);
+            auto bounds = [&](const Zone& zk, const std::vector<int>& pk, int nl, int nh, Zone& out) {
+                // upper bounds of the new row left of nl / right of nh: chain predecessor's bound + the best step
+                long left = zk.psiL, right = zk.psiR;
+                for (int c = zk.cl; c <= std::min(zk.ch, nl - 1); ++c) left = std::max(left, (long)pk[(size_t)c]);
+                for (int c = std::max(zk.cl, nh); c <= zk.ch; ++c) right = std::max(right, (long)pk[(size_t)c]);
+                out.cl = nl; out.ch = nh;
+                out.psiL = left <= NEGV / 2 ? NEGV : left + std::max(mm, g_i);
+                out.psiR = right <= NEGV / 2 ? NEGV : right + std::max(mm, g_i);
+                // (the new row's own L moves only lower a bound: g <= 0)
+            };
+            bounds(za, pa, al, ah, nz[a]);
+            const std::vector<uint8_t>& dir = dirs[i][gi];
+            for (size_t k : grp.members) {
+                if (k == a) continue;
+                const Zone& zk = z[k];
+                const int klo = std::max(0, tk[i][k] - w), khi = std::min(n, tk[i][k] + w);
+                std::vector<uint8_t> ck((size_t)W, 0);
+                for (int j = klo; j <= khi; ++j) {
+                    if (j < al || j > ah) continue;                 // the alpha's decision there is not certified
+                    const uint8_t d = dir[(size_t)j];
+                    ck[(size_t)j] = d == 1 ? (j >= 1 && in(zk, j - 1)) : d == 2 ? in(zk, j) : (j >= 1 && ck[(size_t)j - 1]);
+                    if (j == 0) ck[0] = in(zk, 0);
+                }
+                int kl, kh;
+                const int lo_save = lo, hi_save = hi;
+                (void)lo_save; (void)hi_save;
+                {   // run around k's diagonal inside k's window
+                    int m = std::min(std::max(tk[i][k], klo), khi);
+                    if (!ck[(size_t)m]) { int best = -1; for (int d = 1; d <= 2 * w && best < 0; ++d) { if (m - d >= klo && ck[(size_t)(m - d)]) best = m - d; else if (m + d <= khi && ck[(size_t)(m + d)]) best = m + d; } m = best; }
+                    if (m < 0) { kl = 0; kh = -1; }
+                    else { kl = kh = m; while (kl - 1 >= klo && ck[(size_t)kl - 1]) --kl; while (kh + 1 <= khi && ck[(size_t)kh + 1]) ++kh; }
+                }
+                bounds(zk, prev[k], kl, kh, nz[k]);
+            }
+        }
+        for (size_t k = 0; k < P; ++k) {
+            if (!g.paths_nodes[i][k]) continue;
+            z[k] = nz[k];
+            prev[k] = full[i][k];
+            if (z[k].ch >= z[k].cl) {
+                res.min_left = std::min(res.min_left, tk[i][k] - z[k].cl);
+                res.min_right = std::min(res.min_right, z[k].ch - tk[i][k]);
+                for (int j = z[k].cl; j <= z[k].ch; ++j) { ++res.certified_cells; if (band[i][k][(size_t)j] != full[i][k][(size_t)j]) ++res.unsound; }
+            } else { res.min_left = std::min(res.min_left, -1); res.min_right = std::min(res.min_right, -1); }
+        }
+    }
+    return res;
 }
 
 }  // namespace
@@ -126,10 +257,19 @@ int main(int argc, char** argv) {
         const int w = atoi(argv[a]);
         long reads_changed = 0, reads_core_changed = 0, reads_sink_changed = 0, cells_kept = 0, cells_changed = 0, deepest = 0;
         std::vector<long> depth_hist(8, 0);     // deepest change per read: edge .. diagonal in eighths of the band
+        int cert_min_left = INT_MAX, cert_min_right = INT_MAX;
+        long cert_unsound = 0, cert_cells = 0, cert_left_sum = 0, cert_right_sum = 0;
         for (const std::string& seq : reads) {
             std::vector<std::vector<std::vector<int>>> full, band;
-            sweep(g, pr, tk, seq, sc, -1, full);
+            std::vector<std::vector<std::vector<uint8_t>>> dirs;
+            sweep(g, pr, tk, seq, sc, -1, full, &dirs);
             sweep(g, pr, tk, seq, sc, w, band);
+            if (getenv("BAND_CERT")) {
+                const CertResult cr = certify(g, pr, tk, seq, sc, w, full, dirs, band);
+                cert_min_left = std::min(cert_min_left, cr.min_left); cert_min_right = std::min(cert_min_right, cr.min_right);
+                cert_unsound += cr.unsound; cert_cells += cr.certified_cells;
+                cert_left_sum += cr.min_left; cert_right_sum += cr.min_right;
+            }
             const size_t W = seq.size();
             long ch = 0, dp = -1;
             bool corech = false, sinkch = false;
@@ -162,7 +302,13 @@ int main(int argc, char** argv) {
                "\"kept_cells\": %ld, \"changed_cells\": %ld, \"deepest_change_columns_from_edge\": %ld, \"deepest_change_histogram_eighths\": [",
                a > 4 ? ", " : "", w, reads_changed, reads_core_changed, reads_sink_changed, cells_kept, cells_changed, deepest);
         for (size_t b = 0; b < 8; ++b) printf("%s%ld", b ? ", " : "", depth_hist[b]);
-        printf("]}");
+        printf("]");
+        if (getenv("BAND_CERT"))
+            printf(", \"certificate\": {\"certified_cells\": %ld, \"certified_cells_that_differ_from_the_full_dp\": %ld, "
+                   "\"smallest_certified_reach_left_of_a_diagonal\": %d, \"smallest_certified_reach_right_of_a_diagonal\": %d, "
+                   "\"mean_over_reads_left\": %.1f, \"mean_over_reads_right\": %.1f}", cert_cells, cert_unsound, cert_min_left, cert_min_right,
+                   (double)cert_left_sum / reads.size(), (double)cert_right_sum / reads.size());
+        printf("}");
         fflush(stdout);
     }
     printf("]}\n");

@@ -21,7 +21,7 @@ def test_a_band_changes_kept_cells_and_the_changes_stop_short_of_the_diagonal(tm
     (tmp_path / "g.gfa").write_text(sg.gfa())
     (tmp_path / "r.txt").write_text("\n".join(synth.haplotype_reads(sg, 12, length=300, seed=32, mosaic_frac=0.5)) + "\n")
     out = subprocess.run([str(exe), str(tmp_path / "g.gfa"), str(tmp_path / "r.txt"), "12", "16", "64", "120"], capture_output=True, text=True,
-                         check=True, timeout=600).stdout
+                         check=True, timeout=600, env=dict(os.environ, BAND_CERT="1")).stdout
     d = json.loads(out)
     by_w = {b["w"]: b for b in d["bands"]}
     # a narrow band corrupts even the cells on the diagonal and the paths' final scores
@@ -32,5 +32,11 @@ def test_a_band_changes_kept_cells_and_the_changes_stop_short_of_the_diagonal(tm
         assert b["changed_cells"] > 10000
         assert b["deepest_change_columns_from_edge"] < 48                # ... but the changes stay near the edge on this data
         assert b["reads_with_changed_core_cells"] == 0 and b["reads_with_changed_sink_value"] == 0
+        # the certificate that would make the band exact by construction (per path: certified interval + a scalar upper bound
+        # of everything beyond it) is SOUND on this data — no certified cell differs from the full DP — and useless: on some
+        # row of some read the certified interval does not even reach its path's diagonal
+        c = b["certificate"]
+        assert c["certified_cells"] > 100000 and c["certified_cells_that_differ_from_the_full_dp"] == 0
+        assert min(c["smallest_certified_reach_left_of_a_diagonal"], c["smallest_certified_reach_right_of_a_diagonal"]) < 12
     # the depth does not shrink with a wider band: it is a property of the data (error density, read length), not of w
     assert abs(by_w[64]["deepest_change_columns_from_edge"] - by_w[120]["deepest_change_columns_from_edge"]) <= 8
