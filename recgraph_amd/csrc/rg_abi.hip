@@ -41,6 +41,7 @@ Options& options() {
         o.no_spec = env("RG_NO_SPEC");
         o.no_gather = env("RG_NO_GATHER");
         o.no_split = env("RG_NO_SPLIT");
+        o.layer_i32 = env("RG_LAYER_I32");
         o.spin_wait = env("RG_SPIN_WAIT");
         { const char* v = getenv("RG_SPEC_MARGIN"); if (v) o.spec_margin = atoi(v); }
     });
@@ -365,6 +366,7 @@ static std::atomic<int>* option_slot(const char* name) {
     if (!strcmp(name, "no_spec")) return &o.no_spec;
     if (!strcmp(name, "no_gather")) return &o.no_gather;
     if (!strcmp(name, "no_split")) return &o.no_split;
+    if (!strcmp(name, "layer_i32")) return &o.layer_i32;
     if (!strcmp(name, "spin_wait")) return &o.spin_wait;
     if (!strcmp(name, "spec_margin")) return &o.spec_margin;
     return nullptr;

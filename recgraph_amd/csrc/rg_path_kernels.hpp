@@ -220,6 +220,7 @@ void launch_search(const SearchArgs& a, int nreads, hipStream_t s);
 void launch_need(const ReadState* st, const unsigned* nf, const unsigned* nr, const unsigned* nrec, const unsigned* nrrec,
                  unsigned* need, int nreads, hipStream_t s);
 void launch_layer(const LayerArgs& a, int nreads, int C, hipStream_t s);
+void launch_layer16(const LayerArgs& a, int nreads, int C, hipStream_t s);   // packed rows (dir_fmt 1, one wave per read)
 void launch_trace(const TraceArgs& a, int C, hipStream_t s);
 
 }  // namespace rg

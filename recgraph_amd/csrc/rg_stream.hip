@@ -128,6 +128,8 @@ struct rg_stream {
     std::unique_ptr<Tile> cur;              // the tile rg_stream_next last returned
     std::vector<rg_batch*> kept;            // keep_records: results-only handles of the delivered tiles (until released)
 
+    std::mutex pmu;                         // one push at a time: the tiles of a push get consecutive ids even when it has to wait for
+                                            // room in the queue (pushes from several threads queue up behind each other)
     std::mutex fmu;                         // rg_stream_feed_fasta: one text at a time
     rg::FastaFeeder feeder;
     rg::FastaReads fbuf;                    // complete reads not yet pushed (less than one tile between calls)
@@ -329,6 +331,7 @@ struct rg_stream {
     // device slots (at least one tile per slot, a multiple of the slot count): a push of one tile — what
     // rg_stream_feed_fasta and a caller that cuts its own tiles hand over — stays one tile.
     int push(const char* reads, const int64_t* read_off, int64_t nreads, const char* const* names, const std::vector<std::string>* own_names) {
+        std::lock_guard<std::mutex> one_push(pmu);
         const int64_t T = tile_reads, D = (int64_t)devs.size();
         int64_t nt = (nreads + T - 1) / T;
         bool first_push;
@@ -357,7 +360,6 @@ struct rg_stream {
                 if (o.max_queued_tiles > 0)
                     cv_space.wait(lk, [&] { return stopping || finished || (int64_t)queue.size() < o.max_queued_tiles; });
                 if (finished || stopping) return fail(RG_ERR_ARG, "rg_stream_push after rg_stream_finish");
-                // (reads of one push stay consecutive: pushes from several threads are serialised by the caller)
                 if (base < 0) { base = reads_pushed; reads_pushed += nreads; }
                 t->id = tiles_pushed++;
                 t->first = base + lo;

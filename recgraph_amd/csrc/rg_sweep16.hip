@@ -1244,6 +1244,175 @@ void launch_colmax_rec(const ExpandArgs& a, int* colmax_out, int* colarg_out, in
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// k_layer on packed rows (k_layer of rg_pathwise.hip is the i32 form: 16 columns per lane unpacked, ~350 wave-instructions
+// per row; this one ~220).  Same job: rebuild the layer of ONE path from the sweep's direction words (rows of that path
+// only) and store, per cell, the move the reference's traceback takes there (pathwise_alignment_output.rs:32-110,
+// recombination_output.rs:391-470, 659-736: d, u, l re-derived from the path's own layer, D > U > L).  Rows are in the
+// sweep's z-space (z = A - c * g): d, u and l of one cell are compared at the same column, so the comparison is the same.
+// The walkers take the L step's cost from the key ('-', read base), the sweep from (read base, '-'): the
+// driver only sends batches here whose two gap tables agree (every CLI matrix); others keep the i32 form.
+template <int C>
+__global__ __launch_bounds__(64) void k_layer16(LayerArgs a) {
+    constexpr int H = C / 2;
+    const int rd = blockIdx.x;
+    const int lane = threadIdx.x;
+    const PathGraphDev& g = a.g;
+    ReadState* rs = a.state + rd;
+    if (rs->status & (ST_BAD_BASE | ST_WOULD_PANIC | ST_OVERFLOW)) return;
+    const bool rev = a.rev;
+    const int path = rev ? rs->rev_path : rs->fwd_path;
+    const bool recomb = rs->fwd_path != rs->rev_path;
+    if (rev && !recomb) return;  // no recombination: reverse layer not needed
+    const long long ro = a.read_off[rd];
+    const int n = (int)(a.read_off[rd + 1] - ro);
+    const uint8_t* read = a.reads + ro - 1;
+    const int ncols = rev ? n : n + 1;
+    const int GAP = 5;
+    extern __shared__ __attribute__((aligned(16))) int lds16[];
+    int* sct = lds16;                    // [36]
+    int* s2 = lds16 + 64;                // [5][64] packed (s - g) pairs by (code_lo | code_hi << 3)
+    int* sprof = s2 + 5 * 64;            // [5][64][H]: the lane's packed diagonal steps per row base (see k_sweep16)
+    if (lane < 36) sct[lane] = a.sc.t[lane];
+    __syncthreads();
+    const int gcost = sct[GAP];
+    for (int e = lane; e < 5 * 64; e += WAVE) {
+        const int li = e >> 6, cl = e & 7, ch = (e >> 3) & 7;
+        s2[e] = (cl < 6 && ch < 6) ? pack16(sct[li * 6 + cl] - gcost, sct[li * 6 + ch] - gcost) : 0;
+    }
+    __syncthreads();
+    int cur[H];
+#pragma unroll
+    for (int r = 0; r < H; ++r) {
+        const int c0 = lane * C + r, c1 = c0 + H;
+        int k0 = 4, k1 = 4;
+        if (c0 >= 1 && c0 < ncols) k0 = rev ? read[n - c0 + 1] : read[c0];
+        if (c1 >= 1 && c1 < ncols) k1 = rev ? read[n - c1 + 1] : read[c1];
+#pragma unroll
+        for (int li = 0; li < 5; ++li) sprof[(li * WAVE + lane) * H + r] = s2[li * 64 + (k0 | (k1 << 3))];
+        cur[r] = pack16(c0 < ncols ? 0 : NEG16, c1 < ncols ? 0 : NEG16);       // the gap-only start row: z = 0
+    }
+    __syncthreads();
+    uint32_t* tdir = reinterpret_cast<uint32_t*>(a.layer) + (long long)rd * a.layer_stride;
+    const int* prow = rev ? a.rprow : a.fprow;
+    const int* pslot = rev ? a.rpslot : a.fpslot;
+    const int* poff = rev ? a.rpoff : a.fpoff;
+    const uint32_t* dirs = a.dirs + (long long)rd * a.dirs_stride;
+    const int nrows = poff[path + 1] - poff[path];
+    const int start_row = recomb ? rs->fen : rs->end_row;
+    const int start_col = recomb ? rs->rec_col : n;
+    constexpr unsigned FULL = RowOps16<C>::FULL;
+    constexpr unsigned LOWH = H >= 16 ? 0xffffu : ((1u << H) - 1u);
+    constexpr int PF = 4;
+    int pf_li[PF], pf_row[PF];
+    uint32_t pf_w0[PF], pf_w1[PF];
+    auto prefetch = [&](int tt, int& li_o, int& row_o, uint32_t& w0_o, uint32_t& w1_o) {
+        li_o = 4; row_o = -1; w0_o = 0; w1_o = 0;
+        if (tt < nrows) {
+            const int ii = prow[poff[path] + tt];
+            const int sl = pslot[poff[path] + tt];
+            row_o = ii;
+            li_o = g.lnz[ii];
+            w0_o = dirs[(long long)sl * a.dir_words + lane];
+            if (C > 16) w1_o = dirs[(long long)sl * a.dir_words + WAVE + lane];
+        }
+    };
+#pragma unroll
+    for (int k = 0; k < PF; ++k) prefetch(k, pf_li[k], pf_row[k], pf_w0[k], pf_w1[k]);
+    for (int t = 0; t < nrows; ++t) {
+        const int li = pf_li[0], irow = pf_row[0];
+        const uint32_t word0 = pf_w0[0], word1 = pf_w1[0];
+#pragma unroll
+        for (int k = 0; k + 1 < PF; ++k) { pf_li[k] = pf_li[k + 1]; pf_row[k] = pf_row[k + 1]; pf_w0[k] = pf_w0[k + 1]; pf_w1[k] = pf_w1[k + 1]; }
+        prefetch(t + PF, pf_li[PF - 1], pf_row[PF - 1], pf_w0[PF - 1], pf_w1[PF - 1]);
+        const int g_i = __builtin_amdgcn_readfirstlane(sct[li * 6 + GAP]);
+        const int g0 = a.semi ? 0 : g_i;
+        const int GI = pack16(g_i, g_i);
+        const int GI0 = lane == 0 ? pack16(g0, g_i) : GI;
+        // direction masks of the row in the packed-bit form of k_sweep16 (bit r: column r of the lane, bit 16 + r: column H + r)
+        unsigned um2, lm2;
+        if (C <= 16) {
+            const unsigned uu = word0 & 0xffffu, ll = word0 >> 16;
+            um2 = (uu & LOWH) | (((uu >> H) & LOWH) << 16);
+            lm2 = (ll & LOWH) | (((ll >> H) & LOWH) << 16);
+        } else { um2 = word0; lm2 = word1; }
+        int s[H], MU[H], ML[H], SEL[H];
+        {
+            const int* sp = sprof + (li * WAVE + lane) * H;
+#pragma unroll
+            for (int r = 0; r < H; ++r) s[r] = sp[r];
+        }
+#pragma unroll
+        for (int r = 0; r < H; ++r) {
+            MU[r] = pk_sub(0, (int)((um2 >> r) & (unsigned)ONE2));       // 0 - 1 = 0xffff per half
+            ML[r] = pk_sub(0, (int)((lm2 >> r) & (unsigned)ONE2));
+            SEL[r] = bfi(MU[r], r == 0 ? GI0 : GI, s[r]);
+        }
+        const unsigned long long have = __ballot((lm2 & FULL) != FULL) & ((1ull << lane) - 1ull);
+        const int src = have ? 63 - __clzll((long long)have) : 0;
+        int old[H];
+#pragma unroll
+        for (int r = 0; r < H; ++r) old[r] = cur[r];
+        RowOps16<C>::member(cur, SEL, lane, MU, ML, lm2, src);
+        // ---- traceback decisions of this row ----
+        // the reverse matrix keeps its start row (row L-1) delta-encoded in the reference (absolute_scores skips it): path 0
+        // reads its absolute value there, every other path reads 0 (pathwise_alignment_recombination.rs:748): A = 0 is
+        // z = -c * g in z-space
+        const bool zero_prev = rev && t == 0 && path != 0;
+        if (zero_prev) {
+#pragma unroll
+            for (int r = 0; r < H; ++r) {
+                const int c0 = lane * C + r, c1 = c0 + H;
+                old[r] = pack16(-c0 * gcost, -c1 * gcost);
+            }
+        }
+        int o1 = __builtin_amdgcn_alignbit(old[H - 1], dpp_shr1(old[H - 1], NEGPAIR), 16);      // old row, column c - 1
+        int nl = __builtin_amdgcn_alignbit(cur[H - 1], dpp_shr1(cur[H - 1], NEGPAIR), 16);      // new row, column c - 1
+        if (zero_prev && lane == 0) o1 = pack16(gcost, hi16(o1));      // (k_layer reads 0 for the cell left of column 0 too: z = +g)
+        unsigned tw0 = 0, tw1 = 0;
+#pragma unroll
+        for (int r = 0; r < H; ++r) {
+            const int d = pk_add(o1, s[r]);
+            const int u = pk_add(old[r], GI);                           // (the walkers add the row's gap cost in column 0 too, semiglobal or not)
+            const int mx = pk_max(pk_max(d, u), nl);
+            const int nd = pk_sign(pk_sub_sat(d, mx));                  // 0xffff where D does not attain the maximum
+            const int nu = pk_sign(pk_sub_sat(u, mx));
+            // 1 = D, 2 = U, 3 = L per half: bit 1 = nd, bit 0 = ~nd | nu
+            const int b0 = __builtin_amdgcn_bitop3_b32(nd, nu, ONE2, 0x8A);           // (~nd | nu) & 1
+            const unsigned code2 = (unsigned)(b0 | (nd & 0x00020002));
+            if (H <= 8) tw0 |= code2 << (2 * r);
+            else { tw0 |= (code2 & 3u) << (2 * r); tw1 |= (code2 >> 16) << (2 * r); }
+            o1 = old[r];
+            nl = cur[r];
+        }
+        if (C <= 16) {
+            // codes of columns 0 .. H-1 sit at bits 2r, those of H .. C-1 at bits 16 + 2r: column order wants them at 2 (H + r)
+            const unsigned word = H == 8 ? tw0 : ((tw0 & 0xffffu) | ((tw0 >> 16) << (2 * H)));
+            tdir[(long long)(t + 1) * a.dir_words + lane] = word;
+        } else {
+            tdir[(long long)(t + 1) * a.dir_words + lane] = tw0;
+            tdir[(long long)(t + 1) * a.dir_words + WAVE + lane] = tw1;
+        }
+        if (!rev && irow == start_row) {
+            int pv = 0;
+#pragma unroll
+            for (int r = 0; r < H; ++r) if (r == (start_col % C) % H) pv = cur[r];
+            if (lane == start_col / C) rs->trace_score = ((start_col % C) >= H ? hi16(pv) : lo16(pv)) + start_col * gcost;
+        }
+    }
+}
+
+void launch_layer16(const LayerArgs& a, int nreads, int C, hipStream_t s) {
+    const size_t bytes = (size_t)(64 + 5 * 64 + 5 * WAVE * (C / 2)) * sizeof(int);
+    switch (C) {
+        case 4: hipLaunchKernelGGL((k_layer16<4>), dim3(nreads), dim3(64), bytes, s, a); break;
+        case 8: hipLaunchKernelGGL((k_layer16<8>), dim3(nreads), dim3(64), bytes, s, a); break;
+        case 16: hipLaunchKernelGGL((k_layer16<16>), dim3(nreads), dim3(64), bytes, s, a); break;
+        default: hipLaunchKernelGGL((k_layer16<32>), dim3(nreads), dim3(64), bytes, s, a); break;
+    }
+}
+
 template <int kColmax, bool kRec, bool kWide>
 static void launch_sweep16_w(const SweepArgs& a, int nreads, int C, hipStream_t s) {
     const size_t bytes = (size_t)(64 + 2 * RG_MAXP + (RG_SWEEP16_THRLDS ? C * WAVE : 0) + C * WAVE + C / 2 * WAVE + 5 * WAVE * (C / 2)) * sizeof(int);

@@ -9,7 +9,7 @@ def _switch(var, on):
     """The diagnostic switches of the library (rg_set_option; the environment variables of the same names only set the
     defaults when the library is loaded)."""
     from recgraph_amd import api
-    api.set_option({"RG_SWEEP_I32": "sweep_i32", "RG_NO_FREC": "no_frec", "RG_THREE_SWEEPS": "three_sweeps"}[var], on)
+    api.set_option({"RG_SWEEP_I32": "sweep_i32", "RG_NO_FREC": "no_frec", "RG_THREE_SWEEPS": "three_sweeps", "RG_LAYER_I32": "layer_i32"}[var], on)
 
 
 
@@ -144,7 +144,7 @@ def test_sweep_kernel_variants_agree(oracle):
                           (api.MODE_PATHWISE, oracle.M4_ABS, 42), (api.MODE_PATHWISE_SEMI, oracle.M5_ABS, 12)):
         reads = [r[:180] for r in rd[:cut]] if mode in (api.MODE_RECOMBINATION_SEMI, api.MODE_PATHWISE_SEMI) else rd[:cut]
         base = _check(oracle, g.gfa(), reads, mode, om)
-        for var in ("RG_SWEEP_I32", "RG_NO_FREC"):
+        for var in ("RG_SWEEP_I32", "RG_NO_FREC", "RG_LAYER_I32"):
             _switch(var, 1)
             texts, _ = api.align_batch(gg, reads, ["r%d" % i for i in range(len(reads))], mode=mode)
             _switch(var, 0)
@@ -301,7 +301,7 @@ def test_random_dag_graphs_in_every_switch_family(oracle):
     cases = ((150, 12, 301, {"max_jump": 3, "max_seg": 8}), (110, 32, 302, {"max_jump": 5, "max_seg": 12, "similar": 0.7}),
              (240, 5, 303, {"max_jump": 2, "max_seg": 4}))
     switches = (("sweep_i32", 1), ("no_frec", 1), ("three_sweeps", 1), ("no_spec", 1), ("spec_margin", 0), ("spec_margin", -1000000),
-                ("no_gather", 1), ("no_split", 1), ("chunk_reads", 5))
+                ("no_gather", 1), ("no_split", 1), ("chunk_reads", 5), ("layer_i32", 1))
     pairs = ((("three_sweeps", 1), ("sweep_i32", 1)), (("no_split", 1), ("no_gather", 1)), (("spec_margin", -1000000), ("chunk_reads", 4)),
              (("no_frec", 1), ("no_spec", 1)))
     defaults = {"spec_margin": 160}
