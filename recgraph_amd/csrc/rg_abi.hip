@@ -42,6 +42,7 @@ Options& options() {
         o.no_gather = env("RG_NO_GATHER");
         o.no_split = env("RG_NO_SPLIT");
         o.layer_i32 = env("RG_LAYER_I32");
+        { const char* v = getenv("RG_NO_RETIRE"); o.no_retire = v ? atoi(v) : 0; }
         o.spin_wait = env("RG_SPIN_WAIT");
         { const char* v = getenv("RG_SPEC_MARGIN"); if (v) o.spec_margin = atoi(v); }
     });
@@ -367,6 +368,7 @@ static std::atomic<int>* option_slot(const char* name) {
     if (!strcmp(name, "no_gather")) return &o.no_gather;
     if (!strcmp(name, "no_split")) return &o.no_split;
     if (!strcmp(name, "layer_i32")) return &o.layer_i32;
+    if (!strcmp(name, "no_retire")) return &o.no_retire;
     if (!strcmp(name, "spin_wait")) return &o.spin_wait;
     if (!strcmp(name, "spec_margin")) return &o.spec_margin;
     return nullptr;
@@ -378,6 +380,7 @@ int32_t rg_set_option(const char* name, int64_t value) {
     if (s == &o.stripe_c) *s = (int)std::max<int64_t>(0, std::min<int64_t>(value, 32));
     else if (s == &o.chunk_reads) *s = (int)std::max<int64_t>(0, std::min<int64_t>(value, 1 << 20));
     else if (s == &o.spec_margin) *s = (int)std::max<int64_t>(-(1 << 24), std::min<int64_t>(value, 1 << 24));
+    else if (s == &o.no_retire) *s = (int)std::max<int64_t>(0, std::min<int64_t>(value, 3));     // 1: off, 2: forward sweep only, 3: reverse sweep only
     else *s = value ? 1 : 0;
     return RG_OK;
 }

@@ -55,6 +55,7 @@ struct PathWorkImpl {
     Buf<int4> fsteps, rsteps;
     int nfsteps = 0, nrsteps = 0;
     Buf<int4> fsplit, rsplit;         // the same records with TAILs moved behind their register runs (split_tails below)
+    Buf<unsigned long long> flead, rlead, fslead, rslead;    // PATH RETIREMENT tables of the four step tables (lead_table below)
     bool have_split = false;
     unsigned fcap = 0, rcap = 0;
     std::vector<hipEvent_t> ev;
@@ -362,16 +363,36 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
                 q = e;
             }
         };
+        // PATH RETIREMENT (k_sweep16): per evaluation point e (record 256 e) and path k, the union of the member masks of the
+        // groups k LEADS in the records from 256 e on (groups with other members only): a path that is hopeless for a read may
+        // stop being computed once no path that is still needed appears in that union
+        auto lead_table = [&](const std::vector<int4>& recs) {
+            const size_t E = recs.size() / 256 + 2;
+            std::vector<unsigned long long> out(E * 64, 0ull);
+            unsigned long long cur[64] = {};
+            for (size_t t = recs.size(); t-- > 0;) {
+                const unsigned x = (unsigned)recs[t].x;
+                const unsigned long long mask = ((unsigned long long)(unsigned)recs[t].w << 32) | (unsigned)recs[t].z;
+                if (recs[t].y >= 0 && mask && (mask & (mask - 1))) {          // not a continuation entry, more than one member
+                    const int alpha = ((x >> 23) & 4u) ? __builtin_ctzll(mask) : (int)((x >> 26) & 63u);
+                    cur[alpha] |= mask;
+                }
+                if (t % 256 == 0) for (int k = 0; k < 64; ++k) out[(t / 256) * 64 + k] = cur[k];
+            }
+            return out;
+        };
         std::vector<int4> st, sp;
         steps(h.fgoff, h.fgroups, true, st);
         if ((rc = w.fsteps.upload(st))) return rc;
         w.nfsteps = (int)st.size();
         w.have_split = P <= 64;
-        if (w.have_split) { split_tails(st, sp); if ((rc = w.fsplit.upload(sp))) return rc; }
+        if (P <= 64 && (rc = w.flead.upload(lead_table(st)))) return rc;
+        if (w.have_split) { split_tails(st, sp); if ((rc = w.fsplit.upload(sp)) || (rc = w.fslead.upload(lead_table(sp)))) return rc; }
         steps(h.rgoff, h.rgroups, false, st);
         if ((rc = w.rsteps.upload(st))) return rc;
         w.nrsteps = (int)st.size();
-        if (w.have_split) { split_tails(st, sp); if ((rc = w.rsplit.upload(sp))) return rc; }
+        if (P <= 64 && (rc = w.rlead.upload(lead_table(st)))) return rc;
+        if (w.have_split) { split_tails(st, sp); if ((rc = w.rsplit.upload(sp)) || (rc = w.rslead.upload(lead_table(sp)))) return rc; }
         w.tables = true;
     }
     const long long layer_stride = (long long)(h.max_path_rows + 2) * dir_words;   // traceback decisions: 2 bits per cell
@@ -474,6 +495,10 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
             // split tables: only where every run between the groups of a row is a register or a gather run of k_sweep16
             sa.fsplit = w.fsplit.p; sa.rsplit = w.rsplit.p;
             sa.use_split = w.have_split && sa.gather_ok && !semi && C <= 16 && !opt.no_split ? 1 : 0;
+            // path retirement: the record pipelines of -m 8 (global), P <= 64
+            sa.flead = w.flead.p; sa.rlead = w.rlead.p; sa.fslead = w.fslead.p; sa.rslead = w.rslead.p;
+            sa.retire = use16 && P <= 64 && !semi && mode == RG_MODE_RECOMBINATION && gaps_nonpos && opt.no_retire != 1 ? 1 : 0;
+            sa.maxmatch = maxmatch;      // (both sweeps: the retirement bound; the forward sweep's speculative thresholds)
         }
         sa.rbw = p.rec_band_width; sa.cand_cap = 0; sa.dir_words = dir_words; sa.cells = d_cells;
         SeedArgs se;
@@ -504,6 +529,7 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
                     f.colarg_out = nullptr;
                 }
                 f.dirs = w.fdirs.p; f.dirs_stride = fdirs_stride; f.count_cells = 1;
+                if (opt.no_retire == 3) f.retire = 0;
                 TIMED(T, use16 ? "k_sweep16_fwd" : "k_sweep_fwd", sweep(f, chunk));
                 TIMED(T, "k_seed", launch_seed(se, stream));
             } else {
@@ -522,6 +548,7 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
                 r.colmax_out = nullptr; r.colarg_out = nullptr;
             }
             r.dirs = w.rdirs.p; r.dirs_stride = rdirs_stride; r.count_cells = 1;
+            if (opt.no_retire == 2) r.retire = 0;
             TIMED(T, use16 ? "k_sweep16_rev" : "k_sweep_rev", sweep(r, chunk));
             if (use_rec) {
                 ExpandArgs ec{w.state.p, w.rrec.p, w.rrec_cap, w.nrrec.p, nullptr, 0, nullptr, nullptr, wpad, p.base_rec_cost, gd.knm, 1, off,

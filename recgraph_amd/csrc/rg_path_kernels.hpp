@@ -62,6 +62,13 @@ struct SweepArgs {
     unsigned frec_cap;
     int nwv;                   // waves (column stripes of 2048) per read: > 1 for reads longer than 2047 bases (k_sweep<32, true, true>)
     int gather_ok;             // k_sweep16 gather runs: the difference of two members' packed values provably fits 16 bits
+    // k_sweep16 PATH RETIREMENT (record pipelines, P <= 64): per 256 records of the step table and per path, the union of the
+    // member masks of the groups the path leads from there on ([evaluation point][64]); one table per step table
+    const unsigned long long* flead;
+    const unsigned long long* rlead;
+    const unsigned long long* fslead;   // ... of the split tables
+    const unsigned long long* rslead;
+    int retire;
 };
 
 // expands the (row, lane) records of the forward sweep into Cand entries, keeping only cells that can still reach

@@ -53,6 +53,9 @@ __device__ __forceinline__ int pk_minu(int a, int b) {
 __device__ __forceinline__ int pk_sub_sat(int a, int b) {
     return __builtin_bit_cast(int, __builtin_elementwise_sub_sat(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b)));
 }
+__device__ __forceinline__ int pk_add_sat(int a, int b) {
+    return __builtin_bit_cast(int, __builtin_elementwise_add_sat(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b)));
+}
 // per half: 0xffff where the half of `v` is negative, else 0  (v_pk_ashrrev_i16)
 __device__ __forceinline__ int pk_sign(int v) {
     return __builtin_bit_cast(int, (s16x2)(__builtin_bit_cast(s16x2, v) >> (s16x2)(15)));
@@ -223,6 +226,7 @@ template <int C, int kColmax, bool kRec, bool kWide>
 __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_WAVES) void k_sweep16(SweepArgs a) {
     constexpr int H = C / 2;
     constexpr bool kTrack = kColmax != 0 || kRec;      // <0, false>: the -m 4 / -m 5 sweep — no best member, no thresholds, no emission
+    constexpr bool kRet = kRec && kColmax != 1 && !kWide && C <= 16;   // PATH RETIREMENT (record pipelines of -m 8, P <= 64): see retire_eval
     constexpr int KRUN = C <= 16 ? (kColmax != 0 ? RG_SWEEP16_KRUN : RG_SWEEP16_KRUN_REV) : 0;   // rows kept in registers across the inner rows of a segment
     const int rd = blockIdx.x;
     const int lane = threadIdx.x;
@@ -256,6 +260,9 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
     // diagonal step into a row whose base is li — one 16-byte LDS read per four registers and row instead of a code
     // extraction + table lookup per register (24 VALU instructions per row at C = 16)
     int* sprof = gS + H * WAVE;                                                            // [5][64][H]
+    // PATH RETIREMENT constants (below), [H][64] <= 512 words: they share the semiglobal end arrays' words (retirement is off in
+    // the semiglobal modes; one more 2 KB block per wave would push eight waves past the CU's 160 KB of LDS)
+    int* rvl = endv;
     if (lane < 36) sct[lane] = a.sc.t[lane];
     __syncthreads();
     const int gcost = sct[GAP];          // uniform read-gap cost (checked by the launcher): the z-space slope
@@ -301,6 +308,7 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
 #endif
     int thz[kRec ? H : 1];               // packed (threshold >> 16) pairs, see below
     int minplain2 = 0;
+    int next_eval = INT32_MAX;           // PATH RETIREMENT: the record index of the next evaluation (INT32_MAX: off for this read)
     int minthrk = INT32_MAX;             // lowest threshold of the lane
     int minplain = INT32_MAX;            // lowest threshold of the lane without the member rule (rows every path visits)
     const bool tight = a.thr != nullptr || a.oob; // thresholds from the other sweep's column maxima / from the speculative bound
@@ -355,6 +363,61 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
             row0[r] = pack16(c0 < ncols ? 0 : NEG16, c1 < ncols ? 0 : NEG16);
         }
         for (int k = 0; k < P; ++k) st_row(k, row0);
+        // PATH RETIREMENT constants: a path whose every FUTURE cell is provably below every threshold is "hopeless".  A
+        // cell of the path at a later row and column j' is reached from some cell (this row, j), j <= j' (reverse sweep:
+        // j >= j'), through moves that gain at most mmx = max(max match, 0) per column (D: a substitution score, L / U: gap
+        // entries, <= 0 in every batch this kernel admits): value' <= value + mmx * |j' - j|.
+        //   forward: it matters only if it can reach lb (seed: its sink value; candidate: value + mmx (n - j') >= lb + R, and
+        //            the test drops the R so that a retired path's final score stays below the verified lb):
+        //            hopeless  <=>  max_j (A[j] + mmx (n - j)) < lb
+        //   reverse: it matters only if w[j'] >= thr[j'] (the emission threshold):
+        //            hopeless  <=>  for all j: A[j] + mmx j < min_{j' <= j} (thr[j'] + mmx j')
+        // Both are "max over the row of (z + constant per column) < 0" on the packed z-space rows: rvl holds the constants
+        // (saturating 16-bit; a constant that would have to be ROUNDED DOWN to fit switches the retirement off for the read).
+        if (kRet && a.retire && !a.semi) {
+            static_assert(!kRet || H * WAVE <= 2 * RG_MAXP, "rvl shares endv / endr");
+            const int mmx = max(a.maxmatch, 0);
+            int tv[C];
+            bool ovf = false;
+            if (!rev) {
+                const int lbv = a.lb ? a.lb[rd] : INT32_MIN / 2;
+#pragma unroll
+                for (int q = 0; q < C; ++q) {
+                    const int c = lane * C + q;
+                    const long long v = (long long)c * (gcost - mmx) + (long long)mmx * n - lbv;
+                    ovf = ovf || (c < ncols && v > 32767);
+                    tv[q] = c < ncols ? (int)max(-32768ll, min(32767ll, v)) : -32768;
+                }
+            } else {
+                // Tmin over mirrored columns c' >= c  (real columns j' <= j)
+                int tq[C], ltot = INT32_MAX;
+#pragma unroll
+                for (int q = 0; q < C; ++q) {
+                    const int c = lane * C + q;
+                    const int j = n - c;
+                    int th = INT32_MAX;
+                    if (c < ncols && j >= oob && j < n + 1 - oob && a.thr) th = a.thr[(long long)rd * wpad + j];
+                    tq[q] = th == INT32_MAX ? INT32_MAX : th + mmx * j;
+                    ltot = min(ltot, tq[q]);
+                }
+                int suf = ltot;
+#pragma unroll
+                for (int d = 1; d < WAVE; d <<= 1) { const int o = __shfl_down(suf, d, WAVE); if (lane + d < WAVE) suf = min(suf, o); }
+                int run = __shfl_down(suf, 1, WAVE);
+                if (lane == WAVE - 1) run = INT32_MAX;
+#pragma unroll
+                for (int q = C - 1; q >= 0; --q) {
+                    run = min(run, tq[q]);
+                    const int c = lane * C + q;
+                    const long long v = (long long)c * gcost + (long long)mmx * (n - c) - (long long)run;
+                    ovf = ovf || (c < ncols && run != INT32_MAX && v > 32767);
+                    tv[q] = (c < ncols && run != INT32_MAX) ? (int)max(-32768ll, min(32767ll, v)) : -32768;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < H; ++r) rvl[r * WAVE + lane] = pack16(tv[r], tv[r + H]);
+            if ((rev ? a.thr != nullptr : a.lb != nullptr) && !__any(ovf)) next_eval = 256;
+        }
     }
     __syncthreads();
 
@@ -645,6 +708,38 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
     int MU[H], ML[H], SEL[H];
     unsigned lmask = 0;                  // L mask and fill-forward source lane of the current group's alpha: live across
     int src = 0;                         // the continuation entries of a group that spans 64-path pages
+    // PATH RETIREMENT (kRet): `needed` = the paths whose rows are still computed.  Every 256 records (at the top of the record
+    // loop: every row is in memory there) the hopeless paths are found (one pass over each needed row against the constants
+    // in rvl) and a hopeless path is retired unless it still LEADS a group with a needed member further down the table — its
+    // decisions are that member's directions — iterated to the fixpoint (lead: per evaluation point and path, the union of
+    // the member masks of the groups the path leads from there on; built beside the step table).  A retired path's row is
+    // never read again: it cannot emit, it cannot be a cell's best member where something emits, its sink value is below
+    // the bound k_verify checks; the needed paths see exactly the decisions they would see in the full sweep.
+    // tests/c/band_experiment.cpp measures why this — not a column band — is the exact way to skip hopeless work here.
+    unsigned long long needed = P >= 64 ? ~0ull : ((1ull << P) - 1ull);
+    bool row_open = false;               // some group of the current several-group row has put its keys into bkey
+    auto retire_eval = [&](int e) {
+        unsigned long long hop = 0, todo = needed;
+        while (todo) {
+            const int k = __builtin_ctzll(todo);
+            todo &= todo - 1;
+            int tmp[H];
+            ld_row(k, tmp);
+            int m = pk_add_sat(tmp[0], rvl[lane]);            // (constants from LDS every time: no registers held across the loop)
+#pragma unroll
+            for (int r = 1; r < H; ++r) m = pk_max(m, pk_add_sat(tmp[r], rvl[r * WAVE + lane]));
+            const int v = max(lo16(m), hi16(m));
+            if (__builtin_amdgcn_readlane(dpp_incl_max(v, INT32_MIN), WAVE - 1) < 0) hop |= 1ull << k;
+        }
+        const unsigned long long lead_k = lane < P ? (rev ? a.rlead : a.flead)[(long long)e * 64 + lane] : 0ull;
+        unsigned long long nd = needed & ~hop;
+        for (;;) {
+            const unsigned long long ad = __ballot(((needed >> lane) & 1ull) && !((nd >> lane) & 1ull) && (lead_k & nd) != 0ull);
+            if (!ad) break;
+            nd |= ad;
+        }
+        needed = nd;
+    };
     while (t < nsteps) {
         int w0, w1;
         unsigned long long gmask;
@@ -667,6 +762,21 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
         // run costs ~180 instructions per member once per run (two passes) + ~160 per row, the member-by-member form ~77 per
         // member and row: it pays when R * (77 (nm - 1) - 160) >= 200 (nm - 1)  (32 paths: 3 rows, 8 paths: 4, 5 paths: 6)
         const int run_left = (flags & F_INNER) ? ((w0 >> 26) & 63) : 0;
+        if (kRet && t >= next_eval) [[unlikely]] { retire_eval(t >> 8); next_eval = (t | 255) + 1; }
+        const unsigned long long gm = kRet ? (gmask & needed) : gmask;     // the members still computed
+        const int nme = kRet ? __popcll(gm) : nm;
+        if (kRet && gm == 0ull) {
+            // every member retired (and with them the alpha: it would be needed otherwise): the record is skipped; a row
+            // with several groups still opens / closes around its skipped groups.  (The records of a register / gather run
+            // — flags read 7 — may lie BETWEEN the groups of such a row in a split table: they leave bkey and row_open alone,
+            // skipped or not.)
+            if (run_left == 0) {
+                if (flags & F_FIRST) row_open = false;
+                if (track && (flags & F_LAST) && row_open) row_end(i, ((w1 >> 20) & 511) - 1, bkey);
+            }
+            ++t;
+            continue;
+        }
         if (RG_SWEEP16_GATHER && (kRec ? (kColmax == 0 || (kColmax == 2 && RG_SWEEP16_GATHER_FWD)) : !track) && !kWide && a.gather_ok && !semi_end && (flags & F_INNER) && nm > KRUN &&
             run_left * (77 * (nm - 1) - 160) >= 200 * (nm - 1)) {
             // ---- GATHER RUN: R consecutive inner rows of a segment that a wide group (nm paths, one group, alpha = its lowest
@@ -682,7 +792,7 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
             const int ka = ga;
             int A[H], G[H];
             __syncthreads();
-            touch_group(gmask, nm, gT);
+            touch_group(gm, nme, gT);
 #pragma unroll
             for (int r = 0; r < H; ++r) A[r] = 0;
             ld_row(ka, A);
@@ -695,7 +805,7 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
                 int bd[H], bk[H];
 #pragma unroll
                 for (int r = 0; r < H; ++r) { bd[r] = 0; bk[r] = pack16(ka, ka); }
-                unsigned long long rest = gmask & ~(1ull << (ka - kbase));
+                unsigned long long rest = gm & ~(1ull << (ka - kbase));
                 int nx[H];
                 int kn = -1;
                 if (rest) {
@@ -731,8 +841,14 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
 #endif
             // (2) G: column -> code of the run-start column whose delta it carries; code = word index of the packed row
             // layout [r][lane] * 2 + half
+            {
+                // (an opaque copy of the lane: otherwise the H constants are computed once before the record loop and — the
+                // forward variant is out of registers — spilled to scratch to be reloaded here)
+                int gl = lane;
+                asm volatile("" : "+v"(gl));
 #pragma unroll
-            for (int r = 0; r < H; ++r) { const int w = r * WAVE + lane; G[r] = pack16(2 * w, 2 * w + 1); }
+                for (int r = 0; r < H; ++r) { const int w = r * WAVE + gl; G[r] = pack16(2 * w, 2 * w + 1); }
+            }
             __syncthreads();
             int ri = i, rli = li, rslot = slot, rw1 = w1;
             for (int step = 0;; ++step) {
@@ -791,13 +907,13 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
                 fetch(t, nw0, nw1, ngm);
                 ri = nw0 & 0xfffff; rli = (nw0 >> 20) & 7; rslot = nw1 & 0xfffff; rw1 = nw1;
             }
-            done += (unsigned long long)(nm - 1) * ((kRec && track) ? 2ull : 1ull);     // passes (1) and (3)
+            done += (unsigned long long)(nme - 1) * ((kRec && track) ? 2ull : 1ull);    // passes (1) and (3)
             // (3) every member once: row_k(end)[c] = A(end)[c] - A0[G(c)] + row_k(start)[G(c)]
 #ifndef RG_G_NOPH3
             {
                 int B[H];
                 __syncthreads();
-                touch_group(gmask, nm, gT);
+                touch_group(gm, nme, gT);
 #pragma unroll
                 for (int r = 0; r < H; ++r) {
                     const int c0 = G[r] & 0xffff, c1 = (unsigned)G[r] >> 16;
@@ -806,7 +922,7 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
                     B[r] = pk_sub_sat(A[r], pack16(a0, a1));
                 }
                 st_row(ka, A);
-                unsigned long long rest = gmask & ~(1ull << (ka - kbase));
+                unsigned long long rest = gm & ~(1ull << (ka - kbase));
                 int nx[H];
                 int kn = -1;
                 if (rest) {
@@ -849,11 +965,11 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
             // drains every store issued before them — in the old order (stores, next record, loads, wait) that was the whole
             // run's rows on every run boundary.  Here the wait covers loads only and the stores drain behind the next run's
             // arithmetic.  rnm / rgm / mk: the run in progress.)
-            int rnm = nm;
-            unsigned long long rgm = gmask;
+            int rnm = nme;                        // members computed (PATH RETIREMENT: the needed ones)
+            unsigned long long rgm = gmask;       // the run's record mask (what its continuation records carry)
             int mk[KRUN > 0 ? KRUN : 1];
             {
-                unsigned long long tm = rgm;
+                unsigned long long tm = kRet ? gm : rgm;
 #pragma unroll
                 for (int kk = 0; kk < KRUN; ++kk) { mk[kk] = tm ? kbase + __builtin_ctzll(tm) : 0; tm = tm ? (tm & (tm - 1)) : 0; }
             }
@@ -900,11 +1016,13 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
 #pragma unroll
                 for (int kk = 1; kk < KRUN; ++kk)
                     if (kk < rnm) RowOps16<C>::member(rr[kk], SEL, lane, MU, ML, lmask, src);
-                cells += (unsigned long long)rnm;
+                cells += (unsigned long long)__popcll(rgm);
                 done += (unsigned long long)rnm;
                 if (kRec && kColmax != 1 && tail) {
                     if (track) {
-                        if (rfl & F_FIRST) set_keys(bkey, rr[0], mk[0]); else fold_keys(bkey, rr[0], mk[0]);
+                        if (rfl & F_FIRST) row_open = false;
+                        if (!row_open) set_keys(bkey, rr[0], mk[0]); else fold_keys(bkey, rr[0], mk[0]);
+                        row_open = true;
 #pragma unroll
                         for (int kk = 1; kk < KRUN; ++kk) if (kk < rnm) fold_keys(bkey, rr[kk], mk[kk]);
                     }
@@ -973,7 +1091,7 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
             // the tail's row: its epilogue when this was its last group
             if (tail) {
                 if (semi_end && (rfl & F_LAST)) end_row_done(ri);
-                if (track && (rfl & F_LAST)) row_end(ri, ((rw1 >> 20) & 511) - 1, bkey);
+                if (track && (rfl & F_LAST) && row_open) row_end(ri, ((rw1 >> 20) & 511) - 1, bkey);
             }
             bool chain = false;
             unsigned long long gm2 = 0;
@@ -1030,9 +1148,9 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
         const int g0 = a.semi ? 0 : g_i;
         load_steps(li);          // (every record: register / gather runs of other rows may lie between the groups of one row)
         {
-            unsigned long long rest = cont ? gmask : gmask & ~(1ull << (ga - kbase));
+            unsigned long long rest = cont ? gm : gm & ~(1ull << (ga - kbase));
             cells += (unsigned long long)nm;
-            done += (unsigned long long)nm;
+            done += (unsigned long long)nme;
             int nxt[H];
 #if defined(RG_SWEEP16_NOROWS) || defined(RG_SWEEP16_NOROWS32)
 #pragma unroll
@@ -1051,9 +1169,13 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
                 RG_ROW_LD(ga, rowa);
                 unsigned umask;
                 RowOps16<C>::alpha(rowa, s, g_i, g0, lane, MU, ML, umask, lmask, src);
-                if (nm > 1) RowOps16<C>::select_steps(SEL, s, MU, g_i, g0, lane);
+                if (nme > 1) RowOps16<C>::select_steps(SEL, s, MU, g_i, g0, lane);
                 RG_ROW_ST(ga, rowa);
-                if (track) { if (flags & F_FIRST) set_keys(bkey, rowa, ga); else fold_keys(bkey, rowa, ga); }
+                if (track) {
+                    if (flags & F_FIRST) row_open = false;
+                    if (!row_open) set_keys(bkey, rowa, ga); else fold_keys(bkey, rowa, ga);
+                    row_open = true;
+                }
                 if (semi_end) end_fold(ga, i, rowa);
                 if (dirs) store_dirs(slot, umask, lmask);
             } else {
@@ -1078,7 +1200,7 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
         }
         }
         if (semi_end && (e_flags & F_LAST)) end_row_done(e_i);
-        if (track && (e_flags & F_LAST)) row_end(e_i, ((e_w1 >> 20) & 511) - 1, bkey);
+        if (track && (e_flags & F_LAST) && row_open) row_end(e_i, ((e_w1 >> 20) & 511) - 1, bkey);
         if (e_adv) ++t;
     }
     if (RG_SWEEP16_PF > 0 && !kWide) asm volatile("" :: "v"(pf_sink));
@@ -1095,9 +1217,13 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
         }
     }
     if (kColmax == 2 && a.colmax_out) {
+        // (an opaque copy of the lane: the column indices and their `c < ncols` predicates are recomputed here instead of
+        // living — spilled — across the whole record loop)
+        int ol = lane;
+        asm volatile("" : "+v"(ol));
 #pragma unroll
         for (int q = 0; q < C; ++q) {
-            const int c = lane * C + q;
+            const int c = ol * C + q;
             const int pv = cmv[kColmax == 2 ? q % H : 0];
             const int z = q >= H ? hi16(pv) : lo16(pv);
             if (c < ncols) a.colmax_out[(long long)rd * wpad + (rev ? n - c : c)] = z <= NEG16 ? NEG32 : z + c * gcost;
@@ -1109,7 +1235,8 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
         const int ql = n % C, ln = n / C;
         for (int k = lane; k < P; k += WAVE) {
             const int pv = rows[(long long)k * wrow + ln * H + (ql % H)];
-            rs->sink_val[k] = (ql >= H ? hi16(pv) : lo16(pv)) + n * gcost;
+            // (a retired path's row is stale: its true final score is below the bound k_verify checks the result against)
+            rs->sink_val[k] = (kRet && !((needed >> k) & 1ull)) ? NEG32 : (ql >= H ? hi16(pv) : lo16(pv)) + n * gcost;
         }
     }
     if (semi_end) {
@@ -1220,9 +1347,13 @@ __global__ __launch_bounds__(256) void k_colmax_rec(ExpandArgs a, int* colmax_ou
             const int key = rp[4 + q] + cc * a.gcost * 65536;              // z-space key -> value << 16 | path
             const int col = a.rev ? nread - cc : cc;
             if (col < oob || col >= nread + 1 - oob) continue;
+            // (a plain read first: the maximum only grows, so a key that does not beat what is there now never will — most keys
+            // of most records stop here, before the row lookup and the 64-bit LDS atomic)
+            const unsigned long long mine = ((unsigned long long)((unsigned)key ^ 0x80000000u) << 32) | (unsigned)(rl >> 6);
+            if (mine <= reinterpret_cast<volatile unsigned long long*>(cm_best)[col]) continue;
             const int knm = a.knm[rl >> 6];
             if (knm >= 0 && key <= knm) continue;
-            atomicMax(&cm_best[col], ((unsigned long long)((unsigned)key ^ 0x80000000u) << 32) | (unsigned)(rl >> 6));
+            atomicMax(&cm_best[col], mine);
         }
     }
     __syncthreads();
@@ -1435,7 +1566,10 @@ void launch_sweep16(const SweepArgs& a_, int nreads, int C, hipStream_t s) {
     if (split_built && a.use_split && a.fsplit && a.rsplit && a.frec && !(a.colmax_out && a.colarg_out) && a.g.P <= 64 && C <= 16) {
         a.fsteps = a.fsplit;
         a.rsteps = a.rsplit;
+        a.flead = a.fslead;
+        a.rlead = a.rslead;
     }
+    if (!(a.rev ? a.rlead : a.flead)) a.retire = 0;
     // a sweep that writes records and is not asked for column maxima skips their tracking
     if (a.frec && !a.colmax_out) launch_sweep16_c<0, true>(a, nreads, C, s);
     else if (a.frec && !a.colarg_out) launch_sweep16_c<2, true>(a, nreads, C, s);     // maxima without their cells

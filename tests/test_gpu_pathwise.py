@@ -301,9 +301,9 @@ def test_random_dag_graphs_in_every_switch_family(oracle):
     cases = ((150, 12, 301, {"max_jump": 3, "max_seg": 8}), (110, 32, 302, {"max_jump": 5, "max_seg": 12, "similar": 0.7}),
              (240, 5, 303, {"max_jump": 2, "max_seg": 4}))
     switches = (("sweep_i32", 1), ("no_frec", 1), ("three_sweeps", 1), ("no_spec", 1), ("spec_margin", 0), ("spec_margin", -1000000),
-                ("no_gather", 1), ("no_split", 1), ("chunk_reads", 5), ("layer_i32", 1))
+                ("no_gather", 1), ("no_split", 1), ("chunk_reads", 5), ("layer_i32", 1), ("no_retire", 1))
     pairs = ((("three_sweeps", 1), ("sweep_i32", 1)), (("no_split", 1), ("no_gather", 1)), (("spec_margin", -1000000), ("chunk_reads", 4)),
-             (("no_frec", 1), ("no_spec", 1)))
+             (("no_frec", 1), ("no_spec", 1)), (("no_retire", 1), ("no_split", 1)), (("no_spec", 1), ("no_gather", 1)))
     defaults = {"spec_margin": 160}
     for nseg, P, seed, kw in cases:
         g = synth.random_dag_graph(nseg, P, seed=seed, **kw)
