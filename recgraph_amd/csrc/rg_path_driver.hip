@@ -56,6 +56,7 @@ struct PathWorkImpl {
     int nfsteps = 0, nrsteps = 0;
     Buf<int4> fsplit, rsplit;         // the same records with TAILs moved behind their register runs (split_tails below)
     Buf<unsigned long long> flead, rlead, fslead, rslead;    // PATH RETIREMENT tables of the four step tables (lead_table below)
+    unsigned long long fmembers = 0, rmembers = 0;           // member rows of the forward / reverse table (sum of the group sizes)
     bool have_split = false;
     unsigned fcap = 0, rcap = 0;
     std::vector<hipEvent_t> ev;
@@ -66,7 +67,7 @@ struct PathWorkImpl {
     Buf<uint32_t> kmer_keys;
     Buf<unsigned long long> kmer_masks;
     unsigned kmer_mask = 0;
-    Buf<int> pick, rt_idx;
+    Buf<int> pick, pick2, rt_idx;
     Buf<uint8_t> rt_flags, rt_reads, rt_bad, rt_ops;
     Buf<long long> rt_off;
     Buf<DevRecord> rt_rec;
@@ -363,11 +364,12 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
                 q = e;
             }
         };
-        // PATH RETIREMENT (k_sweep16): per evaluation point e (record 256 e) and path k, the union of the member masks of the
-        // groups k LEADS in the records from 256 e on (groups with other members only): a path that is hopeless for a read may
+        // PATH RETIREMENT (k_sweep16): per evaluation point e (record e << RG_SWEEP16_RETIRE_SHIFT) and path k, the union of the member masks of the
+        // groups k LEADS in the records from there on (groups with other members only): a path that is hopeless for a read may
         // stop being computed once no path that is still needed appears in that union
         auto lead_table = [&](const std::vector<int4>& recs) {
-            const size_t E = recs.size() / 256 + 2;
+            constexpr size_t EV = (size_t)1 << RG_SWEEP16_RETIRE_SHIFT;       // records per evaluation point
+            const size_t E = recs.size() / EV + 2;
             std::vector<unsigned long long> out(E * 64, 0ull);
             unsigned long long cur[64] = {};
             for (size_t t = recs.size(); t-- > 0;) {
@@ -377,7 +379,7 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
                     const int alpha = ((x >> 23) & 4u) ? __builtin_ctzll(mask) : (int)((x >> 26) & 63u);
                     cur[alpha] |= mask;
                 }
-                if (t % 256 == 0) for (int k = 0; k < 64; ++k) out[(t / 256) * 64 + k] = cur[k];
+                if (t % EV == 0) for (int k = 0; k < 64; ++k) out[(t / EV) * 64 + k] = cur[k];
             }
             return out;
         };
@@ -386,11 +388,18 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
         if ((rc = w.fsteps.upload(st))) return rc;
         w.nfsteps = (int)st.size();
         w.have_split = P <= 64;
+        auto members = [](const std::vector<int4>& recs) {
+            unsigned long long m = 0;
+            for (const int4& r : recs) m += (unsigned long long)(__builtin_popcount((unsigned)r.z) + __builtin_popcount((unsigned)r.w));
+            return m;
+        };
+        w.fmembers = members(st);
         if (P <= 64 && (rc = w.flead.upload(lead_table(st)))) return rc;
         if (w.have_split) { split_tails(st, sp); if ((rc = w.fsplit.upload(sp)) || (rc = w.fslead.upload(lead_table(sp)))) return rc; }
         steps(h.rgoff, h.rgroups, false, st);
         if ((rc = w.rsteps.upload(st))) return rc;
         w.nrsteps = (int)st.size();
+        w.rmembers = members(st);
         if (P <= 64 && (rc = w.rlead.upload(lead_table(st)))) return rc;
         if (w.have_split) { split_tails(st, sp); if ((rc = w.rsplit.upload(sp)) || (rc = w.rslead.upload(lead_table(sp)))) return rc; }
         w.tables = true;
@@ -461,7 +470,7 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
                     (rc = w.rcand.alloc((size_t)chunk * w.rcap)) || (rc = w.ridx.alloc((size_t)chunk * w.rcap)) ||
                     (rc = w.nf.alloc(chunk)) || (rc = w.nr.alloc(chunk)) || (rc = w.lb.alloc(chunk)) || (rc = w.nrec.alloc(chunk)))
                     return rc;
-                if (spec && ((rc = w.pick.alloc(chunk)) || (rc = w.rt_flags.alloc(chunk)))) return rc;
+                if (spec && ((rc = w.pick.alloc(chunk)) || (rc = w.pick2.alloc((size_t)chunk * 2)) || (rc = w.rt_flags.alloc(chunk)))) return rc;
                 if (use_rec && ((rc = w.frec.alloc((size_t)chunk * w.frec_cap * recw)) || (rc = w.rrec.alloc((size_t)chunk * w.rrec_cap * recw)) ||
                                 (rc = w.nrrec.alloc(chunk))))
                     return rc;
@@ -498,6 +507,7 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
             // path retirement: the record pipelines of -m 8 (global), P <= 64
             sa.flead = w.flead.p; sa.rlead = w.rlead.p; sa.fslead = w.fslead.p; sa.rslead = w.rslead.p;
             sa.retire = use16 && P <= 64 && !semi && mode == RG_MODE_RECOMBINATION && gaps_nonpos && opt.no_retire != 1 ? 1 : 0;
+            sa.fmembers = w.fmembers; sa.rmembers = w.rmembers;
             sa.maxmatch = maxmatch;      // (both sweeps: the retirement bound; the forward sweep's speculative thresholds)
         }
         sa.rbw = p.rec_band_width; sa.cand_cap = 0; sa.dir_words = dir_words; sa.cells = d_cells;
@@ -510,9 +520,14 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
             TIMED(T, "k_seed", launch_seed(se, stream));
         } else {
             if (two_sweep) {
-                Opt0Args oa{gd, sa.sc, d_reads, off, bad, w.fpoff.p, w.fprow.p, w.lb.p, semi ? 1 : 0, nullptr, 0, nwv};
+                Opt0Args oa{gd, sa.sc, d_reads, off, bad, w.fpoff.p, w.fprow.p, w.lb.p, semi ? 1 : 0, nullptr, 0, nwv, nullptr, 0};
                 if (spec) {
-                    PickArgs pa{d_reads, off, bad, w.kmer_keys.p, w.kmer_masks.p, w.kmer_mask, P, w.pick.p};
+                    // (two-path picks: one-wave reads, global mode)
+                    const bool pick_two = nwv == 1 && !semi && !opt.no_pick2;
+                    PickArgs pa{d_reads, off, bad, w.kmer_keys.p, w.kmer_masks.p, w.kmer_mask, P, w.pick.p, w.fpoff.p, w.fprow.p,
+                                pick_two ? w.pick2.p : nullptr};
+                    oa.pick2 = pa.pick2;
+                    oa.rec_pen = p.base_rec_cost + (int)std::ceil(p.multi_rec_cost * 8.0f);
                     TIMED(T, "k_pick", launch_pick(pa, chunk, stream));
                     oa.pick = w.pick.p;
                     oa.margin = spec_margin;
@@ -538,7 +553,7 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
                 TIMED(T, use16 ? "k_sweep16_fwd_colmax" : "k_sweep_fwd_colmax", sweep(f1, chunk));
                 TIMED(T, "k_seed", launch_seed(se, stream));
             }
-            ThrArgs t1{w.state.p, w.mf.p, w.thr.p, wpad, p.base_rec_cost, 0};
+            ThrArgs t1{w.state.p, w.mf.p, w.thr.p, wpad, p.base_rec_cost, 0, two_sweep ? w.lb.p : nullptr};
             TIMED(T, "k_threshold", launch_threshold(t1, chunk, stream));
             SweepArgs r = sa;
             r.rev = 1; r.track_best = 1; r.thr = w.thr.p; r.colmax_out = w.wr.p; r.colarg_out = w.wrarg.p; r.cand = w.rcand.p; r.cand_cap = w.rcap; r.ncand_out = w.nr.p;
@@ -563,7 +578,7 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
                          p.rec_band_width};
             TIMED(T, "k_bound", launch_bound(ba, chunk, stream));
             if (!two_sweep) {
-                ThrArgs t2{w.state.p, w.wr.p, w.thr.p, wpad, p.base_rec_cost, 1};
+                ThrArgs t2{w.state.p, w.wr.p, w.thr.p, wpad, p.base_rec_cost, 1, nullptr};
                 TIMED(T, "k_threshold", launch_threshold(t2, chunk, stream));
                 SweepArgs f2 = sa;
                 f2.rev = 0; f2.track_best = 1; f2.thr = w.thr.p; f2.cand = w.fcand.p; f2.cand_cap = w.fcap; f2.ncand_out = w.nf.p;

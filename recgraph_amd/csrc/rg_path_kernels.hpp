@@ -2,6 +2,9 @@
 #pragma once
 #include "rg_path_args.hpp"
 
+#ifndef RG_SWEEP16_RETIRE_SHIFT
+#define RG_SWEEP16_RETIRE_SHIFT 8
+#endif
 namespace rg {
 
 // per-read scalar state carried between the kernels of one batch
@@ -63,12 +66,15 @@ struct SweepArgs {
     int nwv;                   // waves (column stripes of 2048) per read: > 1 for reads longer than 2047 bases (k_sweep<32, true, true>)
     int gather_ok;             // k_sweep16 gather runs: the difference of two members' packed values provably fits 16 bits
     // k_sweep16 PATH RETIREMENT (record pipelines, P <= 64): per 256 records of the step table and per path, the union of the
-    // member masks of the groups the path leads from there on ([evaluation point][64]); one table per step table
+    // member masks of the groups the path leads from there on ([evaluation point][64]); one table per step table.
+    // Evaluation points: every 2^RG_SWEEP16_RETIRE_SHIFT records (kernel and table builder share the constant)
     const unsigned long long* flead;
     const unsigned long long* rlead;
     const unsigned long long* fslead;   // ... of the split tables
     const unsigned long long* rslead;
     int retire;
+    unsigned long long table_members;   // member rows of the step table in use (k_sweep16 with path retirement counts cells from it)
+    unsigned long long fmembers, rmembers;
 };
 
 // expands the (row, lane) records of the forward sweep into Cand entries, keeping only cells that can still reach
@@ -108,6 +114,8 @@ struct ThrArgs {
     int wpad;
     int brc;
     int use_bound;             // 0: S0, 1: the tighter bound of k_bound
+    const int* lb;             // the forward sweep's lower bound of the search maximum (or null): the base is at least that — with
+                               // a two-path pick it lies above the seed; k_verify checks the speculative ones afterwards
 };
 
 struct BoundArgs {
@@ -134,6 +142,8 @@ struct Opt0Args {
     const int* pick;           // ... or against path pick[rd], minus `margin`: the SPECULATIVE bound (see k_pick)
     int margin;
     int nwv;                   // column stripes per read (> 1: k_opt0_striped)
+    const int* pick2;          // two-path picks {p2 or -1, X} (PickArgs), or null
+    int rec_pen;               // what a two-path bound pays for its switch: base recombination cost + displacement allowance
 };
 
 // Speculative lower bound of the -m 8 search maximum.  The forward sweep of the two-sweep pipeline emits every cell that
@@ -152,6 +162,13 @@ struct PickArgs {
     unsigned table_mask;       // table size - 1 (power of two)
     int P;
     int* pick;                 // out: path with the most votes (lowest id on ties; 0 when nothing matched)
+    // TWO-PATH PICK (reads that switch haplotype once: half of config 5).  The votes are per sample position, so the wave
+    // also finds the split t and the paths (p1, p2) that maximise votes_{< t}(p1) + votes_{>= t}(p2); when that beats the
+    // one-path vote clearly, pick2[rd] = {p2, X}: X = a row both paths visit near the split.  k_opt0 then aligns the read
+    // against p1's rows <= X followed by p2's rows > X — the alignment a recombination p1 -> p2 behind the shared segment
+    // realises — and the bound is that score minus the recombination cost.  Speculative like the one-path pick.
+    const int* fpoff; const int* fprow;
+    int* pick2;                // out (null: one-path picks only): {p2 or -1, X}
 };
 constexpr uint32_t ST_RETRY = 0x200u;   // internal: the speculative bound of this read did not hold
 

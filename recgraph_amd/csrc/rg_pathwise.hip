@@ -529,10 +529,23 @@ __global__ __launch_bounds__(64) void k_opt0(Opt0Args a) {
         for (int q = 0; q < C; ++q) { GP[q] += pre; row[q] = lane * C + q < ncols ? GP[q] : NEG; }
     }
     const int pk = a.pick ? a.pick[rd] : 0;      // (only path 0's score is a provable bound: see PickArgs)
-    const int beg = a.fpoff[pk], cnt = a.fpoff[pk + 1] - beg;
+    // (two-path pick: p1's rows <= X, then p2's rows > X)
+    const int pk2 = (a.pick && a.pick2) ? a.pick2[2 * rd] : -1;
+    const int X = pk2 >= 0 ? a.pick2[2 * rd + 1] : INT32_MAX;
+    int beg = a.fpoff[pk], cnt = a.fpoff[pk + 1] - beg;
     int semibest = NEG;
+    bool second = false;
     for (int t = 0; t < cnt; ++t) {
         const int i = a.fprow[beg + t];
+        if (i > X && !second) {
+            // switch lists: first row of p2 above X (its list is ascending)
+            second = true;
+            beg = a.fpoff[pk2]; cnt = a.fpoff[pk2 + 1] - beg;
+            int lo = 0, hi = cnt;
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (a.fprow[beg + mid] <= X) lo = mid + 1; else hi = mid; }
+            t = lo - 1;
+            continue;
+        }
         const int li = g.lnz[i];
         const int g_i = sct[li * 6 + GAP];
         int prev_old = dpp_shr1(row[C - 1], NEG);
@@ -568,7 +581,7 @@ __global__ __launch_bounds__(64) void k_opt0(Opt0Args a) {
     int v = NEG;
 #pragma unroll
     for (int q = 0; q < C; ++q) if (q == ql) v = row[q];
-    if (lane == ln) a.lb[rd] = (a.semi ? semibest : v) - (a.pick ? a.margin : 0);
+    if (lane == ln) a.lb[rd] = (a.semi ? semibest : v) - (a.pick ? a.margin : 0) - (pk2 >= 0 ? a.rec_pen : 0);
 }
 
 // The same for reads longer than 2047 bases: a.nwv waves per read, wave w owns columns [w * 64 * C, (w + 1) * 64 * C) and runs
@@ -645,7 +658,7 @@ __global__ __launch_bounds__(64) void k_pick(PickArgs a) {
     __shared__ unsigned long long smask[256];
     constexpr int K = 12;
     const int npos = n - K + 1;
-    if (a.bad[rd] || npos < 1) { if (lane == 0) a.pick[rd] = 0; return; }
+    if (a.bad[rd] || npos < 1) { if (lane == 0) { a.pick[rd] = 0; if (a.pick2) { a.pick2[2 * rd] = -1; a.pick2[2 * rd + 1] = 0; } } return; }
     const int step = (npos + 255) / 256;
     const int nsamp = (npos + step - 1) / step;             // <= 256
     for (int t = lane; t < 256; t += WAVE) {
@@ -673,7 +686,45 @@ __global__ __launch_bounds__(64) void k_pick(PickArgs a) {
     if (lane >= a.P) votes = -1;
     int key = (votes << 8) | (255 - lane);                   // most votes, lowest path id on ties
     for (int d = WAVE / 2; d >= 1; d >>= 1) key = max(key, __shfl_xor(key, d, WAVE));
-    if (lane == 0) a.pick[rd] = (key >> 8) > 0 ? 255 - (key & 255) : 0;
+    const int best1 = key >> 8;
+    const int p_one = best1 > 0 ? 255 - (key & 255) : 0;
+    if (lane == 0) a.pick[rd] = p_one;
+    if (!a.pick2) return;
+    // two-path pick: split t in [1, nsamp): pre = this path's votes among samples [0, t)
+    int pre = 0, bestsum = -1, bt = 0, bp1 = 0, bp2 = 0;
+    for (int t = 1; t < nsamp; ++t) {
+        pre += (int)((smask[t - 1] >> lane) & 1ull);
+        int k1 = lane < a.P ? ((pre << 8) | (255 - lane)) : -1;
+        int k2 = lane < a.P ? (((votes - pre) << 8) | (255 - lane)) : -1;
+        k1 = __builtin_amdgcn_readlane(dpp_incl_max(k1, INT32_MIN), WAVE - 1);
+        k2 = __builtin_amdgcn_readlane(dpp_incl_max(k2, INT32_MIN), WAVE - 1);
+        const int sum = (k1 >> 8) + (k2 >> 8);
+        if (sum > bestsum) { bestsum = sum; bt = t; bp1 = 255 - (k1 & 255); bp2 = 255 - (k2 & 255); }
+    }
+    int p2 = -1, X = 0;
+    // worth it when the two paths explain clearly more samples than one (each sample spans K bases: a switch costs the
+    // one-path alignment a mismatch or so per differing allele, i.e. per few samples)
+    if (bp1 != bp2 && bestsum >= best1 + 6) {
+        // a row of p1 that p2 visits too, at or behind the split (list index ~ read column: the walks are global)
+        const int b1 = a.fpoff[bp1], c1 = a.fpoff[bp1 + 1] - b1, b2 = a.fpoff[bp2], c2 = a.fpoff[bp2 + 1] - b2;
+        const int col = bt * step + K / 2;
+        const int i0 = min(max((int)((long long)col * c1 / max(n, 1)), 0), max(c1 - 1, 0));
+        unsigned long long found = 0;
+        int myrow = -1;
+        for (int base = i0; base < c1 && !found; base += WAVE) {
+            myrow = -1;
+            if (base + lane < c1) {
+                myrow = a.fprow[b1 + base + lane];
+                int lo = 0, hi = c2;
+                while (lo < hi) { const int mid = (lo + hi) >> 1; if (a.fprow[b2 + mid] < myrow) lo = mid + 1; else hi = mid; }
+                if (!(lo < c2 && a.fprow[b2 + lo] == myrow)) myrow = -1;
+            }
+            found = __ballot(myrow >= 0);
+            if (base - i0 >= 3 * WAVE) break;
+        }
+        if (found) { X = __shfl(myrow, __builtin_ctzll(found), WAVE); p2 = bp2; if (lane == 0) a.pick[rd] = bp1; }
+    }
+    if (lane == 0) { a.pick2[2 * rd] = p2; a.pick2[2 * rd + 1] = X; }
 }
 
 // After k_search: the speculation held iff the maximum found is >= the bound the forward sweep pruned with.
@@ -769,7 +820,9 @@ __global__ void k_threshold(ThrArgs a) {
     const ReadState* rs = a.state + rd;
     const long long o = (long long)rd * a.wpad + j;
     const int cm = a.colmax[o];
-    a.thr[o] = cm <= NEG ? INT32_MAX : (a.use_bound ? rs->bound : rs->s0) + a.brc - cm;
+    int base = a.use_bound ? rs->bound : rs->s0;
+    if (a.lb) base = max(base, a.lb[rd]);
+    a.thr[o] = cm <= NEG ? INT32_MAX : base + a.brc - cm;
 }
 
 // Lower bound of the search maximum: the exact score of the pair (best forward cell, best reverse cell)

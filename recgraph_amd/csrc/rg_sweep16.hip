@@ -416,7 +416,7 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
             }
 #pragma unroll
             for (int r = 0; r < H; ++r) rvl[r * WAVE + lane] = pack16(tv[r], tv[r + H]);
-            if ((rev ? a.thr != nullptr : a.lb != nullptr) && !__any(ovf)) next_eval = 256;
+            if ((rev ? a.thr != nullptr : a.lb != nullptr) && !__any(ovf)) next_eval = 1 << RG_SWEEP16_RETIRE_SHIFT;
         }
     }
     __syncthreads();
@@ -559,12 +559,25 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
     if (lane < nsteps) recs = steps[lane];
     if (WAVE + lane < nsteps) recs_next = steps[WAVE + lane];
     int t = 0;
+    int blk = 0;                         // the 64-record block `recs` holds (recs_next: the one behind it)
+    // PATH RETIREMENT: the records of the block in `recs` that still have to be looked at — a needed member, or the last group
+    // of a row with several groups (it closes the row even when skipped); the record loop jumps over the others
+    unsigned long long live = ~0ull;
+    unsigned long long needed = a.g.P >= 64 ? ~0ull : ((1ull << a.g.P) - 1ull);
+    auto block_live = [&]() -> unsigned long long {
+        const unsigned f = ((unsigned)recs.x >> 23) & 7u, field = ((unsigned)recs.x >> 26) & 63u;
+        const bool is_run = (f & 4u) && field != 0u;
+        const unsigned long long m = ((unsigned long long)(unsigned)recs.w << 32) | (unsigned)recs.z;
+        return __ballot((m & needed) != 0ull || (!is_run && (f & 3u) == 2u));
+    };
     auto fetch = [&](int tt, int& w0, int& w1, unsigned long long& gmask) {
         const int idx = tt & (WAVE - 1);
-        if (idx == 0 && tt > 0) {
+        if ((tt >> 6) != blk) {           // (records are taken in order: the next block)
             recs = recs_next;
-            const int nb = tt + WAVE + lane;
+            blk = tt >> 6;
+            const int nb = (blk + 1) * WAVE + lane;
             recs_next = nb < nsteps ? steps[nb] : make_int4(0, 0, 0, 0);
+            if (kRet) live = block_live();
         }
         w0 = __builtin_amdgcn_readlane(recs.x, idx);
         w1 = __builtin_amdgcn_readlane(recs.y, idx);
@@ -575,7 +588,7 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
     // flags of record tt without consuming it (same or next batch)
     auto peek_w0 = [&](int tt) -> int {
         const int idx = tt & (WAVE - 1);
-        return idx == 0 && tt > 0 ? __builtin_amdgcn_readlane(recs_next.x, 0) : __builtin_amdgcn_readlane(recs.x, idx);
+        return (tt >> 6) != blk ? __builtin_amdgcn_readlane(recs_next.x, 0) : __builtin_amdgcn_readlane(recs.x, idx);
     };
 
     // ROW TOUCHES (RG_SWEEP16_PF=1; off: measured slower).  The loops below keep ONE row load in flight (the next member's), and
@@ -588,7 +601,7 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
     int pf_sink = 0;
     const int pf_off = ((lane & 15) * 32) & (wrow - 1);       // one word per 128-byte line of a row
     auto peek_mask = [&](int tt) -> unsigned long long {      // members of record tt (0: outside the batches held / past the end)
-        const int d = tt - (t & ~(WAVE - 1));
+        const int d = tt - blk * WAVE;
         if (tt >= nsteps || d >= 2 * WAVE) return 0ull;
         const unsigned z = (unsigned)(d < WAVE ? __builtin_amdgcn_readlane(recs.z, d) : __builtin_amdgcn_readlane(recs_next.z, d - WAVE));
         const unsigned w = (unsigned)(d < WAVE ? __builtin_amdgcn_readlane(recs.w, d) : __builtin_amdgcn_readlane(recs_next.w, d - WAVE));
@@ -629,7 +642,7 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
     // members of record tt without consuming it (like peek_w0: tt = the record the next fetch will take)
     auto peek_gm = [&](int tt) -> unsigned long long {
         const int idx = tt & (WAVE - 1);
-        const bool nxt = idx == 0 && tt > 0;
+        const bool nxt = (tt >> 6) != blk;
         const unsigned z = (unsigned)(nxt ? __builtin_amdgcn_readlane(recs_next.z, 0) : __builtin_amdgcn_readlane(recs.z, idx));
         const unsigned w = (unsigned)(nxt ? __builtin_amdgcn_readlane(recs_next.w, 0) : __builtin_amdgcn_readlane(recs.w, idx));
         return ((unsigned long long)w << 32) | z;
@@ -708,7 +721,7 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
     int MU[H], ML[H], SEL[H];
     unsigned lmask = 0;                  // L mask and fill-forward source lane of the current group's alpha: live across
     int src = 0;                         // the continuation entries of a group that spans 64-path pages
-    // PATH RETIREMENT (kRet): `needed` = the paths whose rows are still computed.  Every 256 records (at the top of the record
+    // PATH RETIREMENT (kRet): `needed` = the paths whose rows are still computed.  Every 2^RG_SWEEP16_RETIRE_SHIFT records (at the top of the record
     // loop: every row is in memory there) the hopeless paths are found (one pass over each needed row against the constants
     // in rvl) and a hopeless path is retired unless it still LEADS a group with a needed member further down the table — its
     // decisions are that member's directions — iterated to the fixpoint (lead: per evaluation point and path, the union of
@@ -716,20 +729,32 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
     // never read again: it cannot emit, it cannot be a cell's best member where something emits, its sink value is below
     // the bound k_verify checks; the needed paths see exactly the decisions they would see in the full sweep.
     // tests/c/band_experiment.cpp measures why this — not a column band — is the exact way to skip hopeless work here.
-    unsigned long long needed = P >= 64 ? ~0ull : ((1ull << P) - 1ull);
     bool row_open = false;               // some group of the current several-group row has put its keys into bkey
     auto retire_eval = [&](int e) {
         unsigned long long hop = 0, todo = needed;
+        // (four rows in flight per wait: one row per wait made the evaluations ~8 % of the sweep)
+        constexpr int EB = C <= 16 ? 4 : 2;
         while (todo) {
-            const int k = __builtin_ctzll(todo);
-            todo &= todo - 1;
-            int tmp[H];
-            ld_row(k, tmp);
-            int m = pk_add_sat(tmp[0], rvl[lane]);            // (constants from LDS every time: no registers held across the loop)
+            int kq[EB];
+            int tmp[EB][H];
 #pragma unroll
-            for (int r = 1; r < H; ++r) m = pk_max(m, pk_add_sat(tmp[r], rvl[r * WAVE + lane]));
-            const int v = max(lo16(m), hi16(m));
-            if (__builtin_amdgcn_readlane(dpp_incl_max(v, INT32_MIN), WAVE - 1) < 0) hop |= 1ull << k;
+            for (int u = 0; u < EB; ++u) {
+                kq[u] = -1;
+                if (todo) {
+                    kq[u] = __builtin_ctzll(todo);
+                    todo &= todo - 1;
+                    ld_row(kq[u], tmp[u]);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < EB; ++u) {
+                if (kq[u] < 0) break;
+                int m = pk_add_sat(tmp[u][0], rvl[lane]);         // (constants from LDS every time: no registers held across the loop)
+#pragma unroll
+                for (int r = 1; r < H; ++r) m = pk_max(m, pk_add_sat(tmp[u][r], rvl[r * WAVE + lane]));
+                const int v = max(lo16(m), hi16(m));
+                if (__builtin_amdgcn_readlane(dpp_incl_max(v, INT32_MIN), WAVE - 1) < 0) hop |= 1ull << kq[u];
+            }
         }
         const unsigned long long lead_k = lane < P ? (rev ? a.rlead : a.flead)[(long long)e * 64 + lane] : 0ull;
         unsigned long long nd = needed & ~hop;
@@ -743,6 +768,19 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
     while (t < nsteps) {
         int w0, w1;
         unsigned long long gmask;
+        if (kRet && next_eval != INT32_MAX) {
+            // evaluation points; then jump over the records nothing is left to do for (a skipped record costs nothing: with a
+            // fetch and a test each they were a seventh of the sweep once half the member rows were retired)
+            if ((t >> 6) != blk) fetch(t, w0, w1, gmask);           // (moves to t's block; the record is fetched again below)
+            if (t >= next_eval) [[unlikely]] {
+                retire_eval(t >> RG_SWEEP16_RETIRE_SHIFT);
+                next_eval = (t | ((1 << RG_SWEEP16_RETIRE_SHIFT) - 1)) + 1;
+                live = block_live();
+            }
+            const unsigned long long m = live >> (t & (WAVE - 1));
+            if (m == 0ull) { t = (t | (WAVE - 1)) + 1; continue; }
+            t += __builtin_ctzll(m);
+        }
         fetch(t, w0, w1, gmask);
         const int i = w0 & 0xfffff;
         const int li = (w0 >> 20) & 7;
@@ -762,7 +800,6 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
         // run costs ~180 instructions per member once per run (two passes) + ~160 per row, the member-by-member form ~77 per
         // member and row: it pays when R * (77 (nm - 1) - 160) >= 200 (nm - 1)  (32 paths: 3 rows, 8 paths: 4, 5 paths: 6)
         const int run_left = (flags & F_INNER) ? ((w0 >> 26) & 63) : 0;
-        if (kRet && t >= next_eval) [[unlikely]] { retire_eval(t >> 8); next_eval = (t | 255) + 1; }
         const unsigned long long gm = kRet ? (gmask & needed) : gmask;     // the members still computed
         const int nme = kRet ? __popcll(gm) : nm;
         if (kRet && gm == 0ull) {
@@ -773,6 +810,7 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
             if (run_left == 0) {
                 if (flags & F_FIRST) row_open = false;
                 if (track && (flags & F_LAST) && row_open) row_end(i, ((w1 >> 20) & 511) - 1, bkey);
+                if (flags & F_LAST) row_open = false;
             }
             ++t;
             continue;
@@ -994,9 +1032,9 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
                 // the record behind the run (and behind its tail): that load is in flight while the run computes
                 __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0)
                 int nt = t + max(run_left, 1);
-                if (nt < nsteps && nt - (t & ~(WAVE - 1)) < 2 * WAVE) {
-                    const int pw = nt - (t & ~(WAVE - 1)) < WAVE ? __builtin_amdgcn_readlane(recs.x, (nt - (t & ~(WAVE - 1))) & (WAVE - 1))
-                                                                 : __builtin_amdgcn_readlane(recs_next.x, (nt - (t & ~(WAVE - 1))) & (WAVE - 1));
+                if (nt < nsteps && nt - blk * WAVE < 2 * WAVE) {
+                    const int pw = nt - blk * WAVE < WAVE ? __builtin_amdgcn_readlane(recs.x, (nt - blk * WAVE) & (WAVE - 1))
+                                                          : __builtin_amdgcn_readlane(recs_next.x, (nt - blk * WAVE) & (WAVE - 1));
                     if (((pw >> 23) & F_INNER) && ((pw >> 26) & 63) == 0) ++nt;       // a tail: same rows as the run
                 }
                 pf_next = touch4(peek_mask(nt));
@@ -1092,6 +1130,7 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
             if (tail) {
                 if (semi_end && (rfl & F_LAST)) end_row_done(ri);
                 if (track && (rfl & F_LAST) && row_open) row_end(ri, ((rw1 >> 20) & 511) - 1, bkey);
+                if (rfl & F_LAST) row_open = false;
             }
             bool chain = false;
             unsigned long long gm2 = 0;
@@ -1201,6 +1240,7 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
         }
         if (semi_end && (e_flags & F_LAST)) end_row_done(e_i);
         if (track && (e_flags & F_LAST) && row_open) row_end(e_i, ((e_w1 >> 20) & 511) - 1, bkey);
+        if (e_flags & F_LAST) row_open = false;       // (so that a skipped FIRST record of a later row has nothing to reset)
         if (e_adv) ++t;
     }
     if (RG_SWEEP16_PF > 0 && !kWide) asm volatile("" :: "v"(pf_sink));
@@ -1244,7 +1284,10 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
         if (lane == ln_end) { rs->s0 = gbest_val; rs->end_row_best = gbest_row; rs->seed_path = gbest_path; }
     }
     if (lane == 0 && a.count_cells) {
-        atomicAdd(a.cells, cells * (unsigned long long)(n + 1));
+        // counted: every member row of the table (what the reference updates) — from the table builder when records may have
+        // been jumped over; performed: what this wave carried out
+        const unsigned long long all = kRet && a.table_members ? a.table_members : cells;
+        atomicAdd(a.cells, all * (unsigned long long)(n + 1));
         atomicAdd(a.cells + 1, done * (unsigned long long)(n + 1));
     }
 }
@@ -1570,6 +1613,7 @@ void launch_sweep16(const SweepArgs& a_, int nreads, int C, hipStream_t s) {
         a.rlead = a.rslead;
     }
     if (!(a.rev ? a.rlead : a.flead)) a.retire = 0;
+    a.table_members = a.rev ? a.rmembers : a.fmembers;
     // a sweep that writes records and is not asked for column maxima skips their tracking
     if (a.frec && !a.colmax_out) launch_sweep16_c<0, true>(a, nreads, C, s);
     else if (a.frec && !a.colarg_out) launch_sweep16_c<2, true>(a, nreads, C, s);     // maxima without their cells

@@ -84,13 +84,38 @@ def test_c5_m8_properties(oracle, c5):
     assert not bad, (len(bad), bad[:5], texts[bad[0]][-200:], exp[bad[0]][-200:])
     # the same reads with a ZERO speculation margin (k_verify sends every read whose optimum is not its picked path's score
     # through the second pass with the provable bound) and with the plain step tables: the same bytes
-    for name, val in (("spec_margin", 0), ("no_split", 1), ("no_retire", 1)):
+    for name, val in (("spec_margin", 0), ("no_split", 1), ("no_retire", 1), ("no_pick2", 1)):
         try:
             api.set_option(name, val)
             again, _ = api.align_batch(g, reads[:64], names[:64], mode=api.MODE_RECOMBINATION)
         finally:
             api.set_option(name, 160 if name == "spec_margin" else 0)
         assert again == texts[:64], name
+
+
+def test_c5_path_retirement_skips_work_and_says_so(c5):
+    """Path retirement (k_sweep16) and the two-path pick are exact — the byte comparisons above — and they must actually
+    bite at config 5: the `performed` counter (member-row updates the sweeps carried out) falls clearly below its value
+    with retirement off, while the `counted` one (the reference's cell updates: the unit of the CUPS figures) does not
+    move."""
+    from recgraph_amd import api
+    sg, reads, g = c5
+    got = {}
+    for key, opts in (("default", ()), ("no_retire", (("no_retire", 1),)), ("one_path_picks", (("no_pick2", 1),))):
+        try:
+            for name, val in opts:
+                api.set_option(name, val)
+            b = api.Batch(g, reads[:256], api.make_params(api.MODE_RECOMBINATION))
+            b.run()
+            b.fetch()
+            got[key] = (b.cell_updates, b.cell_updates_performed)
+        finally:
+            for name, _ in opts:
+                api.set_option(name, 0)
+    assert got["default"][0] == got["no_retire"][0] == got["one_path_picks"][0]
+    assert got["default"][1] < 0.85 * got["no_retire"][1], got
+    assert got["default"][1] <= got["one_path_picks"][1], got
+    assert got["no_retire"][1] <= got["no_retire"][0]
 
 
 def test_c5_huge_recombination_cost_equals_best_single_path(c5):

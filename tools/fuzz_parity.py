@@ -73,6 +73,9 @@ while time.time() < t_end and not fails:
             b, f = float(rng.choice([1.0, 5.0, 30.0])), float(rng.choice([0.01, 0.1, 1.0]))
             kw.update(b=b, f=f); okw.update(b=b, f=f)
         rd = reads if mode in [m for m, _ in PATH_MODES] else [r_[:400] for r_ in reads]
+        if os.environ.get("FUZZ_VERBOSE"):
+            print("it", it, "P", P, "plen", plen, "rows", sg.rows, "mode", mode, "variant", variant, kw if sc is None else {k: v for k, v in kw.items() if k != "score_matrix"},
+                  "reads", [len(q) for q in rd], file=sys.stderr, flush=True)
         texts, status = api.align_batch(g, rd, names, mode=mode, **kw)
         for i, q in enumerate(rd):
             exp, _, panic, _ = og.align(om, q, name=names[i], idx=i + 1, **okw)
