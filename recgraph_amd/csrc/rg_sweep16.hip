@@ -816,7 +816,7 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
             continue;
         }
         if (RG_SWEEP16_GATHER && (kRec ? (kColmax == 0 || (kColmax == 2 && RG_SWEEP16_GATHER_FWD)) : !track) && !kWide && a.gather_ok && !semi_end && (flags & F_INNER) && nm > KRUN &&
-            run_left * (77 * (nm - 1) - 160) >= 200 * (nm - 1)) {
+            (!kRet || nme > KRUN) && run_left * (77 * (nm - 1) - 160) >= 200 * (nm - 1)) {
             // ---- GATHER RUN: R consecutive inner rows of a segment that a wide group (nm paths, one group, alpha = its lowest
             // path) runs through.  Every member follows the alpha's directions, and a direction only MOVES values (D: from
             // column c - 1 of the row above, U: from column c, L: from column c - 1 of the new row) and adds a constant that
@@ -993,7 +993,11 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
         }
         int e_i = i, e_w1 = w1, e_flags = flags;   // the row whose epilogue runs at the end of this iteration
         bool e_adv = true;
-        if (KRUN > 0 && (flags & F_INNER) && nm <= KRUN && run_left > 0) {
+        // (PATH RETIREMENT: a wide group of which <= KRUN members are left runs here too — a gather run costs two member
+        // updates per row whatever is left of the group; like a gather run it leaves bkey alone, which is what the split
+        // tables count on for the runs between the groups of a row)
+        if (KRUN > 0 && (flags & F_INNER) && (nm <= KRUN || (kRet && nme <= KRUN && RG_SWEEP16_GATHER && !kWide && a.gather_ok && !semi_end &&
+                                                             run_left * (77 * (nm - 1) - 160) >= 200 * (nm - 1))) && run_left > 0) {
             // ---- inner rows of a segment with a small group: the same paths, one group, predecessor = previous row.
             // Their rows stay in registers for the whole run: no row load/store latency, no HBM traffic.  The group
             // alpha of an inner row is its lowest path (alphas[row] == alphas[pred], rg_graph.cpp) = member 0.
