@@ -332,7 +332,7 @@ int32_t rg_stream_handles(rg_stream* s);      /* batch handles that aligned at l
  * most reads one pathwise kernel launch takes), "no_gather" / "no_split" (RG_NO_GATHER / RG_NO_SPLIT: k_sweep16 without its gather runs / on the
  * plain step tables), "layer_i32" (RG_LAYER_I32: the layer rebuild in its i32 form), "no_retire" (RG_NO_RETIRE: k_sweep16 computes
  * every path to the end; 2 / 3: retirement in the forward / reverse sweep only), "no_pick2" (RG_NO_PICK2: the speculative
- * bound from one-path picks only), "stripe_c" (RG_STRIPE_C: 8, 16 or 32 columns per lane for reads longer
+ * bound from one-path picks only), "no_order" (RG_NO_ORDER: the sweeps' waves in read order instead of longest first), "stripe_c" (RG_STRIPE_C: 8, 16 or 32 columns per lane for reads longer
  * than 2047 bases; 0 = 16 up to 8191 bases, 32 beyond), "spin_wait" (RG_SPIN_WAIT: hipStreamSynchronize instead of sleep-polling
  * for the long waits), "debug" (RG_DEBUG: list statistics on stderr).
  * The variants compute the same records byte for byte (tests/test_gpu_pathwise.py). */

@@ -33,6 +33,7 @@ struct Options {
     std::atomic<int> lb_bonus{0};       // RG_LB_BONUS (experiments only): added to the forward sweep's lower bound; > 0 may drop candidates
     std::atomic<int> stripe_c{0};       // RG_STRIPE_C: columns per lane of the striped long-read kernels (8, 16, 32; 0: 16 up to 8191 bases, else 32)
     std::atomic<int> no_retire{0};      // RG_NO_RETIRE: k_sweep16 computes every path to the end (no path retirement)
+    std::atomic<int> no_order{0};       // RG_NO_ORDER: the sweeps' waves in read order (no longest-first launch order)
     std::atomic<int> no_pick2{0};       // RG_NO_PICK2: the speculative bound from one-path picks only (no two-path picks)
     std::atomic<int> layer_i32{0};      // RG_LAYER_I32: k_layer in its i32 form even when the sweep ran packed (test hook)
     std::atomic<int> chunk_reads{0};    // RG_CHUNK_READS: most reads one pathwise kernel launch takes (0: what the HBM budget allows, <= 8192)

@@ -67,7 +67,7 @@ struct PathWorkImpl {
     Buf<uint32_t> kmer_keys;
     Buf<unsigned long long> kmer_masks;
     unsigned kmer_mask = 0;
-    Buf<int> pick, pick2, rt_idx;
+    Buf<int> pick, pick2, order, rt_idx;
     Buf<uint8_t> rt_flags, rt_reads, rt_bad, rt_ops;
     Buf<long long> rt_off;
     Buf<DevRecord> rt_rec;
@@ -470,7 +470,7 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
                     (rc = w.rcand.alloc((size_t)chunk * w.rcap)) || (rc = w.ridx.alloc((size_t)chunk * w.rcap)) ||
                     (rc = w.nf.alloc(chunk)) || (rc = w.nr.alloc(chunk)) || (rc = w.lb.alloc(chunk)) || (rc = w.nrec.alloc(chunk)))
                     return rc;
-                if (spec && ((rc = w.pick.alloc(chunk)) || (rc = w.pick2.alloc((size_t)chunk * 2)) || (rc = w.rt_flags.alloc(chunk)))) return rc;
+                if (spec && ((rc = w.pick.alloc(chunk)) || (rc = w.pick2.alloc((size_t)chunk * 2)) || (rc = w.order.alloc(chunk)) || (rc = w.rt_flags.alloc(chunk)))) return rc;
                 if (use_rec && ((rc = w.frec.alloc((size_t)chunk * w.frec_cap * recw)) || (rc = w.rrec.alloc((size_t)chunk * w.rrec_cap * recw)) ||
                                 (rc = w.nrrec.alloc(chunk))))
                     return rc;
@@ -529,6 +529,10 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
                     oa.pick2 = pa.pick2;
                     oa.rec_pen = p.base_rec_cost + (int)std::ceil(p.multi_rec_cost * 8.0f);
                     TIMED(T, "k_pick", launch_pick(pa, chunk, stream));
+                    if (sa.retire && !opt.no_order) {
+                        launch_order(w.pick.p, pa.pick2, w.order.p, chunk, stream);
+                        sa.order = w.order.p;
+                    }
                     oa.pick = w.pick.p;
                     oa.margin = spec_margin;
                 }

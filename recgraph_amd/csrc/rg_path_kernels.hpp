@@ -73,6 +73,7 @@ struct SweepArgs {
     const unsigned long long* fslead;   // ... of the split tables
     const unsigned long long* rslead;
     int retire;
+    const int* order;                   // launch order of the reads (block b sweeps read order[b]) or null: see launch_order
     unsigned long long table_members;   // member rows of the step table in use (k_sweep16 with path retirement counts cells from it)
     unsigned long long fmembers, rmembers;
 };
@@ -235,6 +236,10 @@ void launch_colmax_rec(const ExpandArgs& a, int* colmax_out, int* colarg_out, in
 void launch_seed(const SeedArgs& a, hipStream_t s);
 void launch_opt0(const Opt0Args& a, int nreads, int C, hipStream_t s);
 void launch_pick(const PickArgs& a, int nreads, hipStream_t s);
+// Launch order of the sweeps' waves under path retirement: the work of a read grows with the highest id among its picked
+// paths (every lower path leads it somewhere), from a few percent of a full sweep to all of it — longest first,
+// so that the launch does not end on a few full-length waves (one block: counting sort by that id, descending).
+void launch_order(const int* pick, const int* pick2, int* order, int nreads, hipStream_t s);
 void launch_verify(ReadState* st, const int* lb, unsigned* nretry, uint8_t* flags, int nreads, hipStream_t s);
 void launch_gather_reads(const uint8_t* reads, const long long* off, const int* idx, const long long* sub_off, uint8_t* out, int n, hipStream_t s);
 void launch_scatter_results(const int* idx, const DevRecord* sub_rec, const uint8_t* sub_ops, DevRecord* rec, uint8_t* ops, long long ops_stride, int n, hipStream_t s);

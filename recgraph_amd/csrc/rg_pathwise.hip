@@ -1322,6 +1322,25 @@ void launch_opt0(const Opt0Args& a, int nreads, int C, hipStream_t s) {
     }
 }
 void launch_pick(const PickArgs& a, int nreads, hipStream_t s) { hipLaunchKernelGGL(k_pick, dim3(nreads), dim3(64), 0, s, a); }
+__global__ __launch_bounds__(1024) void k_order(const int* pick, const int* pick2, int* order, int nreads) {
+    __shared__ unsigned cnt[256], base[256];
+    const int tid = threadIdx.x;
+    if (tid < 256) cnt[tid] = 0;
+    __syncthreads();
+    auto key = [&](int rd) {          // bin 0 = the highest path id
+        int k = pick[rd];
+        if (pick2 && pick2[2 * rd] >= 0) k = max(k, pick2[2 * rd]);
+        return 255 - min(max(k, 0), 255);
+    };
+    for (int rd = tid; rd < nreads; rd += blockDim.x) atomicAdd(&cnt[key(rd)], 1u);
+    __syncthreads();
+    if (tid == 0) { unsigned run = 0; for (int b = 0; b < 256; ++b) { base[b] = run; run += cnt[b]; } }
+    __syncthreads();
+    for (int rd = tid; rd < nreads; rd += blockDim.x) order[atomicAdd(&base[key(rd)], 1u)] = rd;
+}
+void launch_order(const int* pick, const int* pick2, int* order, int nreads, hipStream_t s) {
+    hipLaunchKernelGGL(k_order, dim3(1), dim3(1024), 0, s, pick, pick2, order, nreads);
+}
 void launch_verify(ReadState* st, const int* lb, unsigned* nretry, uint8_t* flags, int nreads, hipStream_t s) {
     hipLaunchKernelGGL(k_verify, dim3((nreads + 255) / 256), dim3(256), 0, s, st, lb, nretry, flags, nreads);
 }

@@ -228,7 +228,7 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
     constexpr bool kTrack = kColmax != 0 || kRec;      // <0, false>: the -m 4 / -m 5 sweep — no best member, no thresholds, no emission
     constexpr bool kRet = kRec && kColmax != 1 && !kWide && C <= 16;   // PATH RETIREMENT (record pipelines of -m 8, P <= 64): see retire_eval
     constexpr int KRUN = C <= 16 ? (kColmax != 0 ? RG_SWEEP16_KRUN : RG_SWEEP16_KRUN_REV) : 0;   // rows kept in registers across the inner rows of a segment
-    const int rd = blockIdx.x;
+    const int rd = a.order ? a.order[blockIdx.x] : blockIdx.x;      // (launch order: see launch_order)
     const int lane = threadIdx.x;
     const PathGraphDev& g = a.g;
     const int P = g.P;

@@ -302,7 +302,7 @@ def test_random_dag_graphs_in_every_switch_family(oracle):
              (240, 5, 303, {"max_jump": 2, "max_seg": 4}))
     switches = (("sweep_i32", 1), ("no_frec", 1), ("three_sweeps", 1), ("no_spec", 1), ("spec_margin", 0), ("spec_margin", -1000000),
                 ("no_gather", 1), ("no_split", 1), ("chunk_reads", 5), ("layer_i32", 1), ("no_retire", 1), ("no_retire", 2), ("no_retire", 3),
-                ("no_pick2", 1))
+                ("no_pick2", 1), ("no_order", 1))
     pairs = ((("three_sweeps", 1), ("sweep_i32", 1)), (("no_split", 1), ("no_gather", 1)), (("spec_margin", -1000000), ("chunk_reads", 4)),
              (("no_frec", 1), ("no_spec", 1)), (("no_retire", 1), ("no_split", 1)), (("no_spec", 1), ("no_gather", 1)),
              (("no_pick2", 1), ("spec_margin", 0)), (("no_retire", 3), ("no_split", 1)))
