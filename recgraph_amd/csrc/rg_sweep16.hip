@@ -1578,6 +1578,9 @@ __global__ __launch_bounds__(64) void k_layer16(LayerArgs a) {
             for (int r = 0; r < H; ++r) if (r == (start_col % C) % H) pv = cur[r];
             if (lane == start_col / C) rs->trace_score = ((start_col % C) >= H ? hi16(pv) : lo16(pv)) + start_col * gcost;
         }
+        // the walkers start at (fen | end row, column) / (rsn, column) and only ever move to earlier rows of the list: the
+        // rows behind the start row are never read (a recombined read uses about half of each path)
+        if (recomb && irow == (rev ? rs->rsn : rs->fen)) break;
     }
 }
 
