@@ -730,6 +730,10 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
     // the bound k_verify checks; the needed paths see exactly the decisions they would see in the full sweep.
     // tests/c/band_experiment.cpp measures why this — not a column band — is the exact way to skip hopeless work here.
     bool row_open = false;               // some group of the current several-group row has put its keys into bkey
+#ifdef RG_SWEEP16_RETSTAT
+    // (statistics build, tools/sweep_variants.sh RETSTAT: the counters carry evaluations | needed paths << 32 and not-hopeless paths)
+    unsigned long long stat_e = 0, stat_n = 0, stat_h = 0;
+#endif
     auto retire_eval = [&](int e) {
         unsigned long long hop = 0, todo = needed;
         // (four rows in flight per wait: one row per wait made the evaluations ~8 % of the sweep)
@@ -758,12 +762,18 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
         }
         const unsigned long long lead_k = lane < P ? (rev ? a.rlead : a.flead)[(long long)e * 64 + lane] : 0ull;
         unsigned long long nd = needed & ~hop;
+#ifdef RG_SWEEP16_RETSTAT
+        const unsigned long long nd_first = nd;
+#endif
         for (;;) {
             const unsigned long long ad = __ballot(((needed >> lane) & 1ull) && !((nd >> lane) & 1ull) && (lead_k & nd) != 0ull);
             if (!ad) break;
             nd |= ad;
         }
         needed = nd;
+#ifdef RG_SWEEP16_RETSTAT
+        stat_e += 1ull; stat_n += (unsigned long long)__popcll(nd); stat_h += (unsigned long long)__popcll(nd_first);
+#endif
     };
     while (t < nsteps) {
         int w0, w1;
@@ -1291,6 +1301,9 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
         // counted: every member row of the table (what the reference updates) — from the table builder when records may have
         // been jumped over; performed: what this wave carried out
         const unsigned long long all = kRet && a.table_members ? a.table_members : cells;
+#ifdef RG_SWEEP16_RETSTAT
+        if (kRet) { atomicAdd(a.cells, stat_e | (stat_n << 32)); atomicAdd(a.cells + 1, stat_h | ((unsigned long long)(rev ? 0 : 1) << 48)); return; }
+#endif
         atomicAdd(a.cells, all * (unsigned long long)(n + 1));
         atomicAdd(a.cells + 1, done * (unsigned long long)(n + 1));
     }
