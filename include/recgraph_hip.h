@@ -168,7 +168,10 @@ int64_t rg_batch_format_all(const rg_batch* b, const char* const* names, int64_t
  * per-kernel device time measured with HIP events on the stream the kernels were launched on. */
 uint64_t rg_batch_cell_updates(const rg_batch* b);
 /* The cell updates the kernels actually performed for that workload: the same number except where k_sweep16 runs a
- * segment's rows as a gather run (per row the alpha and a column map instead of one update per member path). */
+ * segment's rows as a gather run (per row the alpha and a column map instead of one update per member path) and where
+ * its -m 8 sweeps retire paths (a path that provably cannot matter any more, and leads no path that can,
+ * is not updated further; the results are the same bytes).  Updates of a second pass after a failed speculation are in
+ * neither number. */
 uint64_t rg_batch_cell_updates_performed(const rg_batch* b);
 int32_t rg_batch_kernel_count(const rg_batch* b);
 const char* rg_batch_kernel_name(const rg_batch* b, int32_t k);
