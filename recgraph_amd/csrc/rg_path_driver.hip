@@ -522,8 +522,8 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
             if (two_sweep) {
                 Opt0Args oa{gd, sa.sc, d_reads, off, bad, w.fpoff.p, w.fprow.p, w.lb.p, semi ? 1 : 0, nullptr, 0, nwv, nullptr, 0};
                 if (spec) {
-                    // (two-path picks: one-wave reads, global mode)
-                    const bool pick_two = nwv == 1 && !semi && !opt.no_pick2;
+                    // (two-path picks: global mode)
+                    const bool pick_two = !semi && !opt.no_pick2;
                     PickArgs pa{d_reads, off, bad, w.kmer_keys.p, w.kmer_masks.p, w.kmer_mask, P, w.pick.p, w.fpoff.p, w.fprow.p,
                                 pick_two ? w.pick2.p : nullptr};
                     oa.pick2 = pa.pick2;

@@ -619,11 +619,23 @@ __global__ __launch_bounds__(512) void k_opt0_striped(Opt0Args a) {
         row[q] = c < ncols ? c * gcost : NEG;               // the gap-only start row
     }
     const int pk = a.pick ? a.pick[rd] : 0;      // (only path 0's score is a provable bound: see PickArgs)
-    const int beg = a.fpoff[pk], cnt = a.fpoff[pk + 1] - beg;
+    // (two-path pick: p1's rows <= X, then p2's rows > X — every wave of the block takes the same rows)
+    const int pk2 = (a.pick && a.pick2) ? a.pick2[2 * rd] : -1;
+    const int X = pk2 >= 0 ? a.pick2[2 * rd + 1] : INT32_MAX;
+    int beg = a.fpoff[pk], cnt = a.fpoff[pk + 1] - beg;
     int semibest = NEG;
+    bool second = false;
     StripeIO io{NEG, NEG, NEG, NEG};
     for (int t = 0; t < cnt; ++t) {
         const int i = a.fprow[beg + t];
+        if (i > X && !second) {
+            second = true;
+            beg = a.fpoff[pk2]; cnt = a.fpoff[pk2 + 1] - beg;
+            int lo = 0, hi = cnt;
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (a.fprow[beg + mid] <= X) lo = mid + 1; else hi = mid; }
+            t = lo - 1;
+            continue;
+        }
         const int li = g.lnz[i];
         const int g_i = sct[li * 6 + GAP];
 #pragma unroll
@@ -644,7 +656,7 @@ __global__ __launch_bounds__(512) void k_opt0_striped(Opt0Args a) {
     int v = NEG;
 #pragma unroll
     for (int q = 0; q < C; ++q) if (q == n % C) v = row[q];
-    if (lane == n / C) a.lb[rd] = (a.semi ? semibest : v) - (a.pick ? a.margin : 0);
+    if (lane == n / C) a.lb[rd] = (a.semi ? semibest : v) - (a.pick ? a.margin : 0) - (pk2 >= 0 ? a.rec_pen : 0);
 }
 
 // ---------------------------------------------------------------------------------
@@ -1168,6 +1180,9 @@ __global__ __launch_bounds__(kStripes ? 512 : 64) void k_layer(LayerArgs a) {
             for (int q = 0; q < C; ++q) if (q == start_col % C) v = cur[q];
             if (lane == start_col / C) rs->trace_score = v;
         }
+        // the walkers only ever move to earlier rows of the list: nothing behind their start row is read (every wave of a
+        // striped read leaves at the same row, its FIFO traffic for that row done)
+        if (recomb && irow == (rev ? rs->rsn : rs->fen)) break;
     }
 }
 
