@@ -236,7 +236,7 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
                     const long long* d_off, const uint8_t* d_bad, int nreads, int max_n, DevRecord* d_rec, uint8_t* d_ops,
                     long long ops_stride, unsigned long long* d_cells, hipStream_t stream, size_t mem_budget,
                     unsigned long long* cells_out,
-                    std::vector<std::pair<std::string, std::pair<double, long long>>>& stats, bool allow_spec);
+                    std::vector<std::pair<std::string, std::pair<double, long long>>>& stats, int spec_level);
 }
 
 // Text of read i exactly as the reference prints it (warning lines + GAFStruct::to_string), appended to `out`.
@@ -727,7 +727,7 @@ int rg_run_pathwise(rg_batch* b) {
     unsigned long long c[2] = {0, 0};
     b->pw.spin_wait = b->spin_wait;
     int rc = path_driver_run(h, gd, b->p, b->pw, b->in.reads, b->in.off, b->in.bad, (int)b->nreads, b->max_n, b->d_rec.p,
-                             b->d_ops.p, b->ops_stride, b->d_cells.p, b->stream, b->mem_budget, c, st, true);
+                             b->d_ops.p, b->ops_stride, b->d_cells.p, b->stream, b->mem_budget, c, st, 0);
     b->stats.clear();
     for (auto& s : st) b->stats.push_back(KernelStat{s.first, s.second.first, s.second.second});
     if (rc) return rc;

@@ -139,7 +139,7 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
                     const long long* d_off, const uint8_t* d_bad, int nreads, int max_n, DevRecord* d_rec, uint8_t* d_ops,
                     long long ops_stride, unsigned long long* d_cells, hipStream_t stream, size_t mem_budget,
                     unsigned long long* cells_out /* [2]: counted | performed */,
-                    std::vector<std::pair<std::string, std::pair<double, long long>>>& stats, bool allow_spec) {
+                    std::vector<std::pair<std::string, std::pair<double, long long>>>& stats, int spec_level) {
     if (!pw.impl) pw.impl = new PathWorkImpl();
     PathWorkImpl& w = *pw.impl;
     const Options& opt = options();
@@ -434,10 +434,15 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
     // speculative forward bound (PickArgs in rg_path_kernels.hpp): checked by k_verify, failed reads aligned again below
     // (long reads emit Cand entries, not records: without the speculation their forward lists would hold every cell within
     // ~(seed - path-0 score) / 10 columns of a diagonal — millions per read at 5 kbp)
+    // spec_level: 0 = the batch itself; 1 = the reads whose speculation failed, once more with a generous margin (their sweeps
+    // still retire paths and emit few records: a second pass on the provable bound keeps one wave per read busy for two full
+    // sweeps and a search over ~40 000 records); 2 = what fails even that, with the provable bound
+    const bool allow_spec = spec_level < 2;
     const bool spec = (use_rec || (two_sweep && nwv > 1)) && allow_spec && !semi && P <= 64 && !opt.no_spec;
     // (a follower path's sink value lies below its own NW optimum — measured up to 72 at 1 kbp — and the gap grows with the
     // read: long reads scale the margin with their length, or every read would fail the check and run again)
-    const int spec_margin = nwv > 1 ? opt.spec_margin * ((max_n + 999) / 1000) : (int)opt.spec_margin;
+    const int spec_margin = (nwv > 1 ? opt.spec_margin * ((max_n + 999) / 1000) : (int)opt.spec_margin) +
+                            (spec_level == 1 ? 320 * ((max_n + 999) / 1000) : 0);
     const int recw = 4 + C;
     if (w.fcap == 0) { w.fcap = (two_sweep && !use_rec) ? 1u << 20 : 1u << 15; w.rcap = use_rec ? 1u << 16 : 1u << 19; w.frec_cap = 1u << 16; w.rrec_cap = 1u << 15; }   // (reverse records at config 5: mean 2.7 k, largest read of a 4096-read tile 21-25 k)
     stats.clear();
@@ -703,7 +708,7 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
             std::vector<std::pair<std::string, std::pair<double, long long>>> st2;
             unsigned long long c2[2] = {0, 0};
             if ((rc = path_driver_run(h, gd, p, w.retry, w.rt_reads.p, w.rt_off.p, w.rt_bad.p, nr, max_n, w.rt_rec.p, w.rt_ops.p, ops_stride,
-                                      w.rt_cells.p, stream, 0, c2, st2, false)))
+                                      w.rt_cells.p, stream, 0, c2, st2, spec_level + 1)))
                 return rc;
             launch_scatter_results(w.rt_idx.p, w.rt_rec.p, w.rt_ops.p, d_rec + done, d_ops + (long long)done * ops_stride, ops_stride, nr, stream);
             HIPCHK(hipStreamSynchronize(stream));
