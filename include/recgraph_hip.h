@@ -331,7 +331,7 @@ int32_t rg_stream_handles(rg_stream* s);      /* batch handles that aligned at l
  * "sweep_i32" (RG_SWEEP_I32: i32 sweep kernel even when the packed 16-bit one is admissible), "three_sweeps"
  * (RG_THREE_SWEEPS), "no_frec" (RG_NO_FREC: Cand-list forward emission), "no_spec" (RG_NO_SPEC: -m 8 forward sweep
  * pruned with the provable bound instead of the speculative one), "spec_margin" (RG_SPEC_MARGIN, an integer: what the
- * speculative bound subtracts from the picked path's score; default 160), "chunk_reads" (RG_CHUNK_READS, an integer:
+ * speculative bound subtracts from the picked path's score; default 112), "chunk_reads" (RG_CHUNK_READS, an integer:
  * most reads one pathwise kernel launch takes), "no_gather" / "no_split" (RG_NO_GATHER / RG_NO_SPLIT: k_sweep16 without its gather runs / on the
  * plain step tables), "layer_i32" (RG_LAYER_I32: the layer rebuild in its i32 form), "no_retire" (RG_NO_RETIRE: k_sweep16 computes
  * every path to the end; 2 / 3: retirement in the forward / reverse sweep only), "no_pick2" (RG_NO_PICK2: the speculative

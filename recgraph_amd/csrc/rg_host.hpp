@@ -29,7 +29,7 @@ struct Options {
     std::atomic<int> no_gather{0};      // RG_NO_GATHER: k_sweep16 without its gather runs
     std::atomic<int> no_split{0};       // RG_NO_SPLIT: k_sweep16 on the plain step tables (no TAIL records)
     std::atomic<int> no_spec{0};        // RG_NO_SPEC: -m 8 forward sweep with the provable bound (path 0) instead of the speculative one
-    std::atomic<int> spec_margin{160};  // RG_SPEC_MARGIN: what the speculative bound subtracts from the picked path's score
+    std::atomic<int> spec_margin{112};  // RG_SPEC_MARGIN: what the speculative bound subtracts from the picked path's score
     std::atomic<int> lb_bonus{0};       // RG_LB_BONUS (experiments only): added to the forward sweep's lower bound; > 0 may drop candidates
     std::atomic<int> stripe_c{0};       // RG_STRIPE_C: columns per lane of the striped long-read kernels (8, 16, 32; 0: 16 up to 8191 bases, else 32)
     std::atomic<int> no_retire{0};      // RG_NO_RETIRE: k_sweep16 computes every path to the end (no path retirement)

@@ -5,6 +5,8 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
+SPEC_MARGIN_DEFAULT = 112     # rg_host.hpp (what the tests put back after changing it)
+
 def _switch(var, on):
     """The diagnostic switches of the library (rg_set_option; the environment variables of the same names only set the
     defaults when the library is loaded)."""
@@ -186,12 +188,12 @@ def test_speculative_forward_bound(oracle):
             for R, r, B in ((0, 0.1, 0.8), (9, 0.5, 1.0)):
                 exp = _check(oracle, g.gfa(), rd[:20], api.MODE_RECOMBINATION, oracle.M8_ABS, R=R, r=r, B=B)
                 assert exp is not None
-        api.set_option("spec_margin", 160)
+        api.set_option("spec_margin", SPEC_MARGIN_DEFAULT)
         api.set_option("no_spec", 1)
         texts, _ = api.align_batch(gg, rd, names, mode=api.MODE_RECOMBINATION)
         assert texts == base
     finally:
-        api.set_option("spec_margin", 160)
+        api.set_option("spec_margin", SPEC_MARGIN_DEFAULT)
         api.set_option("no_spec", 0)
     # a stream tile with forced failures in two chunks (chunk_reads) keeps the input order
     try:
@@ -200,7 +202,7 @@ def test_speculative_forward_bound(oracle):
         texts, _ = api.align_stream(gg, rd, names, mode=api.MODE_RECOMBINATION, device_ids=[0], handles_per_device=2, tile_reads=40)
         assert texts == base
     finally:
-        api.set_option("spec_margin", 160)
+        api.set_option("spec_margin", SPEC_MARGIN_DEFAULT)
         api.set_option("chunk_reads", 0)
 
 
@@ -306,7 +308,7 @@ def test_random_dag_graphs_in_every_switch_family(oracle):
     pairs = ((("three_sweeps", 1), ("sweep_i32", 1)), (("no_split", 1), ("no_gather", 1)), (("spec_margin", -1000000), ("chunk_reads", 4)),
              (("no_frec", 1), ("no_spec", 1)), (("no_retire", 1), ("no_split", 1)), (("no_spec", 1), ("no_gather", 1)),
              (("no_pick2", 1), ("spec_margin", 0)), (("no_retire", 3), ("no_split", 1)))
-    defaults = {"spec_margin": 160}
+    defaults = {"spec_margin": SPEC_MARGIN_DEFAULT}
     for nseg, P, seed, kw in cases:
         g = synth.random_dag_graph(nseg, P, seed=seed, **kw)
         plen = min(len(g.path_sequence(k)) for k in range(P))
@@ -348,7 +350,7 @@ def test_kilobase_reads_on_nested_bubbles(oracle):
                 api.set_option(name, val)
                 texts, _ = api.align_batch(gg, rd, names, mode=api.MODE_RECOMBINATION)
             finally:
-                api.set_option(name, 160 if name == "spec_margin" else 0)
+                api.set_option(name, SPEC_MARGIN_DEFAULT if name == "spec_margin" else 0)
             assert texts == base, (P, name)
 
 

@@ -12,4 +12,4 @@ for margin in (400, 160, 120, 80, 40, 0, -100):
     b = api.Batch(g, reads, api.make_params(api.MODE_RECOMBINATION))
     b.run(); b.fetch()
     print("margin", margin, "performed / counted %.4f" % (b.cell_updates_performed / b.cell_updates), "counted", b.cell_updates)
-api.set_option("spec_margin", 160)
+api.set_option("spec_margin", 112)
