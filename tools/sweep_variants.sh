@@ -2,6 +2,8 @@
 # Timing-only variants of k_sweep16 ("make the evidence reproducible"): builds one library per
 # -DRG_SWEEP16_* flag into tools/build/ (the results of these builds are garbage: nothing ships or tests them) and times
 # the config-5 sweeps of each with a one-handle stream (kernel durations = HIP events, nothing else on the GPU).
+# Two VALID variants too: RSH<k> (path retirement evaluated every 2^k records instead of 256: RSH4 makes the small graphs of the
+# tests and of tools/fuzz_parity.py retire paths) and RETSTAT (statistics build for tools/probes/retire_stat.py).
 #   HERE (no GPU):   tools/sweep_variants.sh build
 #   on the GPU box:  tools/sweep_variants.sh run > gpurun_out/sweep_variants.txt
 cd "$(dirname "$0")/.." || exit 1
