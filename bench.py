@@ -540,7 +540,8 @@ def main():
         pack = api.Batch.pack_reads          # the C ABI's input form, built once per read set (not part of the hot path)
         slice_set = slice_packed
 
-    strong_tile = args.strong_tile or min(batch, STRONG_TILE.get(args.config, batch))
+    # (never above the stream's tile size: a larger push is cut in two by the engine and the region would time other tiles than it reports)
+    strong_tile = min(batch, args.strong_tile or STRONG_TILE.get(args.config, batch))
 
     def share_tiles(total_batches, lo, hi, ramp=0, max_tile=None):
         """Reads [lo, hi) of the canonical read set of `total_batches` batches, as packed tiles of even size (<= batch):
