@@ -462,6 +462,30 @@ std::string dump_graph(const HostGraph& g, int which) {
                 s += ";";
             }
             break;
+        case 31: case 32: case 33: case 34: {
+            // product only: the step tables of the pathwise sweeps (31 forward plain, 32 forward split, 33 / 34 reverse):
+            // "members=..;points=..;" then one "x:y:z:w" record (hex) per step, ";", then the path-retirement table as
+            // "point:path:mask" entries (non-zero masks only)
+            if (g.P == 0) break;
+            StepTables T;
+            build_step_tables(g, which <= 32, g.P <= 64, T);
+            const bool split = which == 32 || which == 34;
+            const std::vector<StepRec>& recs = split ? T.split : T.plain;
+            const std::vector<unsigned long long>& lead = split ? T.lead_split : T.lead_plain;
+            char tmp[96];
+            snprintf(tmp, sizeof tmp, "members=%llu;points=%zu;", T.members, lead.size() / 64);
+            s = tmp;
+            for (size_t t = 0; t < recs.size(); ++t) {
+                snprintf(tmp, sizeof tmp, "%s%x:%x:%x:%x", t ? "," : "", (unsigned)recs[t].x, (unsigned)recs[t].y, (unsigned)recs[t].z, (unsigned)recs[t].w);
+                s += tmp;
+            }
+            s += ";";
+            bool first = true;
+            for (size_t e = 0; e < lead.size(); ++e)
+                if (lead[e]) { snprintf(tmp, sizeof tmp, "%s%zu:%zu:%llx", first ? "" : ",", e / 64, e % 64, lead[e]); s += tmp; first = false; }
+            s += ";";
+            break;
+        }
         case 12: s = ph(g.eoff, g.epred, g.emask); break;
         case 13: for (int32_t i = 0; i < g.L; ++i) { s += bits(g.row_mask[i]); s += ";"; } break;
         case 14: s = csv(g.alphas); break;

@@ -4,6 +4,8 @@
 // reference's HashMap/BitVec containers (graph.rs:23-27, pathwise_graph.rs:10-18,75-78) have no
 // counterpart here.
 #pragma once
+#include "rg_codes.hpp"
+
 #include <atomic>
 #include <cstdint>
 #include <deque>
@@ -128,6 +130,18 @@ int build_from_lnz(const char* lnz, int64_t L, const int64_t* pred_off, const in
 int build_from_path(const char* lnz, int64_t L, int32_t P, const uint64_t* row_mask, const int64_t* edge_off,
                     const int64_t* edge_pred, const uint64_t* edge_mask, const uint64_t* node_id, HostGraph& g);
 std::string dump_graph(const HostGraph& g, int which);
+
+// Step tables of the pathwise sweeps (rg_steps.cpp; record layout: k_sweep in rg_pathwise.hip).  `split`: the same records
+// with the TAIL groups moved behind their register runs (k_sweep16, P <= 64); `lead_*`: per evaluation point of the path
+// retirement and path, the members of the groups the path leads from there on ([point][64], P <= 64); `members`: the sum
+// of the group sizes = the member-row updates one sweep of the reference performs per column.
+struct StepRec { int32_t x, y, z, w; };
+struct StepTables {
+    std::vector<StepRec> plain, split;
+    std::vector<unsigned long long> lead_plain, lead_split;
+    unsigned long long members = 0;
+};
+void build_step_tables(const HostGraph& h, bool forward, bool want_split, StepTables& out);
 
 // ---- alignment records as they come back from the device ----
 struct ReadRecord {

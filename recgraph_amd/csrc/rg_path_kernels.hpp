@@ -2,9 +2,6 @@
 #pragma once
 #include "rg_path_args.hpp"
 
-#ifndef RG_SWEEP16_RETIRE_SHIFT
-#define RG_SWEEP16_RETIRE_SHIFT 8
-#endif
 namespace rg {
 
 // per-read scalar state carried between the kernels of one batch

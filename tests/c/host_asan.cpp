@@ -31,6 +31,8 @@ static void try_gfa(const std::string& t) {
     if (rc == RG_OK) {
         ++ok_gfa;
         for (int which = 0; which < 8; ++which) (void)dump_graph(g, which);     // walks every flattened array
+        // the step tables of the pathwise sweeps, their split form and the path-retirement tables (rg_steps.cpp)
+        for (int which = 30; which <= 34; ++which) (void)dump_graph(g, which);
     } else {
         ++bad_gfa;
     }

@@ -243,3 +243,112 @@ def test_formatter_path_lists_replace_the_predhash_walk(rg, example_gfa):
         for k, lst in enumerate(d[1:]):
             rows = [int(x) for x in lst.split(",")] if lst else []
             assert rows == [i for i in range(1, len(masks) - 1) if masks[i][k] == "1"]
+
+
+def _parse_steps(text):
+    head, recs, lead, _ = text.split(";", 3)[0], None, None, None
+    parts = text.split(";")
+    members = int(parts[0].split("=")[1])
+    points = int(parts[1].split("=")[1])
+    recs = [tuple(int(v, 16) for v in r.split(":")) for r in parts[2].split(",")] if parts[2] else []
+    lead = {}
+    if parts[3]:
+        for e in parts[3].split(","):
+            pt, k, m = e.split(":")
+            lead[(int(pt), int(k))] = int(m, 16)
+    return members, points, recs, lead
+
+
+def _rec_fields(r):
+    x, y, z, w = r
+    return {"row": x & 0xfffff, "li": (x >> 20) & 7, "flags": (x >> 23) & 7, "field": (x >> 26) & 63, "slot": y & 0xfffff,
+            "page": (y >> 29) & 3, "cont": bool(y >> 31), "mask": z | (w << 32)}
+
+
+def test_step_tables_of_the_pathwise_sweeps():
+    """rg_steps.cpp (host-only): the step tables k_sweep / k_sweep16 walk, their split form (TAIL groups behind their
+    register runs) and the path-retirement tables, through rg_graph_dump 31-34.  Invariants the kernels rely on, on
+    block-built and random-walk graphs with up to 64 paths and one with 70 (continuation entries, no retirement tables):
+    every path of a row in exactly one group of the row; rows in sweep order; run fields; the split table holds the same
+    records; a TAIL directly follows the last record of a run on the same paths; the retirement table equals its
+    definition (the kernel's alpha rule) at every evaluation point and only shrinks."""
+    from recgraph_amd import api, synth
+    graphs = [synth.haplotype_graph(700, 8, path_len=120, seed=11), synth.haplotype_graph(2500, 32, path_len=260, seed=12),
+              synth.random_dag_graph(150, 12, seed=13, max_jump=3, max_seg=8), synth.random_dag_graph(90, 40, seed=14, max_jump=6, max_seg=14),
+              synth.random_dag_graph(60, 64, seed=15, similar=0.8), synth.random_dag_graph(80, 70, seed=16)]
+    for sg in graphs:
+        g = api.Graph.from_gfa_text(sg.gfa())
+        P = g.paths_number
+        row_masks = g.dump(13).strip(";").split(";")
+        L = len(row_masks)
+        paths_of = [sum(1 << k for k in range(P) if row_masks[i][k] == "1") for i in range(L)]
+        total = sum(len(sg.path_sequence(k)) for k in range(P))
+        for fwd, (cp, cs) in ((True, (31, 32)), (False, (33, 34))):
+            members, points, plain, lead = _parse_steps(g.dump(cp))
+            assert members == total == sum(bin(_rec_fields(r)["mask"]).count("1") for r in plain)
+            f = [_rec_fields(r) for r in plain]
+            rows = [r["row"] for r in f]
+            assert rows == sorted(rows, reverse=not fwd) and set(rows) == set(range(1, L - 1))
+            by_row = {}
+            for r in f:
+                by_row.setdefault(r["row"], []).append(r)
+            for i, rs in by_row.items():
+                seen = [0, 0, 0, 0]
+                for r in rs:
+                    assert r["mask"] and not (seen[r["page"]] & r["mask"])
+                    seen[r["page"]] |= r["mask"]
+                assert sum(m << (64 * pg) for pg, m in enumerate(seen)) == paths_of[i]
+                plainflags = [r["flags"] for r in rs]
+                if len(rs) > 1:
+                    assert plainflags[0] & 1 and plainflags[-1] & 2 and all(not (fl & 4) for fl in plainflags)
+                    assert all(not (fl & 1) for fl in plainflags[1:]) and all(not (fl & 2) for fl in plainflags[:-1])
+                elif rs[0]["flags"] & 4:        # HEAD (4) or inner row (7) of a one-group run led by its lowest member
+                    assert rs[0]["flags"] in (4, 7) and rs[0]["field"] >= 1 and not rs[0]["cont"]
+            for t, r in enumerate(f):           # run field: rows left in the run, this one included, capped at 63
+                if r["flags"] & 4:
+                    nxt = f[t + 1] if t + 1 < len(f) else None
+                    cont_run = nxt is not None and nxt["flags"] == 7
+                    assert r["field"] == (min(nxt["field"] + 1, 63) if cont_run else 1), (t, r, nxt)
+            if P > 64:
+                assert points == 0 and any(r["cont"] for r in f)
+                continue
+            # ---- split table ----
+            m2, p2, split, lead2 = _parse_steps(g.dump(cs))
+            fs = [_rec_fields(r) for r in split]
+            assert m2 == members and sorted((r["row"], r["slot"], r["mask"]) for r in fs) == sorted((r["row"], r["slot"], r["mask"]) for r in f)
+            ntails = 0
+            for t, r in enumerate(fs):
+                is_tail = bool(r["flags"] & 4) and r["field"] == 0
+                if is_tail:
+                    ntails += 1
+                    prev = fs[t - 1]
+                    assert prev["flags"] & 4 and prev["field"] == 1 and prev["mask"] == r["mask"] and prev["row"] != r["row"]
+                    assert bin(r["mask"]).count("1") <= 4 and len(by_row[r["row"]]) > 1
+            srows = {}
+            for r in fs:
+                srows.setdefault(r["row"], []).append(r)
+            for i, rs in srows.items():
+                if len(rs) > 1:              # first / last bits in the NEW order, exactly once each
+                    assert sum(1 for r in rs if r["flags"] & 1) == 1 and rs[0]["flags"] & 1
+                    assert sum(1 for r in rs if r["flags"] & 2) == 1 and rs[-1]["flags"] & 2
+            if sg is graphs[1]:
+                assert ntails > 20           # the block-built graphs are what the split tables were made for
+            # ---- retirement tables: the definition, with the kernel's alpha rule ----
+            for recs, table, npts in ((f, lead, points), (fs, lead2, p2)):
+                ev = 256
+                assert npts == len(recs) // ev + 2
+                cur = [0] * 64
+                want = {}
+                for t in range(len(recs) - 1, -1, -1):
+                    r = recs[t]
+                    if not r["cont"] and bin(r["mask"]).count("1") > 1:
+                        alpha = (r["mask"] & -r["mask"]).bit_length() - 1 if r["flags"] & 4 else r["field"]
+                        assert (r["mask"] >> alpha) & 1
+                        cur[alpha] |= r["mask"]
+                    if t % ev == 0:
+                        for k in range(64):
+                            if cur[k]:
+                                want[(t // ev, k)] = cur[k]
+                assert table == want
+                for (pt, k), m in table.items():
+                    assert pt == 0 or (table.get((pt - 1, k), 0) & m) == m
