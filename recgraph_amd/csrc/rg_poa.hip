@@ -19,21 +19,22 @@ namespace rg {
 
 __device__ __forceinline__ int sc_at(const DevScores& sc, int a, int b) { return sc.t[a * 6 + b]; }
 
-// utils.rs:17-98 (simd_version = true), usize arithmetic of a release build
-__device__ void band_simd(int i, unsigned long long ms, unsigned long long me, int r_val, unsigned long long seq_len,
-                          unsigned long long bta, unsigned long long& left, unsigned long long& right) {
+// utils.rs:17-98 (simd_version = true).  The reference computes in usize; every quantity here is below 2^31 (columns of a
+// read of at most 2^20 bases) and the only wrap-arounds are differences taken modulo 8, which 2^32 preserves — so 32-bit
+// unsigned arithmetic gives the same band with half the scalar instructions (the kernel is bound by the scalar unit).
+__device__ void band_simd(int i, unsigned ms, unsigned me, int r_val, unsigned seq_len, unsigned bta, unsigned& left, unsigned& right) {
     (void)i;
     int tmp_bs = min((int)ms, ((int)seq_len - r_val) - (int)bta);
-    unsigned long long band_start = tmp_bs < 0 ? 0ull : (unsigned long long)tmp_bs;
-    unsigned long long r64 = r_val < 0 ? ~0ull : (unsigned long long)r_val;
-    unsigned long long band_end;
-    if (seq_len > r64) {
-        unsigned long long a = me > seq_len - r64 ? me : seq_len - r64;
+    unsigned band_start = tmp_bs < 0 ? 0u : (unsigned)tmp_bs;
+    unsigned r32 = r_val < 0 ? ~0u : (unsigned)r_val;
+    unsigned band_end;
+    if (seq_len > r32) {
+        unsigned a = me > seq_len - r32 ? me : seq_len - r32;
         band_end = min(seq_len, a + bta);
     } else {
         band_end = min(seq_len, me + bta);
     }
-    unsigned long long nr = band_end, nl = band_start;
+    unsigned nr = band_end, nl = band_start;
     while ((nr - nl) % 8 != 0) {
         if ((nr - nl) % 2 == 0 && nr < seq_len) nr += 1;
         else if (nl > 0) nl -= 1;
@@ -98,7 +99,7 @@ __global__ __launch_bounds__(64) void k_m0_simd(PoaArgs a) {
     int* am = a.arena_m + (long long)slot * a.cap_cells;
     uint32_t* apw = a.arena_pw + (long long)slot * a.cap_cells;
     int4* rinfo = a.rinfo + (long long)slot * L;
-    const unsigned long long bta = (unsigned long long)a.bta[rd];
+    const unsigned bta = (unsigned)a.bta[rd];
     const int GAP = 5;
     const int ugap = sct[GAP];            // (kUniGap: the cost of every read base)
     M0Ctx cx{am, rinfo, a.col0, 2 * W * sct[read_at(1) * 6 + GAP]};  // global_abpoa.rs:20
@@ -107,11 +108,14 @@ __global__ __launch_bounds__(64) void k_m0_simd(PoaArgs a) {
     bool overflow = false;
 
     // ---- row 0 (global_abpoa.rs:47-61) ----
-    unsigned long long rinfo_right0 = 0;
-    int row0_val[4] = {};           // m[0][64 k + lane] for the first four chunks of row 0
+    unsigned rinfo_right0 = 0;
+    // m[0][64 k + lane] for the first four chunks of row 0.  (Four named registers, here and for the previous row below: as
+    // `int pv[4]` selected through a loop the compiler kept the array in SCRATCH — 32 bytes per lane, one scratch store per
+    // row and two dependent scratch loads per chunk in the fast path, found in the ISA in round 4.)
+    int row0_v0 = 0, row0_v1 = 0, row0_v2 = 0, row0_v3 = 0;
     {
-        unsigned long long left, right;
-        band_simd(0, 0, 0, g.r_values[0], (unsigned long long)W, bta, left, right);
+        unsigned left, right;
+        band_simd(0, 0, 0, g.r_values[0], (unsigned)W, bta, left, right);
         if ((long long)right > a.cap_cells) overflow = true;
         if (!overflow) {
             int carry = 0;
@@ -120,8 +124,14 @@ __global__ __launch_bounds__(64) void k_m0_simd(PoaArgs a) {
                 int gc = (c >= 1 && c < (int)right) ? sct[read_at(c) * 6 + GAP] : 0;
                 int s = wave_incl_sum(gc, lane) + carry;
                 if (c < (int)right) { am[c] = s; apw[c] = (c == 0) ? 0u : 3u; }  // path 0.3 -> (pred 0, L)
-#pragma unroll
-                for (int k = 0; k < 4; ++k) if (cb == k * WAVE) row0_val[k] = s;
+                row0_v0 = cb == 0 ? s : row0_v0;
+                asm volatile("" : "+v"(row0_v0));
+                row0_v1 = cb == WAVE ? s : row0_v1;
+                asm volatile("" : "+v"(row0_v1));
+                row0_v2 = cb == 2 * WAVE ? s : row0_v2;
+                asm volatile("" : "+v"(row0_v2));
+                row0_v3 = cb == 3 * WAVE ? s : row0_v3;
+                asm volatile("" : "+v"(row0_v3));
                 carry = __shfl(s, WAVE - 1, WAVE);
             }
         }
@@ -134,16 +144,22 @@ __global__ __launch_bounds__(64) void k_m0_simd(PoaArgs a) {
     // forget, and the per-row metadata is fetched one row ahead.  Rows with listed predecessors (segment starts) and bands
     // wider than 64 columns take the memory path below; a barrier orders this wave's earlier stores before those loads.
     constexpr int KC = 4;           // up to 256 band columns per row
-    int pv[KC] = {};                // values of the previous row
+    static_assert(KC == 4, "four named registers per row below");
+    int pv0 = row0_v0, pv1 = row0_v1, pv2 = row0_v2, pv3 = row0_v3;   // values of the previous row
     int p_start = 0, p_right = (int)rinfo_right0, p_best = 0;
     bool p_valid = (int)rinfo_right0 <= KC * WAVE;
-#pragma unroll
-    for (int k = 0; k < KC; ++k) pv[k] = row0_val[k];
     // chunk k of the previous row (k is wave-uniform; a select chain instead of a dynamically indexed register array)
+    // (the empty asm statements keep the selects apart: left alone the compiler fuses them into a dynamically indexed
+    // 4-vector, which it keeps in scratch)
     auto pv_chunk = [&](int k) -> int {
-        int r = pv[0];
-#pragma unroll
-        for (int kk = 1; kk < KC; ++kk) r = k == kk ? pv[kk] : r;
+        int r = pv0;
+        asm volatile("" : "+v"(r));
+        r = k == 1 ? pv1 : r;
+        asm volatile("" : "+v"(r));
+        r = k == 2 ? pv2 : r;
+        asm volatile("" : "+v"(r));
+        r = k == 3 ? pv3 : r;
+        asm volatile("" : "+v"(r));
         return r;
     };
     // m[i-1][col] of the reference's full-width matrix for this lane's column `col` (chunk base k0 is wave-uniform)
@@ -171,23 +187,23 @@ __global__ __launch_bounds__(64) void k_m0_simd(PoaArgs a) {
         const bool nwp = pe > pb;
         // a listed predecessor list that is just {i - 1} (chains of single-base segments) behaves like an inner row
         const bool only_prev = !nwp || (pe - pb == 1 && p0_cur == i - 1);
-        unsigned long long ms, me;
+        unsigned ms, me;
         if (only_prev) {
-            const unsigned long long pl = (unsigned long long)p_best;   // best_scoring_pos of row i - 1
+            const unsigned pl = (unsigned)p_best;   // best_scoring_pos of row i - 1
             ms = pl + 1; me = pl + 1;
         } else {
             if (dirty) { __syncthreads(); dirty = false; }
-            unsigned long long pl = 0, pr = 0;
+            unsigned pl = 0, pr = 0;
             for (int e = pb; e < pe; ++e) {
-                unsigned long long cb = (unsigned long long)rinfo[g.pred_rows[e]].w;
+                unsigned cb = (unsigned)rinfo[g.pred_rows[e]].w;
                 if (e == pb) { pl = cb; pr = cb; }
                 if (cb < pl) pl = cb;
                 if (cb > pr) pr = cb;
             }
             ms = pl + 1; me = pr + 1;
         }
-        unsigned long long left64, right64;
-        band_simd(i, ms, me, rv, (unsigned long long)W, bta, left64, right64);
+        unsigned left64, right64;
+        band_simd(i, ms, me, rv, (unsigned)W, bta, left64, right64);
         const int left = (int)left64, right = (int)right64;
         const int start = left == 0 ? 1 : left;
         const int end = right == W ? ((right - start) / 8) * 8 + start : right;
@@ -200,7 +216,7 @@ __global__ __launch_bounds__(64) void k_m0_simd(PoaArgs a) {
         int carry_z = (start - 1 == 0) ? c0_cur : cx.min_score;
         int carry_G = 0;
         int best_v = left == 0 ? c0_cur : INT32_MIN, best_c = left == 0 ? 0 : left;
-        int v_keep[KC] = {};
+        int vk0 = 0, vk1 = 0, vk2 = 0, vk3 = 0;
         int ci = 0;
         for (int cb = start; cb < right; cb += WAVE, ++ci) {
             const int c = cb + lane;
@@ -227,38 +243,39 @@ __global__ __launch_bounds__(64) void k_m0_simd(PoaArgs a) {
                 const int dprev = lane == 0 ? e0 : left_bu;
                 bd = (c - 1 == 0 && i - 1 > 0) ? c0_prev : dprev;
             }
-            if (act) {
-                const int rc = read_at(c);
-                if (!fast) {
-                    if (!nwp) {
-                        bu = m_at(cx, i - 1, c); bd = m_at(cx, i - 1, c - 1);
-                    } else {
-                        int p0 = g.pred_rows[pb];
-                        bu = m_at(cx, p0, c); bd = m_at(cx, p0, c - 1); pu = pd = p0;
-                        for (int e = pb + 1; e < pe; ++e) {  // strict '>' : first predecessor wins ties (:127-139)
-                            int p = g.pred_rows[e];
-                            int u = m_at(cx, p, c), d = m_at(cx, p, c - 1);
-                            if (u > bu) { bu = u; pu = p; }
-                            if (d > bd) { bd = d; pd = p; }
-                        }
+            // predecessor values of the rows that take the memory path (listed predecessors / wide bands)
+            if (!fast && act) {
+                if (!nwp) {
+                    bu = m_at(cx, i - 1, c); bd = m_at(cx, i - 1, c - 1);
+                } else {
+                    int p0 = g.pred_rows[pb];
+                    bu = m_at(cx, p0, c); bd = m_at(cx, p0, c - 1); pu = pd = p0;
+                    for (int e = pb + 1; e < pe; ++e) {  // strict '>' : first predecessor wins ties (:127-139)
+                        int p = g.pred_rows[e];
+                        int u = m_at(cx, p, c), d = m_at(cx, p, c - 1);
+                        if (u > bu) { bu = u; pu = p; }
+                        if (d > bd) { bd = d; pd = p; }
                     }
                 }
+            }
+            {
+                // The cell itself, WITHOUT divergent control flow: every lane computes, idle lanes (c >= right) read the
+                // last read base and are masked by selects.  The kernel is bound by the scalar unit (counters_C2.json: 6 waves
+                // per SIMD issue SALU 96 % of the time) and every divergent `if` costs it three instructions (save exec,
+                // branch, restore): the nest this replaces — active / SIMD part or tail / strict or weak compare — was a
+                // third of the row's scalar instructions.
+                const int rc = read_at(min(c, W - 1));
                 const int us = bu + g_row;
-                if (simd) {
-                    const int ds = bd + sct[li * 6 + rc];
-                    const bool isd = ds > us;                      // ties -> up (:144)
-                    b = isd ? ds : us;
-                    pw = isd ? ((uint32_t)pd << 2 | 1u) : ((uint32_t)pu << 2 | 2u);
-                    if (!kUniGap) {
-                        const int head = start + ((c - start) / 8) * 8;
-                        gc = sct[read_at(head) * 6 + GAP];       // gap key of the chunk head (:157)
-                    }
-                } else {
-                    const int ds = bd + (nwp ? sct[rc * 6 + li] : sct[li * 6 + rc]);  // swapped key (:206)
-                    const bool isd = ds >= us;                     // tail: D > U > L (:175-181)
-                    b = isd ? ds : us;
-                    pw = isd ? ((uint32_t)pd << 2 | 1u) : ((uint32_t)pu << 2 | 2u);
-                    if (!kUniGap) gc = sct[rc * 6 + GAP];
+                // SIMD part (:144): key (row base, read base), ties -> up; tail (:175-181, :206): D > U > L and, behind a row
+                // with listed predecessors, the swapped key
+                const int ds = bd + sct[(simd || !nwp) ? li * 6 + rc : rc * 6 + li];
+                const bool isd = simd ? ds > us : ds >= us;
+                b = act ? (isd ? ds : us) : INT32_MIN / 2;
+                pw = isd ? ((uint32_t)pd << 2 | 1u) : ((uint32_t)pu << 2 | 2u);
+                if (!kUniGap) {
+                    const int head = start + ((c - start) / 8) * 8;
+                    const int gk = simd ? read_at(min(head, W - 1)) : rc;  // gap key: the chunk head's base (:157) / the cell's own
+                    gc = act ? sct[gk * 6 + GAP] : 0;
                 }
             }
             // active lanes are a prefix of the wave: with one gap cost for every base the inclusive sum is (lane + 1) * g
@@ -267,14 +284,21 @@ __global__ __launch_bounds__(64) void k_m0_simd(PoaArgs a) {
             const int zi = dpp_incl_max(y, INT32_MIN / 2);
             int zprev = dpp_shr1(zi, INT32_MIN / 2);
             zprev = lane == 0 ? carry_z : max(zprev, carry_z);
-            int v = b;
+            const bool tl = act && zprev > y;                                 // strict '>' (:158)
+            const int v = tl ? zprev + G : b;
+            pw = tl ? (((uint32_t)i << 2) | 3u) : pw;
             if (act) {
-                if (zprev > y) { v = zprev + G; pw = ((uint32_t)i << 2) | 3u; }  // strict '>' (:158)
                 am[off + (c - start)] = v;
                 apw[off + (c - start)] = pw;
             }
-#pragma unroll
-            for (int k = 0; k < KC; ++k) v_keep[k] = ci == k ? v : v_keep[k];
+            vk0 = ci == 0 ? v : vk0;
+            asm volatile("" : "+v"(vk0));
+            vk1 = ci == 1 ? v : vk1;
+            asm volatile("" : "+v"(vk1));
+            vk2 = ci == 2 ? v : vk2;
+            asm volatile("" : "+v"(vk2));
+            vk3 = ci == 3 ? v : vk3;
+            asm volatile("" : "+v"(vk3));
             // best_col: last column attaining the row maximum (:162-164, :220-222)
             const int vm = act ? v : INT32_MIN;
             const int cmx = __builtin_amdgcn_readlane(dpp_incl_max(vm, INT32_MIN), WAVE - 1);
@@ -290,8 +314,7 @@ __global__ __launch_bounds__(64) void k_m0_simd(PoaArgs a) {
         ncells += (unsigned long long)width;
         dirty = true;
         p_best = best_c; p_start = start; p_right = right; p_valid = width <= KC * WAVE;
-#pragma unroll
-        for (int k = 0; k < KC; ++k) pv[k] = v_keep[k];
+        pv0 = vk0; pv1 = vk1; pv2 = vk2; pv3 = vk3;
         c0_prev = c0_cur;
     }
     __syncthreads();

@@ -95,10 +95,13 @@ __global__ __launch_bounds__(64) void k_poa_banded(PoaArgs a) {
     int pvm[KC] = {}, pvy[kGap ? KC : 1] = {};
     int p_left = 0, p_right = 0, p_best = 0, p_off = 0;
     bool p_valid = false, dirty = false;
+    // (the empty asm statements keep the selects apart: left alone the compiler fuses a chain of them into a dynamically
+    // indexed vector which it keeps in SCRATCH — 48 bytes per lane, stores every row and dependent loads every chunk of the
+    // fast path; found in the ISA in round 4, see rg_poa.hip)
     auto chunk_of = [&](const int (&arr)[KC], int k) -> int {
         int r = arr[0];
 #pragma unroll
-        for (int kk = 1; kk < KC; ++kk) r = k == kk ? arr[kk] : r;
+        for (int kk = 1; kk < KC; ++kk) { r = k == kk ? arr[kk] : r; asm volatile("" : "+v"(r)); }
         return r;
     };
     // stored cell of the row above at absolute column `col` (band-relative index col - p_left; chunk base k0 uniform)
@@ -160,7 +163,10 @@ __global__ __launch_bounds__(64) void k_poa_banded(PoaArgs a) {
                 if (kGap) {
                     int ylo = pvy[0], yhi = pvy[0];
 #pragma unroll
-                    for (int kk = 1; kk < (kGap ? KC : 1); ++kk) { ylo = ka == kk ? pvy[kGap ? kk : 0] : ylo; yhi = kb == kk ? pvy[kGap ? kk : 0] : yhi; }
+                    for (int kk = 1; kk < (kGap ? KC : 1); ++kk) {
+                        ylo = ka == kk ? pvy[kGap ? kk : 0] : ylo; yhi = kb == kk ? pvy[kGap ? kk : 0] : yhi;
+                        asm volatile("" : "+v"(ylo), "+v"(yhi));
+                    }
                     f_yu = prev_at(c, k0, ylo, yhi);
                 }
             }
@@ -264,7 +270,7 @@ __global__ __launch_bounds__(64) void k_poa_banded(PoaArgs a) {
                 carry_z = max(carry_z, __builtin_amdgcn_readlane(zi, WAVE - 1));
                 carry_G = __builtin_amdgcn_readlane(G, WAVE - 1);
 #pragma unroll
-                for (int k = 0; k < KC; ++k) keep_m[k] = ci == k ? mval : keep_m[k];
+                for (int k = 0; k < KC; ++k) { keep_m[k] = ci == k ? mval : keep_m[k]; asm volatile("" : "+v"(keep_m[k])); }
             } else {
                 // ---------------- m2 (gap_global_abpoa.rs:67-196) ----------------
                 const bool fixed0 = act && i > 0 && j == 0 && left == 0;   // first column (:78-92)
@@ -328,7 +334,8 @@ __global__ __launch_bounds__(64) void k_poa_banded(PoaArgs a) {
 #pragma unroll
                 for (int k = 0; k < KC; ++k) {
                     keep_m[k] = ci == k ? mval : keep_m[k];
-                    if (kGap) keep_y[kGap ? k : 0] = ci == k ? yval : keep_y[kGap ? k : 0];
+                    asm volatile("" : "+v"(keep_m[k]));
+                    if (kGap) { keep_y[kGap ? k : 0] = ci == k ? yval : keep_y[kGap ? k : 0]; asm volatile("" : "+v"(keep_y[kGap ? k : 0])); }
                 }
             }
             // best_scoring_pos: last column attaining the row maximum
