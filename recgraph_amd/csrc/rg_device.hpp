@@ -97,6 +97,11 @@ __device__ __forceinline__ int dpp_incl_sum(int v) {
 __device__ __forceinline__ int uload(const int* p) {
     return *reinterpret_cast<const __attribute__((address_space(4))) int*>(reinterpret_cast<uintptr_t>(p));
 }
+__device__ __forceinline__ int4 uload4(const int4* p) {      // (one s_load_dwordx4; p 16-byte aligned)
+    typedef int v4i __attribute__((ext_vector_type(4)));
+    const v4i v = *reinterpret_cast<const __attribute__((address_space(4))) v4i*>(reinterpret_cast<uintptr_t>(p));
+    return make_int4(v.x, v.y, v.z, v.w);
+}
 __device__ __forceinline__ int uload_u8(const uint8_t* base, int i) {
     const uintptr_t a = reinterpret_cast<uintptr_t>(base) + (uintptr_t)i;
     const int w = *reinterpret_cast<const __attribute__((address_space(4))) int*>(a & ~(uintptr_t)3);

@@ -172,18 +172,15 @@ __global__ __launch_bounds__(64) void k_m0_simd(PoaArgs a) {
     bool dirty = true;              // stores issued since the last barrier
     int c0_prev = 0;                // col0[i - 1]
     // metadata of the next row, loaded one iteration ahead
-    int n_pb = uload(g.pred_off + 1), n_pe = L > 2 ? uload(g.pred_off + 2) : n_pb;
-    int n_li = L > 2 ? uload_u8(g.lnz, 1) : 4, n_rv = L > 2 ? uload(g.r_values + 1) : 0, n_c0 = L > 2 ? uload(a.col0 + 1) : 0;
-    int n_p0 = n_pe > n_pb ? uload(g.pred_rows + n_pb) : -1;   // first listed predecessor of the next row
+    // (PoaArgs::rowmeta: one 16-byte scalar load per row; as five loads — two of them dependent on the others — the row loop
+    // waited for the scalar cache twice per row)
+    int n_pb = uload(g.pred_off + 1);
+    int4 n_meta = L > 2 ? uload4(a.rowmeta + 1) : make_int4(n_pb, 0, 0, 4 << 24);
 
     // ---- rows 1..L-2 (global_abpoa.rs:63-226) ----
     for (int i = 1; i + 1 < L && !overflow; ++i) {
-        const int pb = n_pb, pe = n_pe, li = n_li, rv = n_rv, c0_cur = n_c0, p0_cur = n_p0;
-        if (i + 2 < L) {
-            n_pb = pe; n_pe = uload(g.pred_off + i + 2); n_li = uload_u8(g.lnz, i + 1); n_rv = uload(g.r_values + i + 1);
-            n_c0 = uload(a.col0 + i + 1);
-            n_p0 = n_pe > n_pb ? uload(g.pred_rows + n_pb) : -1;
-        }
+        const int pb = n_pb, pe = n_meta.x, rv = n_meta.y, c0_cur = n_meta.z, p0_cur = (n_meta.w & 0xffffff) - 1, li = n_meta.w >> 24;
+        if (i + 2 < L) { n_pb = pe; n_meta = uload4(a.rowmeta + i + 1); }
         const bool nwp = pe > pb;
         // a listed predecessor list that is just {i - 1} (chains of single-base segments) behaves like an inner row
         const bool only_prev = !nwp || (pe - pb == 1 && p0_cur == i - 1);

@@ -12,6 +12,10 @@ struct PoaArgs {
     const uint8_t* bad;        // per read: 1 = contains a base outside ACGTN
     const int* bta;            // per read bases_to_add (main.rs:57)
     const int* col0;           // m0: m[i][0] per row (global_abpoa.rs:36-46), depends on scores only
+    // m0 (k_m0_simd): what a row needs besides its predecessor list, in ONE 16-byte record per row — {end of the row's
+    // predecessor list (pred_off[i + 1]), r_values[i], col0[i], (first listed predecessor + 1) | base code << 24} — so that
+    // the row loop issues one scalar load a row ahead instead of five dependent ones (the kernel is bound by its scalar unit)
+    const int4* rowmeta;
     int nreads;
     int max_n;                 // longest read of the batch
     int lds_read;              // m0: the read's base codes are staged in LDS (max_n + 2 bytes per wave)
