@@ -141,7 +141,7 @@ int run_local(rg_batch* b) {
     PoaArgs a;
     a.g = DevLnz{h.L, g->d_lnz.p, g->d_pred_off.p, g->d_pred_rows.p, g->d_r_values.p, g->d_min_pred.p};
     for (int i = 0; i < 36; ++i) a.sc.t[i] = b->p.scores[i];
-    a.reads = b->in.reads; a.read_off = b->in.off; a.bad = b->in.bad; a.bta = b->in.bta; a.col0 = b->d_col0.p; a.rowmeta = b->d_rowmeta.p;
+    a.reads = b->in.reads; a.read_off = b->in.off; a.bad = b->in.bad; a.bta = b->in.bta; a.col0 = b->d_col0.p; a.rowmeta = b->d_rowmeta.p; a.rowmeta_b = b->d_rowmeta_b.p;
     a.gap_open = b->p.gap_open; a.gap_ext = b->p.gap_ext; a.max_n = b->max_n; a.lds_read = b->max_n <= 16000 ? 1 : 0;
     a.cap_cells = b->cap_cells; a.arena_m = b->d_arena_m.p; a.arena_pw = b->d_arena_pw.p; a.rinfo = b->d_rinfo.p;
     a.rec = b->d_rec.p; a.ops = b->d_ops.p; a.oprows = b->d_oprows.p; a.ops_stride = b->ops_stride;
@@ -194,7 +194,7 @@ int run_poa(rg_batch* b) {
         PoaArgs a;
         a.g = DevLnz{h.L, g->d_lnz.p, g->d_pred_off.p, g->d_pred_rows.p, g->d_r_values.p, g->d_min_pred.p};
         for (int i = 0; i < 36; ++i) a.sc.t[i] = b->p.scores[i];
-        a.reads = b->in.reads; a.read_off = b->in.off; a.bad = b->in.bad; a.bta = b->in.bta; a.col0 = b->d_col0.p; a.rowmeta = b->d_rowmeta.p;
+        a.reads = b->in.reads; a.read_off = b->in.off; a.bad = b->in.bad; a.bta = b->in.bta; a.col0 = b->d_col0.p; a.rowmeta = b->d_rowmeta.p; a.rowmeta_b = b->d_rowmeta_b.p;
         a.max_n = b->max_n; a.lds_read = b->max_n <= 16000 ? 1 : 0; a.gap_open = b->p.gap_open; a.gap_ext = b->p.gap_ext;
         a.cap_cells = b->cap_cells; a.arena_m = b->d_arena_m.p; a.arena_pw = b->d_arena_pw.p; a.rinfo = b->d_rinfo.p;
         a.rec = b->d_rec.p; a.ops = b->d_ops.p; a.oprows = b->d_oprows.p; a.ops_stride = b->ops_stride;
@@ -585,6 +585,16 @@ int32_t rg_batch_create(const rg_graph* gc, const rg_params* p, const char* read
                 rm[i] = make_int4(pend, (int)h.r_values[i], col0[i], (p0 + 1) | ((c < 0 ? 4 : c) << 24));
             }
             if ((rc = b->d_rowmeta.upload(rm))) return rc;
+        }
+        if (mode == RG_MODE_GLOBAL_POA_SCALAR || mode == RG_MODE_GAP_POA) {
+            std::vector<int4> rm(h.L, make_int4(0, 0, 0, 0));
+            for (int i = 0; i < h.L; ++i) {
+                const int pbeg = (int)h.pred_off[i], pend = (int)h.pred_off[i + 1];
+                const int p0 = pend > pbeg ? (int)h.pred_rows[pbeg] : -1;
+                const int c = (i >= 1 && i + 1 < h.L) ? base_code(h.lnz[i]) : 4;
+                rm[i] = make_int4(pend, (int)h.r_values[i], i > 0 ? (int)h.min_pred[i] : 0, (p0 + 1) | ((c < 0 ? 4 : c) << 24));
+            }
+            if ((rc = b->d_rowmeta_b.upload(rm))) return rc;
         }
     }
     if ((rc = load_reads(b.get(), reads, read_off, nreads))) return rc;

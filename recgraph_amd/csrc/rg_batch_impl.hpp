@@ -199,7 +199,7 @@ struct rg_batch {
     PinBuf<uint8_t> stage;
     struct InView { const uint8_t* reads; const long long* off; const uint8_t* bad; const int* bta; } in{};
     DevBuf<int> d_col0;
-    DevBuf<int4> d_rowmeta;   // PoaArgs::rowmeta
+    DevBuf<int4> d_rowmeta, d_rowmeta_b;   // PoaArgs::rowmeta, rowmeta_b
     // work + outputs
     DevBuf<int> d_arena_m;
     DevBuf<uint32_t> d_arena_pw;

@@ -16,6 +16,9 @@ struct PoaArgs {
     // predecessor list (pred_off[i + 1]), r_values[i], col0[i], (first listed predecessor + 1) | base code << 24} — so that
     // the row loop issues one scalar load a row ahead instead of five dependent ones (the kernel is bound by its scalar unit)
     const int4* rowmeta;
+    // the same for k_poa_banded (-m 2, scalar -m 0): {pred_off[i + 1], r_values[i], min_pred[i] (0 for row 0), (first listed
+    // predecessor + 1) | base code << 24}
+    const int4* rowmeta_b;
     int nreads;
     int max_n;                 // longest read of the batch
     int lds_read;              // m0: the read's base codes are staged in LDS (max_n + 2 bytes per wave)

@@ -111,10 +111,16 @@ __global__ __launch_bounds__(64) void k_poa_banded(PoaArgs a) {
         return (idx >> 6) == k0 ? sh_lo : sh_hi;
     };
 
+    // per-row metadata: one 16-byte scalar load, a row ahead (PoaArgs::rowmeta_b; as six loads at the top of the row — one of
+    // them dependent — every row waited for the scalar cache several times)
+    int n_pb = 0;
+    int4 n_meta = uload4(a.rowmeta_b);
     for (int i = 0; i + 1 < L; ++i) {
-        const int pb = uload(g.pred_off + i), pe = uload(g.pred_off + i + 1);
+        const int pb = n_pb, pe = n_meta.x, m_rv = n_meta.y, m_minp = n_meta.z, m_p0 = (n_meta.w & 0xffffff) - 1, m_li = n_meta.w >> 24;
+        n_pb = pe;
+        if (i + 2 < L) n_meta = uload4(a.rowmeta_b + i + 1);
         const bool nwp = pe > pb;
-        const bool only_prev = i > 0 && (!nwp || (pe - pb == 1 && uload(g.pred_rows + pb) == i - 1));
+        const bool only_prev = i > 0 && (!nwp || (pe - pb == 1 && m_p0 == i - 1));
         unsigned long long ms = 0, me = 0;
         if (i > 0) {
             if (only_prev) { unsigned long long pl = (unsigned long long)p_best; ms = pl + 1; me = pl + 1; }
@@ -131,12 +137,12 @@ __global__ __launch_bounds__(64) void k_poa_banded(PoaArgs a) {
             }
         }
         int left, right;
-        band_plain(ms, me, uload(g.r_values + i), (unsigned long long)W, bta, left, right);
+        band_plain(ms, me, m_rv, (unsigned long long)W, bta, left, right);
         if (right <= left) { status |= ST_WOULD_PANIC; break; }   // empty row: m[i][best_val_pos] out of range
         const int width = right - left;
         if (off + width > a.cap_cells) { overflow = true; break; }
-        const int li = i > 0 ? uload_u8(g.lnz, i) : 4;
-        const int minp = i > 0 ? uload(g.min_pred + i) : 0;
+        const int li = m_li;
+        const int minp = m_minp;
         const bool fast = only_prev && p_valid && width <= KC * WAVE;
         if (i > 0 && !fast && dirty) { __syncthreads(); dirty = false; }
         int keep_m[KC] = {}, keep_y[kGap ? KC : 1] = {};
