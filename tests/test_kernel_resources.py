@@ -22,3 +22,18 @@ def test_headline_sweep_variants_use_no_scratch():
         for v in ("2, true, false", "0, true, false", "0, false, false"):
             k = ks["rg::k_sweep16<%d, %s>" % (c, v)]
             assert k["ScratchSize [bytes/lane]"] == 0, (c, v, k)
+
+
+def test_poa_kernels_use_no_scratch():
+    """`k_m0_simd` and `k_poa_banded` keep the previous row's chunks in registers — the compiler once fused the select chains
+    that pick a chunk into a dynamically indexed vector it kept in scratch (32 / 48 bytes per lane, dependent scratch loads in
+    the fast path of every row; profiles/r04_notes.md).  No variant of either may allocate scratch."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import kernel_resources
+    seen = 0
+    for src, prefix in (("rg_poa.hip", "rg::k_m0_simd<"), ("rg_poa_banded.hip", "rg::k_poa_banded<")):
+        for k in kernel_resources.report(src):
+            if k["name"].startswith(prefix):
+                seen += 1
+                assert k["ScratchSize [bytes/lane]"] == 0 and k["VGPRs Spill"] == 0, k
+    assert seen == 8
