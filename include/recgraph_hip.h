@@ -310,6 +310,11 @@ int64_t rg_stream_pending(rg_stream* s);
 /* keep_records: gives a tile's record handle back before rg_stream_destroy (the handle is freed). */
 void rg_stream_release(rg_stream* s, rg_batch* records);
 int32_t rg_stream_finish(rg_stream* s);
+/* Error exit of a bounded stream (the caller's counterpart of a panic inside the reference's read loop, main.rs:56-105):
+ * tiles still queued are dropped, every thread blocked in rg_stream_push / rg_stream_feed_fasta (waiting for room) or in
+ * rg_stream_next returns RG_ERR_ARG ("stream aborted"), later calls fail the same way; the tiles on a device finish and
+ * are discarded by rg_stream_destroy, which also waits for threads still inside a push / feed call.  Any thread. */
+int32_t rg_stream_abort(rg_stream* s);
 /* RG_OK: *out describes the next tile (pointers valid until the next rg_stream_next / rg_stream_destroy on this stream);
  * RG_STREAM_END: finished and everything delivered; negative: that tile failed. */
 int32_t rg_stream_next(rg_stream* s, rg_stream_result* out);

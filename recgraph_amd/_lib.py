@@ -64,7 +64,7 @@ SYMBOLS = ["rg_params_default", "rg_scores_match_mis", "rg_graph_from_gfa", "rg_
            "rg_device_count", "rg_set_device",
            "rg_reads_from_fasta", "rg_reads_count", "rg_reads_bases", "rg_reads_offsets", "rg_reads_names", "rg_reads_destroy", "rg_fasta_check",
            "rg_stream_opts_default", "rg_stream_create", "rg_stream_push", "rg_stream_push_fasta", "rg_stream_feed_fasta", "rg_stream_pending",
-           "rg_stream_release", "rg_stream_finish", "rg_stream_next",
+           "rg_stream_release", "rg_stream_finish", "rg_stream_abort", "rg_stream_next",
            "rg_stream_destroy", "rg_stream_kernel_count", "rg_stream_kernel_name", "rg_stream_kernel_ms",
            "rg_stream_kernel_launches", "rg_stream_tiles_done", "rg_stream_handles", "rg_set_option", "rg_get_option"]
 
@@ -154,6 +154,7 @@ def load():
     l.rg_stream_release.argtypes = [vp, vp]
     l.rg_stream_release.restype = None
     l.rg_stream_finish.argtypes = [vp]
+    l.rg_stream_abort.argtypes = [vp]
     l.rg_stream_next.argtypes = [vp, P(StreamResult)]
     l.rg_stream_destroy.argtypes = [vp]
     l.rg_stream_kernel_count.argtypes = [vp]

@@ -557,6 +557,12 @@ class Stream:
     def finish(self):
         check(_lib.load().rg_stream_finish(self._h))
 
+    def abort(self):
+        """rg_stream_abort: the error exit — queued tiles are dropped and every thread blocked in ``push`` / ``feed_fasta`` /
+        ``next`` returns with an error, so that a feeder thread can be joined before the stream is closed."""
+        if self._h:
+            check(_lib.load().rg_stream_abort(self._h))
+
     def next(self, copy_text=True):
         """The next tile in input order (blocks), or None after ``finish`` when everything was delivered."""
         lib = _lib.load()

@@ -148,22 +148,33 @@ def main(argv=None):
             scan["err"] = ex
     sc = threading.Thread(target=scanner, daemon=True)
     sc.start()
-    for t in st:
-        if "first_tile" not in phases:
-            mark("first_tile", tp)
-            sc.join()
-            if "err" in scan:
-                ex = scan["err"]
-                raise SystemExit(str(ex).split(": ", 1)[-1] if isinstance(ex, api._lib.RecGraphError) else str(ex))
-        bad = (t.status & (api.READ_WOULD_PANIC | api.READ_BAD_BASE)).nonzero()[0]
-        n_ok = int(bad[0]) if len(bad) else t.n
-        if n_ok == t.n and not to_file:
-            sys.stdout.buffer.write(t.text)
-        else:
-            emit(t.first, [t.text_of(i).decode() for i in range(n_ok)])
-        if len(bad):
-            sys.stdout.flush()
-            raise SystemExit("read %d: the reference panics on this input" % (t.first + n_ok))
+    def bail(msg):
+        # every early exit stops the stream FIRST: the feeder may be blocked in a bounded push and must be out of the library
+        # before the stream is freed at interpreter teardown
+        sys.stdout.flush()
+        st.abort()
+        th.join()
+        st.close()
+        raise SystemExit(msg)
+
+    try:
+        for t in st:
+            if "first_tile" not in phases:
+                mark("first_tile", tp)
+                sc.join()
+                if "err" in scan:
+                    ex = scan["err"]
+                    bail(str(ex).split(": ", 1)[-1] if isinstance(ex, api._lib.RecGraphError) else str(ex))
+            bad = (t.status & (api.READ_WOULD_PANIC | api.READ_BAD_BASE)).nonzero()[0]
+            n_ok = int(bad[0]) if len(bad) else t.n
+            if n_ok == t.n and not to_file:
+                sys.stdout.buffer.write(t.text)
+            else:
+                emit(t.first, [t.text_of(i).decode() for i in range(n_ok)])
+            if len(bad):
+                bail("read %d: the reference panics on this input" % (t.first + n_ok))
+    except api._lib.RecGraphError as ex:         # a failed tile
+        bail(str(ex))
     th.join()
     sc.join()
     if "err" in scan:        # (a file without a single complete read: no tile ever came)

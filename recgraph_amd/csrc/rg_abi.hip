@@ -47,6 +47,7 @@ Options& options() {
         o.no_order = env("RG_NO_ORDER");
         o.spin_wait = env("RG_SPIN_WAIT");
         { const char* v = getenv("RG_SPEC_MARGIN"); if (v) o.spec_margin = atoi(v); }
+        { const char* v = getenv("RG_LDS_PAD"); o.lds_pad = v ? atoi(v) : 0; }
     });
     return o;
 }
@@ -375,6 +376,8 @@ static std::atomic<int>* option_slot(const char* name) {
     if (!strcmp(name, "no_order")) return &o.no_order;
     if (!strcmp(name, "spin_wait")) return &o.spin_wait;
     if (!strcmp(name, "spec_margin")) return &o.spec_margin;
+    if (!strcmp(name, "lds_pad")) return &o.lds_pad;
+    if (!strcmp(name, "retire_shift")) return &retire_shift_option();
     return nullptr;
 }
 int32_t rg_set_option(const char* name, int64_t value) {
@@ -383,6 +386,8 @@ int32_t rg_set_option(const char* name, int64_t value) {
     Options& o = options();
     if (s == &o.stripe_c) *s = (int)std::max<int64_t>(0, std::min<int64_t>(value, 32));
     else if (s == &o.chunk_reads) *s = (int)std::max<int64_t>(0, std::min<int64_t>(value, 1 << 20));
+    else if (s == &retire_shift_option()) *s = (int)std::max<int64_t>(2, std::min<int64_t>(value, 12));
+    else if (s == &o.lds_pad) *s = (int)std::max<int64_t>(0, std::min<int64_t>(value, 40 << 10));
     else if (s == &o.spec_margin) *s = (int)std::max<int64_t>(-(1 << 24), std::min<int64_t>(value, 1 << 24));
     else if (s == &o.no_retire) *s = (int)std::max<int64_t>(0, std::min<int64_t>(value, 3));     // 1: off, 2: forward sweep only, 3: reverse sweep only
     else *s = value ? 1 : 0;

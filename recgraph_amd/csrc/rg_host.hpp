@@ -38,6 +38,7 @@ struct Options {
     std::atomic<int> no_order{0};       // RG_NO_ORDER: the sweeps' waves in read order (no longest-first launch order)
     std::atomic<int> no_pick2{0};       // RG_NO_PICK2: the speculative bound from one-path picks only (no two-path picks)
     std::atomic<int> layer_i32{0};      // RG_LAYER_I32: k_layer in its i32 form even when the sweep ran packed (test hook)
+    std::atomic<int> lds_pad{0};        // RG_LDS_PAD (experiments only): extra dynamic LDS bytes per k_sweep16 workgroup — lowers the waves per CU
     std::atomic<int> chunk_reads{0};    // RG_CHUNK_READS: most reads one pathwise kernel launch takes (0: what the HBM budget allows, <= 8192)
 };
 Options& options();
@@ -140,8 +141,14 @@ struct StepTables {
     std::vector<StepRec> plain, split;
     std::vector<unsigned long long> lead_plain, lead_split;
     unsigned long long members = 0;
+    int retire_shift = RG_SWEEP16_RETIRE_SHIFT;     // the period the lead tables were built for
 };
 void build_step_tables(const HostGraph& h, bool forward, bool want_split, StepTables& out);
+// log2 of the records between two evaluation points of the path retirement (rg_set_option "retire_shift" / RG_RETIRE_SHIFT,
+// 2..12, default RG_SWEEP16_RETIRE_SHIFT = 8): read when a handle builds its step tables, carried to the kernel with them
+// (StepTables::retire_shift -> SweepArgs::retire_shift).  Small graphs only retire paths with a small period: the test
+// suite runs its switch families at 4.
+std::atomic<int>& retire_shift_option();
 
 // ---- alignment records as they come back from the device ----
 struct ReadRecord {

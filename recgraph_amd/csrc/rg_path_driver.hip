@@ -56,6 +56,7 @@ struct PathWorkImpl {
     int nfsteps = 0, nrsteps = 0;
     Buf<int4> fsplit, rsplit;         // the same records with TAILs moved behind their register runs (split_tails below)
     Buf<unsigned long long> flead, rlead, fslead, rslead;    // PATH RETIREMENT tables of the four step tables (lead_table below)
+    int retire_shift = RG_SWEEP16_RETIRE_SHIFT;              // the evaluation period the lead tables were built for
     unsigned long long fmembers = 0, rmembers = 0;           // member rows of the forward / reverse table (sum of the group sizes)
     bool have_split = false;
     unsigned fcap = 0, rcap = 0;
@@ -259,6 +260,7 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
         if ((rc = up_recs(w.fsteps, st.plain))) return rc;
         w.nfsteps = (int)st.plain.size();
         w.fmembers = st.members;
+        w.retire_shift = st.retire_shift;
         if (P <= 64 && (rc = w.flead.upload(st.lead_plain))) return rc;
         if (w.have_split && ((rc = up_recs(w.fsplit, st.split)) || (rc = w.fslead.upload(st.lead_split)))) return rc;
         build_step_tables(h, false, w.have_split, st);
@@ -275,7 +277,7 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
     // reads per chunk: bounded by a memory budget for the per-read work buffers
     const size_t per_read = (size_t)(fdirs_stride + (mode == RG_MODE_RECOMBINATION ? rdirs_stride : 0)) * 4 +
                             (size_t)layer_stride * 4 * (mode == RG_MODE_RECOMBINATION ? 2 : 1) +
-                            (size_t)P * wpad * 4 + (size_t)wpad * 20 + sizeof(ReadState);
+                            (size_t)(P + 2) * wpad * 4 + (size_t)wpad * 20 + sizeof(ReadState);
     size_t budget = (size_t)96 << 30;
     {
         size_t fr = 0, tot = 0;
@@ -331,7 +333,8 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
             if ((rc = w.state.alloc(chunk)) || (rc = w.fdirs.alloc((size_t)chunk * fdirs_stride)) ||
                 (rc = w.flayer.alloc((size_t)chunk * layer_stride)))
                 return rc;
-            if ((rc = w.roll.alloc((size_t)chunk * P * wpad))) return rc;
+            // (k_sweep16: P + 2 packed rows per read — two pseudo-rows behind the rolling rows — of wpad / 2 words)
+            if ((rc = w.roll.alloc((size_t)chunk * (P + 2) * wpad))) return rc;
             if (mode == RG_MODE_RECOMBINATION) {
                 if ((rc = w.rdirs.alloc((size_t)chunk * rdirs_stride)) || (rc = w.rlayer.alloc((size_t)chunk * layer_stride)) ||
                     (rc = w.mf.alloc((size_t)chunk * wpad)) || (rc = w.mfc.alloc((size_t)chunk * wpad)) || (rc = w.wr.alloc((size_t)chunk * wpad)) ||
@@ -377,6 +380,7 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
             // path retirement: the record pipelines of -m 8 (global), P <= 64
             sa.flead = w.flead.p; sa.rlead = w.rlead.p; sa.fslead = w.fslead.p; sa.rslead = w.rslead.p;
             sa.retire = use16 && P <= 64 && !semi && mode == RG_MODE_RECOMBINATION && gaps_nonpos && opt.no_retire != 1 ? 1 : 0;
+            sa.retire_shift = w.retire_shift;
             sa.fmembers = w.fmembers; sa.rmembers = w.rmembers;
             sa.maxmatch = maxmatch;      // (both sweeps: the retirement bound; the forward sweep's speculative thresholds)
         }

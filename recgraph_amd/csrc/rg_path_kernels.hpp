@@ -64,12 +64,13 @@ struct SweepArgs {
     int gather_ok;             // k_sweep16 gather runs: the difference of two members' packed values provably fits 16 bits
     // k_sweep16 PATH RETIREMENT (record pipelines, P <= 64): per 256 records of the step table and per path, the union of the
     // member masks of the groups the path leads from there on ([evaluation point][64]); one table per step table.
-    // Evaluation points: every 2^RG_SWEEP16_RETIRE_SHIFT records (kernel and table builder share the constant)
+    // Evaluation points: every 2^retire_shift records (StepTables::retire_shift: what the table builder used)
     const unsigned long long* flead;
     const unsigned long long* rlead;
     const unsigned long long* fslead;   // ... of the split tables
     const unsigned long long* rslead;
     int retire;
+    int retire_shift;
     const int* order;                   // launch order of the reads (block b sweeps read order[b]) or null: see launch_order
     unsigned long long table_members;   // member rows of the step table in use (k_sweep16 with path retirement counts cells from it)
     unsigned long long fmembers, rmembers;

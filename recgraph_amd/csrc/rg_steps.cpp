@@ -11,7 +11,18 @@
 #include <utility>
 #include <vector>
 
+#include <cstdlib>
+
 namespace rg {
+
+std::atomic<int>& retire_shift_option() {
+    static std::atomic<int> v{[] {
+        const char* e = getenv("RG_RETIRE_SHIFT");
+        const int k = e ? atoi(e) : RG_SWEEP16_RETIRE_SHIFT;
+        return k < 2 ? 2 : (k > 12 ? 12 : k);
+    }()};
+    return v;
+}
 
 void build_step_tables(const HostGraph& h, bool forward, bool want_split, StepTables& T) {
     const int L = h.L;
@@ -136,11 +147,11 @@ auto split_tails = [&](const std::vector<StepRec>& in, std::vector<StepRec>& out
         q = e;
     }
 };
-// PATH RETIREMENT (k_sweep16): per evaluation point e (record e << RG_SWEEP16_RETIRE_SHIFT) and path k, the union of the member masks of the
+// PATH RETIREMENT (k_sweep16): per evaluation point e (record e << retire_shift) and path k, the union of the member masks of the
 // groups k LEADS in the records from there on (groups with other members only): a path that is hopeless for a read may
 // stop being computed once no path that is still needed appears in that union
 auto lead_table = [&](const std::vector<StepRec>& recs) {
-    constexpr size_t EV = (size_t)1 << RG_SWEEP16_RETIRE_SHIFT;       // records per evaluation point
+    const size_t EV = (size_t)1 << T.retire_shift;                    // records per evaluation point
     const size_t E = recs.size() / EV + 2;
     std::vector<unsigned long long> out(E * 64, 0ull);
     unsigned long long cur[64] = {};
@@ -157,6 +168,7 @@ auto lead_table = [&](const std::vector<StepRec>& recs) {
 };
 
     steps(goff_, groups_, forward, T.plain);
+    T.retire_shift = retire_shift_option().load();
     T.members = 0;
     for (const StepRec& r : T.plain) T.members += (unsigned long long)(__builtin_popcount((unsigned)r.z) + __builtin_popcount((unsigned)r.w));
     T.lead_plain.clear();

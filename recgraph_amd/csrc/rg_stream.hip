@@ -124,6 +124,7 @@ struct rg_stream {
     int64_t tiles_pushed = 0, next_out = 0, reads_pushed = 0;
     int64_t undelivered_bytes = 0;          // out_bytes of the tiles in `done`
     bool finished = false, stopping = false;
+    bool aborted = false;                   // rg_stream_abort: queued tiles are dropped, every blocked push / feed / next returns an error
     std::vector<std::thread> workers;
     std::unique_ptr<Tile> cur;              // the tile rg_stream_next last returned
     std::vector<rg_batch*> kept;            // keep_records: results-only handles of the delivered tiles (until released)
@@ -149,6 +150,11 @@ struct rg_stream {
         }
         cv_work.notify_all();
         cv_space.notify_all();
+        cv_done.notify_all();
+        // a thread still inside rg_stream_push / rg_stream_feed_fasta (blocked on a full queue until `stopping` woke it) leaves
+        // through members of this object: wait until it is out (a daemon feeder at interpreter teardown)
+        { std::lock_guard<std::mutex> f(fmu); }
+        { std::lock_guard<std::mutex> q(pmu); }
         for (auto& t : workers) t.join();
         for (Tile* t : queue) delete t;
         for (auto& kv : done) delete kv.second;
@@ -290,11 +296,11 @@ struct rg_stream {
                 // back-pressure on the output side: no new tile while the finished, undelivered ones hold more than the
                 // cap — except the tile rg_stream_next is waiting for (the queue is in id order: that is its front)
                 cv_work.wait(lk, [&] {
-                    if (stopping) return true;
+                    if (stopping || aborted) return true;
                     if (queue.empty()) return false;
                     return o.max_undelivered_bytes <= 0 || undelivered_bytes < o.max_undelivered_bytes || queue.front()->id == next_out;
                 });
-                if (stopping) break;
+                if (stopping || aborted) break;
                 t = queue.front();
                 queue.pop_front();
             }
@@ -337,6 +343,7 @@ struct rg_stream {
         bool first_push;
         {
             std::lock_guard<std::mutex> lk(mu);
+            if (aborted) return fail(RG_ERR_ARG, "stream aborted");
             if (finished) return fail(RG_ERR_ARG, "rg_stream_push after rg_stream_finish");
             first_push = tiles_pushed == 0;
         }
@@ -359,7 +366,8 @@ struct rg_stream {
                 std::unique_lock<std::mutex> lk(mu);
                 if (o.max_queued_tiles > 0)
                     cv_space.wait(lk, [&] { return stopping || finished || (int64_t)queue.size() < o.max_queued_tiles; });
-                if (finished || stopping) return fail(RG_ERR_ARG, "rg_stream_push after rg_stream_finish");
+                if (aborted || stopping) return fail(RG_ERR_ARG, "stream aborted");
+                if (finished) return fail(RG_ERR_ARG, "rg_stream_push after rg_stream_finish");
                 if (base < 0) { base = reads_pushed; reads_pushed += nreads; }
                 t->id = tiles_pushed++;
                 t->first = base + lo;
@@ -450,10 +458,10 @@ int32_t rg_stream_feed_fasta(rg_stream* s, const char* piece, int64_t len, int32
             int64_t have = (int64_t)r.names.size(), at = 0;
             while (have - at >= s->tile_reads || (all && have > at)) {
                 const int64_t cnt = std::min<int64_t>(s->tile_reads, have - at);
-                // ONE tile per push (see rg_stream::push): names handed over by value
-                std::vector<std::string> nm(std::make_move_iterator(r.names.begin() + at), std::make_move_iterator(r.names.begin() + at + cnt));
                 for (int64_t i = 0; i < cnt; ++i)
                     if (r.off[(size_t)(at + i + 1)] - r.off[(size_t)(at + i)] < 1) return fail(RG_ERR_ARG, "empty read");
+                // ONE tile per push (see rg_stream::push): names handed over by value
+                std::vector<std::string> nm(std::make_move_iterator(r.names.begin() + at), std::make_move_iterator(r.names.begin() + at + cnt));
                 const int rc = s->push(r.bases.data(), r.off.data() + at, cnt, nullptr, &nm);
                 if (rc) return rc;
                 at += cnt;
@@ -479,7 +487,12 @@ int32_t rg_stream_feed_fasta(rg_stream* s, const char* piece, int64_t len, int32
             rc = flush(true);
         }
         if (nreads_out) *nreads_out = total;
-        if (rc) return rc;
+        if (rc) {
+            // a failed feed leaves nothing behind: reads already pushed are not pushed again, no stale carry
+            s->feeder = rg::FastaFeeder();
+            s->fbuf = rg::FastaReads();
+            return rc;
+        }
         if (final) {
             const bool ok = s->feeder.balanced();
             s->feeder = rg::FastaFeeder();
@@ -489,6 +502,8 @@ int32_t rg_stream_feed_fasta(rg_stream* s, const char* piece, int64_t len, int32
         return RG_OK;
     } catch (const std::exception& ex) {
         if (nreads_out) *nreads_out = total;
+        s->feeder = rg::FastaFeeder();
+        s->fbuf = rg::FastaReads();
         return fail(RG_ERR_CAPACITY, std::string("host memory: ") + ex.what());
     }
 }
@@ -509,6 +524,19 @@ int32_t rg_stream_finish(rg_stream* s) {
     return RG_OK;
 }
 
+int32_t rg_stream_abort(rg_stream* s) {
+    if (!s) return fail(RG_ERR_ARG, "null stream");
+    {
+        std::lock_guard<std::mutex> lk(s->mu);
+        s->aborted = true;
+        s->finished = true;
+    }
+    s->cv_done.notify_all();
+    s->cv_space.notify_all();
+    s->cv_work.notify_all();
+    return RG_OK;
+}
+
 int64_t rg_stream_pending(rg_stream* s) {
     if (!s) return 0;
     std::lock_guard<std::mutex> lk(s->mu);
@@ -520,7 +548,8 @@ int32_t rg_stream_next(rg_stream* s, rg_stream_result* out) {
     Tile* t = nullptr;
     {
         std::unique_lock<std::mutex> lk(s->mu);
-        s->cv_done.wait(lk, [&] { return s->done.count(s->next_out) || (s->finished && s->next_out == s->tiles_pushed); });
+        s->cv_done.wait(lk, [&] { return s->aborted || s->done.count(s->next_out) || (s->finished && s->next_out == s->tiles_pushed); });
+        if (s->aborted) return fail(RG_ERR_ARG, "stream aborted");
         auto it = s->done.find(s->next_out);
         if (it == s->done.end()) return RG_STREAM_END;
         t = it->second;

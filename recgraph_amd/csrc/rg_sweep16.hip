@@ -165,9 +165,6 @@ struct RowOps16 {
 #ifndef RG_SWEEP16_KRUN
 #define RG_SWEEP16_KRUN 4
 #endif
-#ifndef RG_SWEEP16_THRLDS
-#define RG_SWEEP16_THRLDS 0
-#endif
 #ifndef RG_SWEEP16_GATHER
 #define RG_SWEEP16_GATHER 1          // gather runs (see k_sweep16 and gather_pays)
 #endif
@@ -196,6 +193,9 @@ struct RowOps16 {
 #ifndef RG_SWEEP16_REV_WAVES
 #define RG_SWEEP16_REV_WAVES 2                   // waves per SIMD the compiler must fit that variant into
 #endif
+#ifndef RG_SWEEP16_FWD_WAVES
+#define RG_SWEEP16_FWD_WAVES 2                   // ... and the variants that track column maxima (C <= 16)
+#endif
 // TIMING-ONLY build variants (tools/sweep_variants.sh; the results of such a build are garbage and nothing ships them):
 //   RG_SWEEP16_NOROWS   no rolling-row load / store in the main loop (rows stay whatever the registers hold)
 //   RG_SWEEP16_NOKEYS   the best-member keys are not built (row_end runs on constant keys)
@@ -223,7 +223,7 @@ struct RowOps16 {
 // kWide = true: graphs with more than 64 paths (step entries carry a 64-path page and continuation entries exist); the
 // narrow variant compiles that logic out (page 0, no continuation: it costs registers the forward sweep does not have)
 template <int C, int kColmax, bool kRec, bool kWide>
-__global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_WAVES) void k_sweep16(SweepArgs a) {
+__global__ __launch_bounds__(64, C > 16 ? 2 : (kColmax != 0 ? RG_SWEEP16_FWD_WAVES : RG_SWEEP16_REV_WAVES)) void k_sweep16(SweepArgs a) {
     constexpr int H = C / 2;
     constexpr bool kTrack = kColmax != 0 || kRec;      // <0, false>: the -m 4 / -m 5 sweep — no best member, no thresholds, no emission
     constexpr bool kRet = kRec && kColmax != 1 && !kWide && C <= 16;   // PATH RETIREMENT (record pipelines of -m 8, P <= 64): see retire_eval
@@ -246,23 +246,27 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
     const int ncols = rev ? n : n + 1;
     const int GAP = 5;
     extern __shared__ __attribute__((aligned(16))) int lds16[];
+    // LDS of one wave: 13 056 bytes at C = 16 in the narrow variants — TWELVE waves (three per SIMD) fit the CU's 160 KB.
+    // Round 5 took 5.6 KB out of the 18.7 KB that capped the CU at eight: the retirement constants and the profile of 'N'
+    // rows live in two pseudo-rows behind the read's rolling rows (PR_RVL, PR_NPROF: read once per 256 records / per 'N'
+    // row), the gather runs re-read the alpha's run-start row from its own rolling row (untouched until the run's end)
+    // instead of keeping a copy, and the semiglobal end arrays are sized by the variant's path count.
+    constexpr int EP = kWide ? RG_MAXP : 64;
+    constexpr int GTW = C * WAVE > 5 * 64 ? C * WAVE : 5 * 64;
     int* sct = lds16;                    // [36] score table
-    int* endv = lds16 + 64;              // [RG_MAXP]
-    int* endr = lds16 + 64 + RG_MAXP;    // [RG_MAXP]
+    int* endv = lds16 + 64;              // [EP]
+    int* endr = endv + EP;               // [EP]
+    // gather runs (below): gT[q][lane] = best (delta << 16 | path) of the run's members at the run start; at the end of the
+    // run the same words hold one packed row at a time ([r][lane]: the alpha's row at the run start, then each member's)
+    int* gT = endr + EP;                 // [GTW]
     // [5][64] packed score pairs: s2[li*64 + (code_lo | code_hi << 3)] — only read while the profile below is built: it
-    // shares the words of gT / gS (C * 64 + C / 2 * 64 >= 320 words)
-    int* s2 = lds16 + 64 + 2 * RG_MAXP + (RG_SWEEP16_THRLDS ? C * WAVE : 0);
-    // gather runs (below): gT[q][lane] = best (delta << 16 | path) of the run's members at the run start, gS[r][lane] = one
-    // member's packed row at the run start
-    int* gT = lds16 + 64 + 2 * RG_MAXP + (RG_SWEEP16_THRLDS ? C * WAVE : 0);            // [C][64]
-    int* gS = gT + C * WAVE;                                                               // [H][64]
+    // shares the words of gT
+    int* s2 = gT;
     // score profile of this read: sprof[(li * 64 + lane) * H + r] = the packed (s - g) pair register r of the lane adds on a
-    // diagonal step into a row whose base is li — one 16-byte LDS read per four registers and row instead of a code
-    // extraction + table lookup per register (24 VALU instructions per row at C = 16)
-    int* sprof = gS + H * WAVE;                                                            // [5][64][H]
-    // PATH RETIREMENT constants (below), [H][64] <= 512 words: they share the semiglobal end arrays' words (retirement is off in
-    // the semiglobal modes; one more 2 KB block per wave would push eight waves past the CU's 160 KB of LDS)
-    int* rvl = endv;
+    // diagonal step into a row whose base is li (A, C, G, T) — one 16-byte LDS read per four registers and row instead of a
+    // code extraction + table lookup per register (24 VALU instructions per row at C = 16)
+    int* sprof = gT + GTW;               // [4][64][H]
+    const int PR_RVL = P, PR_NPROF = P + 1;     // pseudo-rows behind the P rolling rows (same [lane][r] layout)
     if (lane < 36) sct[lane] = a.sc.t[lane];
     __syncthreads();
     const int gcost = sct[GAP];          // uniform read-gap cost (checked by the launcher): the z-space slope
@@ -270,7 +274,7 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
         const int li = e >> 6, cl = e & 7, ch = (e >> 3) & 7;
         s2[e] = (cl < 6 && ch < 6) ? pack16(sct[li * 6 + cl] - gcost, sct[li * 6 + ch] - gcost) : 0;   // diagonal step in z-space
     }
-    int* rows = a.roll + (long long)rd * P * wrow;
+    int* rows = a.roll + (long long)rd * (P + 2) * wrow;
     // rolling rows in HBM: [path][lane][r] — the H packed words of a lane are contiguous, so a row moves as 16-byte
     // accesses (two per lane at C = 16; the wave covers the row's 2 KB contiguously) instead of one 4-byte access per word
     auto ld_row = [&](int k, int (&dst)[H]) {
@@ -297,15 +301,9 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
     };
     // per-column constants of this lane
     unsigned long long pcode[(H + 7) / 8] = {};   // 8 bits per register: code_lo | code_hi << 3
-    // emission threshold << 16 per column (INT32_MAX = never; columns that do not exist).  Kept in LDS ([q][lane], read once
-    // per row by the epilogue): the forward variant has no registers to spare (RG_SWEEP16_THRLDS=0: in registers)
-#if RG_SWEEP16_THRLDS
-    int* thrl = lds16 + 64 + 2 * RG_MAXP;
-#define THRK(q) thrl[(q) * WAVE + lane]
-#else
+    // emission threshold << 16 per column (INT32_MAX = never; columns that do not exist)
     int thrk[(kRec || !kTrack) ? 1 : C];        // (record variants test packed values against thz: no per-column key thresholds to keep)
 #define THRK(q) thrk[(kRec || !kTrack) ? 0 : (q)]
-#endif
     int thz[kRec ? H : 1];               // packed (threshold >> 16) pairs, see below
     int minplain2 = 0;
     int next_eval = INT32_MAX;           // PATH RETIREMENT: the record index of the next evaluation (INT32_MAX: off for this read)
@@ -343,9 +341,15 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
             if (!kRec && kTrack) THRK(q) = thr_key(q, true);
         }
 #pragma unroll
-        for (int li = 0; li < 5; ++li) {
+        for (int li = 0; li < 4; ++li) {
 #pragma unroll
             for (int r = 0; r < H; ++r) sprof[(li * WAVE + lane) * H + r] = s2[li * 64 + (int)((pcode[r / 8] >> (8 * (r % 8))) & 63)];
+        }
+        {
+            int np[H];
+#pragma unroll
+            for (int r = 0; r < H; ++r) np[r] = s2[4 * 64 + (int)((pcode[r / 8] >> (8 * (r % 8))) & 63)];
+            st_row(PR_NPROF, np);
         }
         // start rows: the gap-only row, identical for every path (uniform gap cost: A = c * gcost, z = 0)
 #pragma unroll
@@ -372,10 +376,9 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
         //            hopeless  <=>  max_j (A[j] + mmx (n - j)) < lb
         //   reverse: it matters only if w[j'] >= thr[j'] (the emission threshold):
         //            hopeless  <=>  for all j: A[j] + mmx j < min_{j' <= j} (thr[j'] + mmx j')
-        // Both are "max over the row of (z + constant per column) < 0" on the packed z-space rows: rvl holds the constants
-        // (saturating 16-bit; a constant that would have to be ROUNDED DOWN to fit switches the retirement off for the read).
+        // Both are "max over the row of (z + constant per column) < 0" on the packed z-space rows: pseudo-row PR_RVL holds the
+        // constants (saturating 16-bit; a constant that would have to be ROUNDED DOWN to fit switches the retirement off for the read).
         if (kRet && a.retire && !a.semi) {
-            static_assert(!kRet || H * WAVE <= 2 * RG_MAXP, "rvl shares endv / endr");
             const int mmx = max(a.maxmatch, 0);
             int tv[C];
             bool ovf = false;
@@ -414,9 +417,13 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
                     tv[q] = (c < ncols && run != INT32_MAX) ? (int)max(-32768ll, min(32767ll, v)) : -32768;
                 }
             }
+            {
+                int rvc[H];
 #pragma unroll
-            for (int r = 0; r < H; ++r) rvl[r * WAVE + lane] = pack16(tv[r], tv[r + H]);
-            if ((rev ? a.thr != nullptr : a.lb != nullptr) && !__any(ovf)) next_eval = 1 << RG_SWEEP16_RETIRE_SHIFT;
+                for (int r = 0; r < H; ++r) rvc[r] = pack16(tv[r], tv[r + H]);
+                st_row(PR_RVL, rvc);
+            }
+            if ((rev ? a.thr != nullptr : a.lb != nullptr) && !__any(ovf)) next_eval = 1 << a.retire_shift;
         }
     }
     __syncthreads();
@@ -651,7 +658,7 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
     // semiglobal end-row selection (see k_sweep)
     const bool semi_end = a.semi && !rev;
     const int ln_end = n / C, ql_end = n % C;
-    if (semi_end) for (int k = lane; k < RG_MAXP; k += WAVE) { endv[k] = INT32_MIN; endr[k] = 0; }
+    if (semi_end) for (int k = lane; k < EP; k += WAVE) { endv[k] = INT32_MIN; endr[k] = 0; }
     __syncthreads();
     int gbest_val = INT32_MIN, gbest_row = 0, gbest_path = 0, rowkey = INT32_MIN;
     auto end_fold = [&](int k, int i, const int (&row)[H]) {
@@ -701,6 +708,13 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
 
     int s[H];
     auto load_steps = [&](int li_) {
+        if (li_ >= 4) [[unlikely]] {
+            // an 'N' row of the graph: its profile is a pseudo-row.  (The empty asm keeps the two paths apart: merged, the
+            // compiler selects between the LDS and the global ADDRESS and issues flat loads for every row.)
+            ld_row(PR_NPROF, s);
+            asm volatile("" ::: "memory");
+            return;
+        }
         const int* sp = sprof + (li_ * WAVE + lane) * H;
         if constexpr (H >= 4) {
 #pragma unroll
@@ -721,7 +735,7 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
     int MU[H], ML[H], SEL[H];
     unsigned lmask = 0;                  // L mask and fill-forward source lane of the current group's alpha: live across
     int src = 0;                         // the continuation entries of a group that spans 64-path pages
-    // PATH RETIREMENT (kRet): `needed` = the paths whose rows are still computed.  Every 2^RG_SWEEP16_RETIRE_SHIFT records (at the top of the record
+    // PATH RETIREMENT (kRet): `needed` = the paths whose rows are still computed.  Every 2^a.retire_shift records (at the top of the record
     // loop: every row is in memory there) the hopeless paths are found (one pass over each needed row against the constants
     // in rvl) and a hopeless path is retired unless it still LEADS a group with a needed member further down the table — its
     // decisions are that member's directions — iterated to the fixpoint (lead: per evaluation point and path, the union of
@@ -738,6 +752,8 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
         unsigned long long hop = 0, todo = needed;
         // (four rows in flight per wait: one row per wait made the evaluations ~8 % of the sweep)
         constexpr int EB = C <= 16 ? 4 : 2;
+        int rvc[H];
+        ld_row(PR_RVL, rvc);
         while (todo) {
             int kq[EB];
             int tmp[EB][H];
@@ -753,9 +769,9 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
 #pragma unroll
             for (int u = 0; u < EB; ++u) {
                 if (kq[u] < 0) break;
-                int m = pk_add_sat(tmp[u][0], rvl[lane]);         // (constants from LDS every time: no registers held across the loop)
+                int m = pk_add_sat(tmp[u][0], rvc[0]);
 #pragma unroll
-                for (int r = 1; r < H; ++r) m = pk_max(m, pk_add_sat(tmp[u][r], rvl[r * WAVE + lane]));
+                for (int r = 1; r < H; ++r) m = pk_max(m, pk_add_sat(tmp[u][r], rvc[r]));
                 const int v = max(lo16(m), hi16(m));
                 if (__builtin_amdgcn_readlane(dpp_incl_max(v, INT32_MIN), WAVE - 1) < 0) hop |= 1ull << kq[u];
             }
@@ -783,8 +799,8 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
             // fetch and a test each they were a seventh of the sweep once half the member rows were retired)
             if ((t >> 6) != blk) fetch(t, w0, w1, gmask);           // (moves to t's block; the record is fetched again below)
             if (t >= next_eval) [[unlikely]] {
-                retire_eval(t >> RG_SWEEP16_RETIRE_SHIFT);
-                next_eval = (t | ((1 << RG_SWEEP16_RETIRE_SHIFT) - 1)) + 1;
+                retire_eval(t >> a.retire_shift);
+                next_eval = (t | ((1 << a.retire_shift) - 1)) + 1;
                 live = block_live();
             }
             const unsigned long long m = live >> (t & (WAVE - 1));
@@ -843,9 +859,7 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
             touch_group(gm, nme, gT);
 #pragma unroll
             for (int r = 0; r < H; ++r) A[r] = 0;
-            ld_row(ka, A);
-#pragma unroll
-            for (int r = 0; r < H; ++r) gS[r * WAVE + lane] = A[r];   // gS: the alpha's row at the run start
+            ld_row(ka, A);            // (the rolling row itself keeps the run-start values until phase (3) stores the new ones)
             // (1) best (delta, path) per column over the members at the run start; ties -> highest path id: members in
             // ascending order, a later one replaces on >=.  Packed: delta = row_k - A0 (saturating: |delta| fits, gather_ok)
 #ifndef RG_G_NOPH1
@@ -960,8 +974,15 @@ __global__ __launch_bounds__(64, (kColmax != 0 || C > 16) ? 2 : RG_SWEEP16_REV_W
 #ifndef RG_G_NOPH3
             {
                 int B[H];
-                __syncthreads();
-                touch_group(gm, nme, gT);
+                int* gS = gT;             // (the table of phase (1) is dead: its words hold one packed row at a time now)
+                {
+                    int a0[H];
+                    ld_row(ka, a0);       // the alpha's row at the run start
+                    __syncthreads();
+#pragma unroll
+                    for (int r = 0; r < H; ++r) gS[r * WAVE + lane] = a0[r];
+                    __syncthreads();
+                }
 #pragma unroll
                 for (int r = 0; r < H; ++r) {
                     const int c0 = G[r] & 0xffff, c1 = (unsigned)G[r] >> 16;
@@ -1609,7 +1630,7 @@ void launch_layer16(const LayerArgs& a, int nreads, int C, hipStream_t s) {
 
 template <int kColmax, bool kRec, bool kWide>
 static void launch_sweep16_w(const SweepArgs& a, int nreads, int C, hipStream_t s) {
-    const size_t bytes = (size_t)(64 + 2 * RG_MAXP + (RG_SWEEP16_THRLDS ? C * WAVE : 0) + C * WAVE + C / 2 * WAVE + 5 * WAVE * (C / 2)) * sizeof(int);
+    const size_t bytes = (size_t)(64 + 2 * (kWide ? RG_MAXP : 64) + std::max(C * WAVE, 5 * 64) + 4 * WAVE * (C / 2)) * sizeof(int) + (size_t)options().lds_pad;
     switch (C) {
         case 4: hipLaunchKernelGGL((k_sweep16<4, kColmax, kRec, kWide>), dim3(nreads), dim3(64), bytes, s, a); break;
         case 8: hipLaunchKernelGGL((k_sweep16<8, kColmax, kRec, kWide>), dim3(nreads), dim3(64), bytes, s, a); break;

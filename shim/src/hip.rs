@@ -21,6 +21,23 @@ fn check(rc: i32) -> Result<(), String> {
     }
 }
 
+/// `rg_fasta_check` over a whole file, block by block: the file-level panic of sequences::get_sequences
+/// (sequences.rs:41-43, "wrong fasta file format") ahead of any output.  Returns the number of reads.
+pub fn fasta_check_file(path: &str) -> Result<i64, String> {
+    use std::io::Read;
+    let mut file = std::fs::File::open(path).map_err(|e| e.to_string())?;
+    let mut block = vec![0u8; 4 << 20];
+    let mut state = [0i64; 4];
+    let mut n: i64 = 0;
+    loop {
+        let got = file.read(&mut block).map_err(|e| e.to_string())?;
+        check(unsafe { rg_fasta_check(block.as_ptr() as *const c_char, got as i64, (got == 0) as i32, state.as_mut_ptr(), &mut n) })?;
+        if got == 0 {
+            return Ok(n);
+        }
+    }
+}
+
 pub fn default_params(mode: i32) -> rg_params {
     let mut p = std::mem::MaybeUninit::<rg_params>::uninit();
     unsafe {
@@ -224,6 +241,12 @@ impl Stream {
 
     pub fn finish(&self) -> Result<(), String> {
         check(unsafe { rg_stream_finish(self.raw) })
+    }
+
+    /// Error exit: queued tiles are dropped and every thread blocked in `push` / `feed_fasta` / `next` returns `Err`
+    /// (`rg_stream_abort`).  Call it before leaving a scope that joins a feeder thread on any error path.
+    pub fn abort(&self) {
+        unsafe { rg_stream_abort(self.raw) };
     }
 
     /// The next tile in input order (blocks); Ok(None) after `finish` when everything was delivered.

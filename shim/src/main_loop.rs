@@ -65,36 +65,60 @@ pub fn align_all(align_mode: i32, sequence_path: &str, graph_path: &str, score_m
     opts.max_queued_tiles = 4;
     opts.max_undelivered_bytes = 64 << 20;
     let stream = hip::Stream::new(&graph, &params, None, Some(opts)).unwrap_or_else(|e| panic!("{}", e));
+    // The reference parses the whole file before it aligns anything and panics on a malformed one (sequences.rs:41-43): the
+    // same check runs over the file (counts only) before the first byte of output.
+    hip::fasta_check_file(sequence_path).unwrap_or_else(|e| panic!("{}", e));
     let stdout = std::io::stdout();
-    std::thread::scope(|sc| {
-        sc.spawn(|| {
-            let mut file = std::fs::File::open(sequence_path).unwrap();
-            let mut block = vec![0u8; 4 << 20];
-            loop {
-                // sequences::get_sequences (sequences.rs:5-45) runs inside the library; a file whose name / sequence
-                // counts differ comes back as "wrong fasta file format" (:41-43)
-                let got = file.read(&mut block).unwrap();
-                stream.feed_fasta(&block[..got], got == 0).unwrap_or_else(|e| panic!("{}", e));
-                if got == 0 {
-                    stream.finish().unwrap();
-                    break;
+    // The feeder NEVER panics and ALWAYS closes the stream: a panic inside a scoped thread is only seen at the join, while
+    // the main thread would sit in `next()` forever; and a main thread that unwinds while the feeder waits inside a bounded
+    // push would wait for that join forever.  So: the feeder hands its error over, and every error path of the main
+    // thread aborts the stream (which wakes a blocked push) before it leaves the scope.
+    let result: Result<(), String> = std::thread::scope(|sc| {
+        let feeder = sc.spawn(|| -> Result<(), String> {
+            let fed = (|| -> Result<(), String> {
+                let mut file = std::fs::File::open(sequence_path).map_err(|e| e.to_string())?;
+                let mut block = vec![0u8; 4 << 20];
+                loop {
+                    // sequences::get_sequences (sequences.rs:5-45) runs inside the library
+                    let got = file.read(&mut block).map_err(|e| e.to_string())?;
+                    stream.feed_fasta(&block[..got], got == 0)?;
+                    if got == 0 {
+                        return Ok(());
+                    }
                 }
+            })();
+            if fed.is_err() {
+                stream.abort(); // the consumer must not wait for tiles that will never come
             }
+            let _ = stream.finish();
+            fed
         });
-        while let Some(tile) = stream.next().unwrap_or_else(|e| panic!("{}", e)) {
-            for i in 0..tile.status.len() {
-                if tile.status[i] & (hip::RG_READ_WOULD_PANIC | hip::RG_READ_BAD_BASE) != 0 {
-                    panic!("read {}: the CPU path panics on this input", tile.first_read + i);
+        let drained = (|| -> Result<(), String> {
+            while let Some(tile) = stream.next()? {
+                for i in 0..tile.status.len() {
+                    if tile.status[i] & (hip::RG_READ_WOULD_PANIC | hip::RG_READ_BAD_BASE) != 0 {
+                        return Err(format!("read {}: the CPU path panics on this input", tile.first_read + i));
+                    }
+                    let text = &tile.text[tile.text_off[i] as usize..tile.text_off[i + 1] as usize];
+                    // the last line is the GAF record; lines before it are the `println!` warnings of the exec functions
+                    let body = &text[..text.len() - 1];
+                    let cut = body.iter().rposition(|c| *c == b'\n').map(|p| p + 1).unwrap_or(0);
+                    stdout.lock().write_all(&text[..cut]).map_err(|e| e.to_string())?;
+                    let record = String::from_utf8_lossy(&body[cut..]).into_owned();
+                    let n = tile.first_read + i;
+                    utils::write_gaf(&record, if align_mode <= 3 { n + 1 } else { n });
                 }
-                let text = &tile.text[tile.text_off[i] as usize..tile.text_off[i + 1] as usize];
-                // the last line is the GAF record; lines before it are the `println!` warnings of the exec functions
-                let body = &text[..text.len() - 1];
-                let cut = body.iter().rposition(|c| *c == b'\n').map(|p| p + 1).unwrap_or(0);
-                stdout.lock().write_all(&text[..cut]).unwrap();
-                let record = String::from_utf8_lossy(&body[cut..]).into_owned();
-                let n = tile.first_read + i;
-                utils::write_gaf(&record, if align_mode <= 3 { n + 1 } else { n });
             }
+            Ok(())
+        })();
+        if drained.is_err() {
+            stream.abort(); // wakes a feeder blocked in a bounded push: the scope can join it
         }
+        let fed = feeder.join().unwrap_or_else(|_| Err("feeder thread panicked".to_string()));
+        // the feeder's error is the cause when both failed ("stream aborted" is only its echo on the other side)
+        fed.and(drained)
     });
+    if let Err(e) = result {
+        panic!("{}", e);
+    }
 }

@@ -12,7 +12,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.mark.parametrize("seed", [11, 12])
 def test_fuzz_parity_short(seed):
+    # the second seed evaluates the path retirement every 16 records: the campaign's graphs are too small to retire anything
+    # at the default period of 256
+    env = dict(os.environ, RG_RETIRE_SHIFT="4") if seed == 12 else None
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_parity.py"), "20", str(seed)], capture_output=True,
-                       text=True, timeout=600)
+                       text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "failures 0" in r.stdout

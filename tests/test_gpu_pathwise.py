@@ -298,17 +298,21 @@ def test_random_dag_graphs_in_every_switch_family(oracle):
     that exercises a kernel switch ran on block-shaped haplotype graphs.  Here random-walk graphs (nested / overlapping
     bubbles, one-row segments, proper-subset groups) go through EVERY switch of the pathwise pipeline — i32 sweep, Cand-list
     emission, three sweeps, speculation off / zero margin / forced second pass, no gather, no split, small chunks, path
-    retirement off / in one sweep only, one-path picks only, and pairs of them — in all four pathwise modes: byte-identical to the default, which equals the oracle."""
+    retirement off / in one sweep only / evaluated every 16 or 4 records (so that graphs of this size retire paths at all),
+    one-path picks only, and pairs of them — in all four pathwise modes: byte-identical to the default, which equals the oracle."""
     from recgraph_amd import api, synth
     cases = ((150, 12, 301, {"max_jump": 3, "max_seg": 8}), (110, 32, 302, {"max_jump": 5, "max_seg": 12, "similar": 0.7}),
              (240, 5, 303, {"max_jump": 2, "max_seg": 4}))
     switches = (("sweep_i32", 1), ("no_frec", 1), ("three_sweeps", 1), ("no_spec", 1), ("spec_margin", 0), ("spec_margin", -1000000),
                 ("no_gather", 1), ("no_split", 1), ("chunk_reads", 5), ("layer_i32", 1), ("no_retire", 1), ("no_retire", 2), ("no_retire", 3),
-                ("no_pick2", 1), ("no_order", 1))
+                ("no_pick2", 1), ("no_order", 1), ("retire_shift", 4), ("retire_shift", 2))
     pairs = ((("three_sweeps", 1), ("sweep_i32", 1)), (("no_split", 1), ("no_gather", 1)), (("spec_margin", -1000000), ("chunk_reads", 4)),
              (("no_frec", 1), ("no_spec", 1)), (("no_retire", 1), ("no_split", 1)), (("no_spec", 1), ("no_gather", 1)),
-             (("no_pick2", 1), ("spec_margin", 0)), (("no_retire", 3), ("no_split", 1)))
-    defaults = {"spec_margin": SPEC_MARGIN_DEFAULT}
+             (("no_pick2", 1), ("spec_margin", 0)), (("no_retire", 3), ("no_split", 1)),
+             # evaluation every 16 / 4 records: graphs of this size only retire paths with a short period (VERDICT r4 2b)
+             (("retire_shift", 4), ("spec_margin", 0)), (("retire_shift", 3), ("no_split", 1)), (("retire_shift", 4), ("no_retire", 2)),
+             (("retire_shift", 4), ("no_retire", 3)), (("retire_shift", 4), ("no_gather", 1)), (("retire_shift", 4), ("no_pick2", 1)))
+    defaults = {"spec_margin": SPEC_MARGIN_DEFAULT, "retire_shift": 8}
     for nseg, P, seed, kw in cases:
         g = synth.random_dag_graph(nseg, P, seed=seed, **kw)
         plen = min(len(g.path_sequence(k)) for k in range(P))
