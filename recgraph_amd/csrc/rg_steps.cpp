@@ -83,8 +83,9 @@ auto steps = [&](const std::vector<int32_t>& goff, const std::vector<GroupDesc>&
 // paths are exactly the paths of a register run (<= 4 paths, led by the lowest) on its predecessor row moves
 // directly behind that run as a TAIL (flag bit 4 with a zero run field): the run continues into it with the rows
 // in registers, and the row's keys fold into bkey across its groups as before (its first / last record in the NEW
-// order carry the first / last bits).  Only runs that the kernel handles as register or gather runs may lie
-// between the groups of one row (they leave bkey alone): the block of such runs directly before the row.
+// order carry the first / last bits).  Only runs that the kernel handles as REGISTER runs may lie between the groups
+// of one row (they leave the row's keys alone, and unlike gather runs they do not use the LDS words the keys wait in):
+// the block of such runs directly before the row.
 auto split_tails = [&](const std::vector<StepRec>& in, std::vector<StepRec>& out) {
     out.clear();
     std::vector<StepMeta> om;
@@ -106,8 +107,11 @@ auto split_tails = [&](const std::vector<StepRec>& in, std::vector<StepRec>& out
             while (fl(out[b]) == 7u && b > 0 && is_run(out[b - 1]) && om[b - 1].mask == om[b].mask) --b;
             const int nm = __builtin_popcountll(om[b].mask);
             const int len = (int)(pos - b);
-            // register run (<= 4 paths), or a gather run by the kernel's own rule (decided at the run's first record)
-            const bool safe = nm <= 4 || (len <= 63 && (int)field(out[b]) == len && len * (77 * (nm - 1) - 160) >= 200 * (nm - 1));
+            // register runs only (<= 4 paths: rg_codes.hpp RG_SWEEP16_KRUN).  Round 4 also admitted gather runs here; since
+            // round 5 the keys of a row in progress wait in the LDS words of the gather table (k_sweep16: keys_ld / keys_st),
+            // so a run that uses that table must not lie between the groups of one row.
+            (void)len;
+            const bool safe = nm <= 4;
             if (!safe) break;
             runs.push_back({b, pos});
             pos = b;

@@ -34,6 +34,16 @@ constexpr int NEG16 = -30000;                               // "minus infinity" 
 constexpr int NEGPAIR = (int)(((unsigned)(NEG16 & 0xffff) << 16) | (unsigned)(NEG16 & 0xffff));
 constexpr int ONE2 = 0x00010001;
 
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+// buffer resource over [base, base + bytes) built from wave-uniform values only (the halves of the pointer go through
+// readfirstlane so that the compiler can PROVE it: otherwise every buffer operation becomes a waterfall loop)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const void* base, unsigned bytes) {
+    const unsigned long long u = (unsigned long long)base;
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)u), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(u >> 32));
+    void* p = (void*)(((unsigned long long)hi << 32) | lo);
+    return __builtin_amdgcn_make_buffer_rsrc(p, 0, (int)__builtin_amdgcn_readfirstlane((int)bytes), 0x00020000);
+}
 typedef short s16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 
@@ -172,11 +182,6 @@ struct RowOps16 {
 #define RG_SWEEP16_GATHER_FWD 1      // the forward record variant spills 121 registers with them compiled in and still gains 3 ms (47.7 -> 44.7)
 #endif
 
-#ifndef RG_SWEEP16_PF
-#define RG_SWEEP16_PF 0              // 1: row touches ahead of the loads (ROW TOUCHES in k_sweep16).  Measured SLOWER by ~1 ms per sweep
-                                     // (profiles/r03_sweep_variants_4.txt: BASE = 1, NOPF = 0): see the note there
-#endif
-
 #ifndef RG_SWEEP16_RUNWAIT
 #define RG_SWEEP16_RUNWAIT 1
 #endif
@@ -269,7 +274,9 @@ __global__ __launch_bounds__(64, C > 16 ? 2 : (kColmax != 0 ? RG_SWEEP16_FWD_WAV
     const int PR_RVL = P, PR_NPROF = P + 1;     // pseudo-rows behind the P rolling rows (same [lane][r] layout)
     if (lane < 36) sct[lane] = a.sc.t[lane];
     __syncthreads();
-    const int gcost = sct[GAP];          // uniform read-gap cost (checked by the launcher): the z-space slope
+    // uniform gap cost (checked by the launcher, sweep16_admissible: score(b, '-') is the same for b = A, C, G, T, N): the
+    // z-space slope — and, being the same table column, what a U move adds in EVERY row (g_i below): no per-row lookup
+    const int gcost = __builtin_amdgcn_readfirstlane(sct[GAP]);
     for (int e = lane; e < 5 * 64; e += WAVE) {
         const int li = e >> 6, cl = e & 7, ch = (e >> 3) & 7;
         s2[e] = (cl < 6 && ch < 6) ? pack16(sct[li * 6 + cl] - gcost, sct[li * 6 + ch] - gcost) : 0;   // diagonal step in z-space
@@ -277,26 +284,35 @@ __global__ __launch_bounds__(64, C > 16 ? 2 : (kColmax != 0 ? RG_SWEEP16_FWD_WAV
     int* rows = a.roll + (long long)rd * (P + 2) * wrow;
     // rolling rows in HBM: [path][lane][r] — the H packed words of a lane are contiguous, so a row moves as 16-byte
     // accesses (two per lane at C = 16; the wave covers the row's 2 KB contiguously) instead of one 4-byte access per word
+    // Row accesses are buffer operations: the read's row area as ONE resource descriptor in SGPRs, the row as the scalar
+    // offset (k is wave-uniform), the lane's 32-bit byte offset as the only VGPR — no 64-bit pointer arithmetic in VGPRs
+    // (the flat form kept `rows + lane offset` and one pointer per access as VGPR pairs and rebuilt them with v_lshl_add_u64)
+    const unsigned lane_row_off = (unsigned)lane * (unsigned)(H * sizeof(int));
+    const __amdgpu_buffer_rsrc_t rows_rsrc = uniform_rsrc(rows, (unsigned)((P + 2) * wrow) * 4u);
     auto ld_row = [&](int k, int (&dst)[H]) {
-        const int* p = rows + (long long)k * wrow + lane * H;
+        const int so = k * (int)(wrow * sizeof(int));
         if constexpr (H >= 4) {
 #pragma unroll
             for (int r4 = 0; r4 < H / 4; ++r4) {
-                const int4 v = reinterpret_cast<const int4*>(p)[r4];
-                dst[4 * r4] = v.x; dst[4 * r4 + 1] = v.y; dst[4 * r4 + 2] = v.z; dst[4 * r4 + 3] = v.w;
+                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rows_rsrc, (int)lane_row_off + 16 * r4, so, 0);
+                dst[4 * r4] = (int)v.x; dst[4 * r4 + 1] = (int)v.y; dst[4 * r4 + 2] = (int)v.z; dst[4 * r4 + 3] = (int)v.w;
             }
         } else {
-            const int2 v = *reinterpret_cast<const int2*>(p);
-            dst[0] = v.x; dst[1] = v.y;
+            const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rows_rsrc, (int)lane_row_off, so, 0);
+            dst[0] = (int)v.x; dst[1] = (int)v.y;
         }
     };
     auto st_row = [&](int k, const int (&src)[H]) {
-        int* p = rows + (long long)k * wrow + lane * H;
+        const int so = k * (int)(wrow * sizeof(int));
         if constexpr (H >= 4) {
 #pragma unroll
-            for (int r4 = 0; r4 < H / 4; ++r4) reinterpret_cast<int4*>(p)[r4] = make_int4(src[4 * r4], src[4 * r4 + 1], src[4 * r4 + 2], src[4 * r4 + 3]);
+            for (int r4 = 0; r4 < H / 4; ++r4) {
+                const u32x4 v = {(unsigned)src[4 * r4], (unsigned)src[4 * r4 + 1], (unsigned)src[4 * r4 + 2], (unsigned)src[4 * r4 + 3]};
+                __builtin_amdgcn_raw_buffer_store_b128(v, rows_rsrc, (int)lane_row_off + 16 * r4, so, 0);
+            }
         } else {
-            *reinterpret_cast<int2*>(p) = make_int2(src[0], src[1]);
+            const u32x2 v = {(unsigned)src[0], (unsigned)src[1]};
+            __builtin_amdgcn_raw_buffer_store_b64(v, rows_rsrc, (int)lane_row_off, so, 0);
         }
     };
     // per-column constants of this lane
@@ -360,6 +376,16 @@ __global__ __launch_bounds__(64, C > 16 ? 2 : (kColmax != 0 ? RG_SWEEP16_FWD_WAV
         for (int r = 0; r < (kRec ? H : 1); ++r)
             thz[kRec ? r : 0] = pack16(thr_key(kRec ? r : 0, true) >> 16, thr_key(kRec ? r + H : 0, true) >> 16);
         minplain2 = pack16(minplain >> 16, minplain >> 16);
+#ifdef RG_SWEEP16_LANEMIN
+        // (experiment: one threshold per lane — the lowest of its columns — instead of one per column: how many more records?)
+        {
+            int mt = 32767;
+#pragma unroll
+            for (int r = 0; r < (kRec ? H : 0); ++r) mt = min(mt, min(lo16(thz[kRec ? r : 0]), hi16(thz[kRec ? r : 0])));
+#pragma unroll
+            for (int r = 0; r < (kRec ? H : 0); ++r) thz[kRec ? r : 0] = pack16(mt, mt);
+        }
+#endif
         int row0[H];
 #pragma unroll
         for (int r = 0; r < H; ++r) {
@@ -442,6 +468,8 @@ __global__ __launch_bounds__(64, C > 16 ? 2 : (kColmax != 0 ? RG_SWEEP16_FWD_WAV
     Cand* cand = !kRec && a.cand ? a.cand + (long long)rd * a.cand_cap : nullptr;
     uint32_t* dirs = a.dirs ? a.dirs + (long long)rd * a.dirs_stride : nullptr;
     const bool track = kTrack && a.track_best;
+    // (direction words of this read: at most 2^20 slots of 64 or 128 words)
+    const __amdgpu_buffer_rsrc_t dirs_rsrc = uniform_rsrc(dirs, dirs ? (unsigned)min(a.dirs_stride * 4ll, 0x7fffffffll) : 0u);
 
     // Per-row epilogue on the packed keys bkey = value << 16 | path (non-members of the reference's matrices hold 0,
     // so a cell is usable iff its winner is a member: value > 0, or value == 0 and path > knm, or no non-member
@@ -494,7 +522,7 @@ __global__ __launch_bounds__(64, C > 16 ? 2 : (kColmax != 0 ? RG_SWEEP16_FWD_WAV
                 const unsigned before = __builtin_amdgcn_mbcnt_hi((unsigned)(has >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)has, 0u));
                 const unsigned pos = ncand + before;
                 if (((has >> lane) & 1ull) && pos < a.frec_cap) {
-                    int4* rp = reinterpret_cast<int4*>(a.frec + ((long long)rd * a.frec_cap + pos) * (4 + C));
+                    int4* rp = reinterpret_cast<int4*>(reinterpret_cast<char*>(a.frec + (long long)rd * a.frec_cap * (4 + C)) + pos * (unsigned)((4 + C) * sizeof(int)));
                     rp[0] = make_int4((i << 6) | lane, 0, 0, 0);
 #pragma unroll
                     for (int q4 = 0; q4 < C / 4; ++q4) rp[1 + q4] = make_int4(bkey[4 * q4], bkey[4 * q4 + 1], bkey[4 * q4 + 2], bkey[4 * q4 + 3]);
@@ -553,7 +581,7 @@ __global__ __launch_bounds__(64, C > 16 ? 2 : (kColmax != 0 ? RG_SWEEP16_FWD_WAV
         if (C <= 16) {
             const unsigned u16 = (umask & ((1u << H) - 1u)) | ((umask >> (16 - H)) & (((1u << H) - 1u) << H));
             const unsigned l16 = (lmask & ((1u << H) - 1u)) | ((lmask >> (16 - H)) & (((1u << H) - 1u) << H));
-            dirs[(long long)slot * a.dir_words + lane] = u16 | (l16 << 16);
+            __builtin_amdgcn_raw_buffer_store_b32(u16 | (l16 << 16), dirs_rsrc, lane * 4, slot * (a.dir_words * 4), 0);
         } else {
             dirs[(long long)slot * a.dir_words + lane] = umask;
             dirs[(long long)slot * a.dir_words + WAVE + lane] = lmask;
@@ -562,11 +590,10 @@ __global__ __launch_bounds__(64, C > 16 ? 2 : (kColmax != 0 ? RG_SWEEP16_FWD_WAV
 
     const int4* steps = rev ? a.rsteps : a.fsteps;
     const int nsteps = rev ? a.nrsteps : a.nfsteps;
-    int4 recs = make_int4(0, 0, 0, 0), recs_next = make_int4(0, 0, 0, 0);
+    int4 recs = make_int4(0, 0, 0, 0);
     if (lane < nsteps) recs = steps[lane];
-    if (WAVE + lane < nsteps) recs_next = steps[WAVE + lane];
     int t = 0;
-    int blk = 0;                         // the 64-record block `recs` holds (recs_next: the one behind it)
+    int blk = 0;                         // the 64-record block `recs` holds (one record per lane)
     // PATH RETIREMENT: the records of the block in `recs` that still have to be looked at — a needed member, or the last group
     // of a row with several groups (it closes the row even when skipped); the record loop jumps over the others
     unsigned long long live = ~0ull;
@@ -577,82 +604,36 @@ __global__ __launch_bounds__(64, C > 16 ? 2 : (kColmax != 0 ? RG_SWEEP16_FWD_WAV
         const unsigned long long m = ((unsigned long long)(unsigned)recs.w << 32) | (unsigned)recs.z;
         return __ballot((m & needed) != 0ull || (!is_run && (f & 3u) == 2u));
     };
+    // Records are taken in order and a look-ahead never goes back: whoever first touches a record of the next block moves
+    // `recs` there.  The block is waited for at once (an L2 hit once per 64 records): round 4 kept the block behind the
+    // current one in flight in four more registers, and that load — pending across the back edge of every row loop, its
+    // landing registers reused by the row's LDS reads — made the compiler open EVERY row with s_waitcnt vmcnt(0), which on
+    // gfx9 also drains the row-before's direction-word and record stores.
+    auto to_block = [&](int b) {
+        blk = b;
+        const int nb = b * WAVE + lane;
+        recs = nb < nsteps ? steps[nb] : make_int4(0, 0, 0, 0);
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        if (kRet) live = block_live();
+    };
     auto fetch = [&](int tt, int& w0, int& w1, unsigned long long& gmask) {
         const int idx = tt & (WAVE - 1);
-        if ((tt >> 6) != blk) {           // (records are taken in order: the next block)
-            recs = recs_next;
-            blk = tt >> 6;
-            const int nb = (blk + 1) * WAVE + lane;
-            recs_next = nb < nsteps ? steps[nb] : make_int4(0, 0, 0, 0);
-            if (kRet) live = block_live();
-        }
+        if ((tt >> 6) != blk) to_block(tt >> 6);
         w0 = __builtin_amdgcn_readlane(recs.x, idx);
         w1 = __builtin_amdgcn_readlane(recs.y, idx);
         gmask = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(recs.w, idx) << 32) |
                 (unsigned)__builtin_amdgcn_readlane(recs.z, idx);
     };
     constexpr int F_FIRST = 1, F_LAST = 2, F_INNER = 4;
-    // flags of record tt without consuming it (same or next batch)
+    // flags / members of record tt without consuming it (tt = the record the next fetch will take)
     auto peek_w0 = [&](int tt) -> int {
-        const int idx = tt & (WAVE - 1);
-        return (tt >> 6) != blk ? __builtin_amdgcn_readlane(recs_next.x, 0) : __builtin_amdgcn_readlane(recs.x, idx);
+        if ((tt >> 6) != blk) to_block(tt >> 6);
+        return __builtin_amdgcn_readlane(recs.x, tt & (WAVE - 1));
     };
-
-    // ROW TOUCHES (RG_SWEEP16_PF=1; off: measured slower).  The loops below keep ONE row load in flight (the next member's), and
-    // a rolling row misses the L2 (2048 resident reads x 64 KB), so the idea was to touch rows early: one load instruction
-    // for FOUR rows (lane l reads one word of line l % 16 of row l / 16), every member of a gather run before the pass that
-    // loads them one by one, and behind a register run's own loads the rows of what follows the run.  Loads return in order
-    // on gfx9 and a wait for a load also drains every store issued before it (one vmcnt for both), so the touches only help
-    // if the waits are for load latency — they are not: with the touches both sweeps got ~1 ms slower, while dropping the
-    // register runs' run-end STORES (timing-only KRUNNOST) takes 3-9 ms off: the waits drain stores.
-    int pf_sink = 0;
-    const int pf_off = ((lane & 15) * 32) & (wrow - 1);       // one word per 128-byte line of a row
-    auto peek_mask = [&](int tt) -> unsigned long long {      // members of record tt (0: outside the batches held / past the end)
-        const int d = tt - blk * WAVE;
-        if (tt >= nsteps || d >= 2 * WAVE) return 0ull;
-        const unsigned z = (unsigned)(d < WAVE ? __builtin_amdgcn_readlane(recs.z, d) : __builtin_amdgcn_readlane(recs_next.z, d - WAVE));
-        const unsigned w = (unsigned)(d < WAVE ? __builtin_amdgcn_readlane(recs.w, d) : __builtin_amdgcn_readlane(recs_next.w, d - WAVE));
-        return ((unsigned long long)w << 32) | z;
-    };
-    // up to four members of gm (lowest first), one touch
-    auto touch4 = [&](unsigned long long gm) -> int {
-        if (!gm) return 0;
-        const int k0 = __builtin_ctzll(gm);
-        gm = gm & (gm - 1) ? gm & (gm - 1) : gm;
-        const int k1 = __builtin_ctzll(gm);
-        gm = gm & (gm - 1) ? gm & (gm - 1) : gm;
-        const int k2 = __builtin_ctzll(gm);
-        gm = gm & (gm - 1) ? gm & (gm - 1) : gm;
-        const int k3 = __builtin_ctzll(gm);
-        int kk = k0;
-        kk = lane >= 16 ? k1 : kk;
-        kk = lane >= 32 ? k2 : kk;
-        kk = lane >= 48 ? k3 : kk;
-        return rows[(long long)kk * wrow + pf_off];
-    };
-    // every member of gm (up to 32): list in LDS (lst: 64 free words), then ceil(nm / 4) touches in flight together
-    auto touch_group = [&](unsigned long long gm, int nm_, int* lst) {
-        if (RG_SWEEP16_PF <= 0 || kWide) return;
-        if ((gm >> lane) & 1ull) lst[__popcll(gm & ((1ull << lane) - 1ull))] = lane;
-        __syncthreads();
-        int v[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            v[j] = 0;
-            if (4 * j < nm_) v[j] = rows[(long long)lst[min(4 * j + (lane >> 4), nm_ - 1)] * wrow + pf_off];
-        }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) pf_sink ^= v[j];
-        __syncthreads();
-    };
-
-    // members of record tt without consuming it (like peek_w0: tt = the record the next fetch will take)
     auto peek_gm = [&](int tt) -> unsigned long long {
+        if ((tt >> 6) != blk) to_block(tt >> 6);
         const int idx = tt & (WAVE - 1);
-        const bool nxt = (tt >> 6) != blk;
-        const unsigned z = (unsigned)(nxt ? __builtin_amdgcn_readlane(recs_next.z, 0) : __builtin_amdgcn_readlane(recs.z, idx));
-        const unsigned w = (unsigned)(nxt ? __builtin_amdgcn_readlane(recs_next.w, 0) : __builtin_amdgcn_readlane(recs.w, idx));
-        return ((unsigned long long)w << 32) | z;
+        return ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(recs.w, idx) << 32) | (unsigned)__builtin_amdgcn_readlane(recs.z, idx);
     };
 
     // semiglobal end-row selection (see k_sweep)
@@ -706,12 +687,12 @@ __global__ __launch_bounds__(64, C > 16 ? 2 : (kColmax != 0 ? RG_SWEEP16_FWD_WAV
         }
     };
 
-    int s[H];
-    auto load_steps = [&](int li_) {
+    auto load_steps = [&](int li_, int (&s)[H]) {
         if (li_ >= 4) [[unlikely]] {
             // an 'N' row of the graph: its profile is a pseudo-row.  (The empty asm keeps the two paths apart: merged, the
             // compiler selects between the LDS and the global ADDRESS and issues flat loads for every row.)
             ld_row(PR_NPROF, s);
+            __builtin_amdgcn_s_waitcnt(0x0F70);       // vmcnt(0) HERE: a load left pending makes every row of the common path wait for its stores
             asm volatile("" ::: "memory");
             return;
         }
@@ -727,14 +708,25 @@ __global__ __launch_bounds__(64, C > 16 ? 2 : (kColmax != 0 ? RG_SWEEP16_FWD_WAV
             s[0] = v.x; s[1] = v.y;
         }
     };
-    int bkey[C];
-#ifdef RG_SWEEP16_NOKEYS
+    // KEYS OF A ROW IN PROGRESS.  A row with several groups folds the (value, path) keys of its groups one record at a time
+    // — and in a split table register runs of other rows lie between those records.  The 16 keys used to sit in registers
+    // across the whole record loop; now they wait in LDS between the records of the row ([q][lane], the words of the gather
+    // table: the step-table builder lets no gather run lie between the groups of a row, rg_steps.cpp) and are registers only
+    // inside the record that folds into them: 16 VGPRs less in every run loop.
+    auto keys_ld = [&](int (&key)[C]) {
 #pragma unroll
-    for (int q = 0; q < C; ++q) bkey[q] = lane * C + q - 40000;
-#endif
-    int MU[H], ML[H], SEL[H];
-    unsigned lmask = 0;                  // L mask and fill-forward source lane of the current group's alpha: live across
-    int src = 0;                         // the continuation entries of a group that spans 64-path pages
+        for (int q = 0; q < C; ++q) key[q] = gT[q * WAVE + lane];
+    };
+    auto keys_st = [&](const int (&key)[C]) {
+#pragma unroll
+        for (int q = 0; q < C; ++q) gT[q * WAVE + lane] = key[q];
+    };
+    // (wide graphs only: direction masks, L mask and fill-forward source lane of the current group's alpha, live across the
+    // continuation entries of a group that spans 64-path pages.  Everywhere else these are locals of the record that
+    // computes them: nothing the compiler could mistake for state of the record loop)
+    int MUw[kWide ? H : 1], MLw[kWide ? H : 1];
+    unsigned lmaskw = 0;
+    int srcw = 0;
     // PATH RETIREMENT (kRet): `needed` = the paths whose rows are still computed.  Every 2^a.retire_shift records (at the top of the record
     // loop: every row is in memory there) the hopeless paths are found (one pass over each needed row against the constants
     // in rvl) and a hopeless path is retired unless it still LEADS a group with a needed member further down the table — its
@@ -743,7 +735,7 @@ __global__ __launch_bounds__(64, C > 16 ? 2 : (kColmax != 0 ? RG_SWEEP16_FWD_WAV
     // never read again: it cannot emit, it cannot be a cell's best member where something emits, its sink value is below
     // the bound k_verify checks; the needed paths see exactly the decisions they would see in the full sweep.
     // tests/c/band_experiment.cpp measures why this — not a column band — is the exact way to skip hopeless work here.
-    bool row_open = false;               // some group of the current several-group row has put its keys into bkey
+    bool row_open = false;               // some group of the current several-group row has put its keys into LDS (keys_st)
 #ifdef RG_SWEEP16_RETSTAT
     // (statistics build, tools/sweep_variants.sh RETSTAT: the counters carry evaluations | needed paths << 32 and not-hopeless paths)
     unsigned long long stat_e = 0, stat_n = 0, stat_h = 0;
@@ -835,7 +827,11 @@ __global__ __launch_bounds__(64, C > 16 ? 2 : (kColmax != 0 ? RG_SWEEP16_FWD_WAV
             // skipped or not.)
             if (run_left == 0) {
                 if (flags & F_FIRST) row_open = false;
-                if (track && (flags & F_LAST) && row_open) row_end(i, ((w1 >> 20) & 511) - 1, bkey);
+                if (track && (flags & F_LAST) && row_open) {
+                    int key[C];
+                    keys_ld(key);
+                    row_end(i, ((w1 >> 20) & 511) - 1, key);
+                }
                 if (flags & F_LAST) row_open = false;
             }
             ++t;
@@ -856,7 +852,6 @@ __global__ __launch_bounds__(64, C > 16 ? 2 : (kColmax != 0 ? RG_SWEEP16_FWD_WAV
             const int ka = ga;
             int A[H], G[H];
             __syncthreads();
-            touch_group(gm, nme, gT);
 #pragma unroll
             for (int r = 0; r < H; ++r) A[r] = 0;
             ld_row(ka, A);            // (the rolling row itself keeps the run-start values until phase (3) stores the new ones)
@@ -914,9 +909,12 @@ __global__ __launch_bounds__(64, C > 16 ? 2 : (kColmax != 0 ? RG_SWEEP16_FWD_WAV
             __syncthreads();
             int ri = i, rli = li, rslot = slot, rw1 = w1;
             for (int step = 0;; ++step) {
-                const int g_i = __builtin_amdgcn_readfirstlane(sct[rli * 6 + GAP]);
+                const int g_i = gcost;
                 const int g0 = a.semi ? 0 : g_i;
-                load_steps(rli);
+                int s[H], MU[H], ML[H];
+                unsigned lmask;
+                int src;
+                load_steps(rli, s);
                 unsigned umask;
                 RowOps16<C>::alpha(A, s, g_i, g0, lane, MU, ML, umask, lmask, src);
                 if (dirs) store_dirs(rslot, umask, lmask);
@@ -1050,54 +1048,55 @@ __global__ __launch_bounds__(64, C > 16 ? 2 : (kColmax != 0 ? RG_SWEEP16_FWD_WAV
 #pragma unroll
             for (int kk = 0; kk < KRUN; ++kk)
                 if (kk < rnm) {
+#if defined(RG_SWEEP16_KRUNNOLD) || defined(RG_SWEEP16_NOROWS) || defined(RG_SWEEP16_NOROWS32)
 #pragma unroll
-                    for (int r = 0; r < H; ++r) rr[kk][r] = s[r] ^ (kk + t);     // (only what the timing-only builds without loads keep)
+                    for (int r = 0; r < H; ++r) rr[kk][r] = lane ^ (kk + t);     // (what the timing-only builds without loads keep)
+#endif
 #ifndef RG_SWEEP16_KRUNNOLD
                     RG_ROW_LD(mk[kk], rr[kk]);
 #endif
                 }
-            int pf_next = 0;
 #if RG_SWEEP16_RUNWAIT
             // wait for the run's rows HERE: otherwise the compiler's wait sits at the top of the row loop as vmcnt(0) (one
             // counter for loads and stores on gfx9) and every row also waits for the direction-word store of the row before
             __builtin_amdgcn_s_waitcnt(0x0F70);
 #endif
-            if (RG_SWEEP16_PF > 0 && !kWide) {
-                // wait for the run's own rows here (the first row update would one instruction later), then touch the rows of
-                // the record behind the run (and behind its tail): that load is in flight while the run computes
-                __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0)
-                int nt = t + max(run_left, 1);
-                if (nt < nsteps && nt - blk * WAVE < 2 * WAVE) {
-                    const int pw = nt - blk * WAVE < WAVE ? __builtin_amdgcn_readlane(recs.x, (nt - blk * WAVE) & (WAVE - 1))
-                                                          : __builtin_amdgcn_readlane(recs_next.x, (nt - blk * WAVE) & (WAVE - 1));
-                    if (((pw >> 23) & F_INNER) && ((pw >> 26) & 63) == 0) ++nt;       // a tail: same rows as the run
-                }
-                pf_next = touch4(peek_mask(nt));
-            }
             int ri = i, rli = li, rslot = slot, rw1 = w1, rfl = 7;
             bool tail = false;
             for (;;) {          // (chained runs)
             tail = false; rfl = 7;
             while (true) {
-                const int g_i = __builtin_amdgcn_readfirstlane(sct[rli * 6 + GAP]);
+                const int g_i = gcost;
                 const int g0 = a.semi ? 0 : g_i;
-                load_steps(rli);
+                int s[H], MU[H], ML[H];
+                unsigned lmask;
+                int src;
+                load_steps(rli, s);
                 unsigned umask;
                 RowOps16<C>::alpha(rr[0], s, g_i, g0, lane, MU, ML, umask, lmask, src);
-                if (rnm > 1) RowOps16<C>::select_steps(SEL, s, MU, g_i, g0, lane);
                 if (dirs) store_dirs(rslot, umask, lmask);
+                if (rnm > 1) {
+                    // (SEL is defined and used under ONE condition: with `if (rnm > 1) select_steps` beside member loops guarded
+                    // by `kk < rnm` the compiler carried its eight registers around the whole record loop)
+                    int SEL[H];
+                    RowOps16<C>::select_steps(SEL, s, MU, g_i, g0, lane);
 #pragma unroll
-                for (int kk = 1; kk < KRUN; ++kk)
-                    if (kk < rnm) RowOps16<C>::member(rr[kk], SEL, lane, MU, ML, lmask, src);
+                    for (int kk = 1; kk < KRUN; ++kk)
+                        if (kk < rnm) RowOps16<C>::member(rr[kk], SEL, lane, MU, ML, lmask, src);
+                }
                 cells += (unsigned long long)__popcll(rgm);
                 done += (unsigned long long)rnm;
                 if (kRec && kColmax != 1 && tail) {
                     if (track) {
                         if (rfl & F_FIRST) row_open = false;
-                        if (!row_open) set_keys(bkey, rr[0], mk[0]); else fold_keys(bkey, rr[0], mk[0]);
-                        row_open = true;
+                        int key[C];
+                        if (row_open) { keys_ld(key); fold_keys(key, rr[0], mk[0]); } else set_keys(key, rr[0], mk[0]);
 #pragma unroll
-                        for (int kk = 1; kk < KRUN; ++kk) if (kk < rnm) fold_keys(bkey, rr[kk], mk[kk]);
+                        for (int kk = 1; kk < KRUN; ++kk) if (kk < rnm) fold_keys(key, rr[kk], mk[kk]);
+                        row_open = true;
+                        // the tail's row: its epilogue when this was its last group
+                        if (rfl & F_LAST) { row_end(ri, ((rw1 >> 20) & 511) - 1, key); row_open = false; }
+                        else keys_st(key);
                     }
                 } else if (track && kRec && kColmax != 1) {
                     // LAZY KEYS (rows in registers): the best VALUE per column is a packed maximum over the members (8
@@ -1135,10 +1134,11 @@ __global__ __launch_bounds__(64, C > 16 ? 2 : (kColmax != 0 ? RG_SWEEP16_FWD_WAV
                         row_end(ri, knm_row, tkey, true, lhit);
                     }
                 } else if (track) {
-                    set_keys(bkey, rr[0], mk[0]);
+                    int key[C];
+                    set_keys(key, rr[0], mk[0]);
 #pragma unroll
-                    for (int kk = 1; kk < KRUN; ++kk) if (kk < rnm) fold_keys(bkey, rr[kk], mk[kk]);
-                    row_end(ri, ((rw1 >> 20) & 511) - 1, bkey);
+                    for (int kk = 1; kk < KRUN; ++kk) if (kk < rnm) fold_keys(key, rr[kk], mk[kk]);
+                    row_end(ri, ((rw1 >> 20) & 511) - 1, key);
                 }
                 if (semi_end) {
 #pragma unroll
@@ -1161,11 +1161,9 @@ __global__ __launch_bounds__(64, C > 16 ? 2 : (kColmax != 0 ? RG_SWEEP16_FWD_WAV
                 tail = to_tail; rfl = nf;
             }
             // ---- the run (and its tail) is over: rows in rr, t = the next record
-            // the tail's row: its epilogue when this was its last group
             if (tail) {
                 if (semi_end && (rfl & F_LAST)) end_row_done(ri);
-                if (track && (rfl & F_LAST) && row_open) row_end(ri, ((rw1 >> 20) & 511) - 1, bkey);
-                if (rfl & F_LAST) row_open = false;
+                if (rfl & F_LAST) row_open = false;       // (untracked sweeps: nothing folded, nothing to close)
             }
             bool chain = false;
             unsigned long long gm2 = 0;
@@ -1207,10 +1205,9 @@ __global__ __launch_bounds__(64, C > 16 ? 2 : (kColmax != 0 ? RG_SWEEP16_FWD_WAV
                 ri = nw0 & 0xfffff; rli = (nw0 >> 20) & 7; rslot = nw1 & 0xfffff; rw1 = nw1;
             }
             }                   // (chained runs)
-            pf_sink ^= pf_next;
 #ifdef RG_SWEEP16_KRUNNOST
 #pragma unroll
-            for (int kk = 0; kk < KRUN; ++kk) if (kk < rnm) { for (int r = 0; r < H; ++r) pf_sink ^= rr[kk][r]; }      // (timing-only: no run-end stores)
+            for (int kk = 0; kk < KRUN; ++kk) if (kk < rnm) { int sink = 0; for (int r = 0; r < H; ++r) sink ^= rr[kk][r]; asm volatile("" :: "v"(sink)); }      // (timing-only: no run-end stores)
 #else
 #pragma unroll
             for (int kk = 0; kk < KRUN; ++kk)
@@ -1218,9 +1215,17 @@ __global__ __launch_bounds__(64, C > 16 ? 2 : (kColmax != 0 ? RG_SWEEP16_FWD_WAV
 #endif
             continue;           // (a tail's epilogue ran above)
         } else {
-        const int g_i = __builtin_amdgcn_readfirstlane(sct[li * 6 + GAP]);
+        const int g_i = gcost;
         const int g0 = a.semi ? 0 : g_i;
-        load_steps(li);          // (every record: register / gather runs of other rows may lie between the groups of one row)
+        int s[H];
+        load_steps(li, s);       // (every record: register / gather runs of other rows may lie between the groups of one row)
+        int MUl[kWide ? 1 : H], MLl[kWide ? 1 : H];
+        unsigned lmaskl = 0;
+        int srcl = 0;
+        int (&MU)[H] = *reinterpret_cast<int (*)[H]>(kWide ? MUw : MUl);
+        int (&ML)[H] = *reinterpret_cast<int (*)[H]>(kWide ? MLw : MLl);
+        unsigned& lmask = kWide ? lmaskw : lmaskl;
+        int& src = kWide ? srcw : srcl;
         {
             unsigned long long rest = cont ? gm : gm & ~(1ull << (ga - kbase));
             cells += (unsigned long long)nm;
@@ -1236,26 +1241,35 @@ __global__ __launch_bounds__(64, C > 16 ? 2 : (kColmax != 0 ? RG_SWEEP16_FWD_WAV
                 rest &= rest - 1;
                 RG_ROW_LD(knext, nxt);
             }
+            int key[C];           // (untracked sweeps never touch it)
+            bool have = false;            // key[] holds the keys of the row's earlier records
+            if (track) {
+                if (flags & F_FIRST) row_open = false;
+                have = row_open;
+                if (have) keys_ld(key);
+            }
             if (!cont) {
                 int rowa[H];
+#if defined(RG_SWEEP16_NOROWS) || defined(RG_SWEEP16_NOROWS32)
 #pragma unroll
                 for (int r = 0; r < H; ++r) rowa[r] = s[r];
+#endif
                 RG_ROW_LD(ga, rowa);
                 unsigned umask;
                 RowOps16<C>::alpha(rowa, s, g_i, g0, lane, MU, ML, umask, lmask, src);
-                if (nme > 1) RowOps16<C>::select_steps(SEL, s, MU, g_i, g0, lane);
                 RG_ROW_ST(ga, rowa);
                 if (track) {
-                    if (flags & F_FIRST) row_open = false;
-                    if (!row_open) set_keys(bkey, rowa, ga); else fold_keys(bkey, rowa, ga);
-                    row_open = true;
+                    if (!have) set_keys(key, rowa, ga); else fold_keys(key, rowa, ga);
+                    have = true;
                 }
                 if (semi_end) end_fold(ga, i, rowa);
                 if (dirs) store_dirs(slot, umask, lmask);
-            } else {
-                // members of another page of the group the previous entry started: MU / ML / lmask / src are its alpha's
-                RowOps16<C>::select_steps(SEL, s, MU, g_i, g0, lane);
             }
+            // (a continuation entry — members of another page of the group the previous entry started — takes MU / ML / lmask /
+            // src from that entry's alpha.  SEL is built unconditionally: eight instructions on a rare path, and no array that
+            // the compiler has to carry around the record loop because it cannot see that definition and use go together)
+            int SEL[H];
+            RowOps16<C>::select_steps(SEL, s, MU, g_i, g0, lane);
             while (knext >= 0) {
                 const int k = knext;
                 int cur[H];
@@ -1268,17 +1282,21 @@ __global__ __launch_bounds__(64, C > 16 ? 2 : (kColmax != 0 ? RG_SWEEP16_FWD_WAV
                 } else knext = -1;
                 RowOps16<C>::member(cur, SEL, lane, MU, ML, lmask, src);
                 RG_ROW_ST(k, cur);
-                if (track) fold_keys(bkey, cur, k);
+                if (track) fold_keys(key, cur, k);
                 if (semi_end) end_fold(k, i, cur);
+            }
+            if (track) {
+                // (a continuation entry always follows its group's first entry: have is true by then)
+                row_open = true;
+                if (e_flags & F_LAST) row_end(e_i, ((e_w1 >> 20) & 511) - 1, key);
+                else keys_st(key);
             }
         }
         }
         if (semi_end && (e_flags & F_LAST)) end_row_done(e_i);
-        if (track && (e_flags & F_LAST) && row_open) row_end(e_i, ((e_w1 >> 20) & 511) - 1, bkey);
         if (e_flags & F_LAST) row_open = false;       // (so that a skipped FIRST record of a later row has nothing to reset)
         if (e_adv) ++t;
     }
-    if (RG_SWEEP16_PF > 0 && !kWide) asm volatile("" :: "v"(pf_sink));
 
     // ---- outputs ----
     if (kColmax == 1 && a.colmax_out) {
@@ -1488,7 +1506,7 @@ __global__ __launch_bounds__(64) void k_layer16(LayerArgs a) {
     int* sprof = s2 + 5 * 64;            // [5][64][H]: the lane's packed diagonal steps per row base (see k_sweep16)
     if (lane < 36) sct[lane] = a.sc.t[lane];
     __syncthreads();
-    const int gcost = sct[GAP];
+    const int gcost = __builtin_amdgcn_readfirstlane(sct[GAP]);      // (= score(b, '-') of every row base b: see k_sweep16)
     for (int e = lane; e < 5 * 64; e += WAVE) {
         const int li = e >> 6, cl = e & 7, ch = (e >> 3) & 7;
         s2[e] = (cl < 6 && ch < 6) ? pack16(sct[li * 6 + cl] - gcost, sct[li * 6 + ch] - gcost) : 0;
@@ -1538,7 +1556,7 @@ __global__ __launch_bounds__(64) void k_layer16(LayerArgs a) {
 #pragma unroll
         for (int k = 0; k + 1 < PF; ++k) { pf_li[k] = pf_li[k + 1]; pf_row[k] = pf_row[k + 1]; pf_w0[k] = pf_w0[k + 1]; pf_w1[k] = pf_w1[k + 1]; }
         prefetch(t + PF, pf_li[PF - 1], pf_row[PF - 1], pf_w0[PF - 1], pf_w1[PF - 1]);
-        const int g_i = __builtin_amdgcn_readfirstlane(sct[li * 6 + GAP]);
+        const int g_i = gcost;
         const int g0 = a.semi ? 0 : g_i;
         const int GI = pack16(g_i, g_i);
         const int GI0 = lane == 0 ? pack16(g0, g_i) : GI;

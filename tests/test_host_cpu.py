@@ -331,6 +331,17 @@ def test_step_tables_of_the_pathwise_sweeps():
                 if len(rs) > 1:              # first / last bits in the NEW order, exactly once each
                     assert sum(1 for r in rs if r["flags"] & 1) == 1 and rs[0]["flags"] & 1
                     assert sum(1 for r in rs if r["flags"] & 2) == 1 and rs[-1]["flags"] & 2
+            # between the first and the last record of a row with several groups lie only REGISTER runs (<= 4 paths) and their
+            # tails: the row's keys wait in the LDS words of the gather table meanwhile (k_sweep16: keys_ld / keys_st)
+            pos_of = {}
+            for t, r in enumerate(fs):
+                pos_of.setdefault(r["row"], []).append(t)
+            for i, ps in pos_of.items():
+                if len(ps) > 1:
+                    for t in range(ps[0], ps[-1] + 1):
+                        r = fs[t]
+                        if r["row"] != i:
+                            assert r["flags"] & 4 and bin(r["mask"]).count("1") <= 4 and not r["cont"], (i, t, r)
             if sg is graphs[1]:
                 assert ntails > 20           # the block-built graphs are what the split tables were made for
             # ---- retirement tables: the definition, with the kernel's alpha rule ----
