@@ -45,7 +45,7 @@ struct PathWorkImpl {
     bool tables = false;
     Buf<int> fpoff, fprow, fpslot, rpoff, rprow, rpslot;
     Buf<ReadState> state;
-    Buf<int> roll, mf, mfc, wr, mfarg, wrarg, thr, flayer, rlayer;
+    Buf<int> roll, mf, wr, mfarg, wrarg, thr, flayer, rlayer;
     Buf<uint32_t> fdirs, rdirs;
     Buf<Cand> fcand, rcand;
     Buf<unsigned> nf, nr, ridx, nrec, nrrec;
@@ -337,7 +337,7 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
             if ((rc = w.roll.alloc((size_t)chunk * (P + 2) * wpad))) return rc;
             if (mode == RG_MODE_RECOMBINATION) {
                 if ((rc = w.rdirs.alloc((size_t)chunk * rdirs_stride)) || (rc = w.rlayer.alloc((size_t)chunk * layer_stride)) ||
-                    (rc = w.mf.alloc((size_t)chunk * wpad)) || (rc = w.mfc.alloc((size_t)chunk * wpad)) || (rc = w.wr.alloc((size_t)chunk * wpad)) ||
+                    (rc = w.mf.alloc((size_t)chunk * wpad)) || (rc = w.wr.alloc((size_t)chunk * wpad)) ||
                     (rc = w.mfarg.alloc((size_t)chunk * wpad)) || (rc = w.wrarg.alloc((size_t)chunk * wpad)) ||
                     (rc = w.thr.alloc((size_t)chunk * wpad)) || (rc = w.fcand.alloc((size_t)chunk * w.fcap)) ||
                     (rc = w.rcand.alloc((size_t)chunk * w.rcap)) || (rc = w.ridx.alloc((size_t)chunk * w.rcap)) ||
@@ -416,14 +416,23 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
                 f.oob = spec ? 1 : 0;        // tight thresholds: most rows emit nothing (row_end tests the lane maximum first)
                 f.colmax_out = w.mf.p; f.colarg_out = w.mfarg.p; f.cand = w.fcand.p; f.cand_cap = w.fcap; f.ncand_out = w.nf.p;
                 if (use_rec) {
-                    // records; exact column maxima as packed values only (k_sweep16<.., 2, ..>): the cell k_bound pairs per
-                    // column comes from the records (k_colmax_rec below)
+                    // records, and NO column maxima in the sweep (round 5: k_sweep16<.., 0, ..>, the reverse sweep's variant).  What
+                    // the reverse thresholds and k_expand need per column is the best forward cell that can be a CANDIDATE — a
+                    // usable cell at or above the forward emission threshold — and every such cell is in the records:
+                    // k_colmax_rec reads maxima and cells out of them right behind the sweep (columns without a record get
+                    // "no partner": no reverse emission there at all).  Round 4 tracked packed maxima of ALL cells in the sweep
+                    // (8 registers, 8 v_pk_max per row) for an upper bound of the same quantity.
                     f.cand = nullptr; f.cand_cap = 0; f.frec = w.frec.p; f.frec_cap = w.frec_cap; f.ncand_out = w.nrec.p;
-                    f.colarg_out = nullptr;
+                    f.colmax_out = nullptr; f.colarg_out = nullptr;
                 }
                 f.dirs = w.fdirs.p; f.dirs_stride = fdirs_stride; f.count_cells = 1;
                 if (opt.no_retire == 3) f.retire = 0;
                 TIMED(T, use16 ? "k_sweep16_fwd" : "k_sweep_fwd", sweep(f, chunk));
+                if (use_rec) {
+                    ExpandArgs fc{w.state.p, w.frec.p, w.frec_cap, w.nrec.p, nullptr, 0, nullptr, nullptr, wpad, p.base_rec_cost, gd.knm, 0, off,
+                                  p.rec_band_width, p.scores[5]};
+                    TIMED(T, "k_colmax_rec_fwd", launch_colmax_rec(fc, w.mf.p, w.mfarg.p, chunk, C, stream));
+                }
                 TIMED(T, "k_seed", launch_seed(se, stream));
             } else {
                 SweepArgs f1 = sa;
@@ -447,12 +456,8 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
                 ExpandArgs ec{w.state.p, w.rrec.p, w.rrec_cap, w.nrrec.p, nullptr, 0, nullptr, nullptr, wpad, p.base_rec_cost, gd.knm, 1, off,
                               p.rec_band_width, p.scores[5]};
                 TIMED(T, "k_colmax_rec", launch_colmax_rec(ec, w.wr.p, w.wrarg.p, chunk, C, stream));
-                // best recorded forward cell per column (value + cell) for k_bound: any real pair is a valid lower bound
-                ExpandArgs fc{w.state.p, w.frec.p, w.frec_cap, w.nrec.p, nullptr, 0, nullptr, nullptr, wpad, p.base_rec_cost, gd.knm, 0, off,
-                              p.rec_band_width, p.scores[5]};
-                TIMED(T, "k_colmax_rec_fwd", launch_colmax_rec(fc, w.mfc.p, w.mfarg.p, chunk, C, stream));
             }
-            BoundArgs ba{gd, w.state.p, off, use_rec ? w.mfc.p : w.mf.p, w.mfarg.p, w.wr.p, w.wrarg.p, wpad, p.base_rec_cost, p.multi_rec_cost,
+            BoundArgs ba{gd, w.state.p, off, w.mf.p, w.mfarg.p, w.wr.p, w.wrarg.p, wpad, p.base_rec_cost, p.multi_rec_cost,
                          p.rec_band_width};
             TIMED(T, "k_bound", launch_bound(ba, chunk, stream));
             if (!two_sweep) {

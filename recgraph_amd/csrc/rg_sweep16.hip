@@ -227,11 +227,14 @@ struct RowOps16 {
 // kRec = true: emissions leave as (row, lane) records (a.frec); false: as Cand entries (a.cand) or not at all
 // kWide = true: graphs with more than 64 paths (step entries carry a 64-path page and continuation entries exist); the
 // narrow variant compiles that logic out (page 0, no continuation: it costs registers the forward sweep does not have)
-template <int C, int kColmax, bool kRec, bool kWide>
+// kSemi = true: the semiglobal modes (-m 5 / -m 9: zero first column, per-path end rows).  A template flag since round 5: the
+// end-row bookkeeping (four per-lane registers of state, sixteen column-select masks in SGPRs) was carried — spilled — through
+// the record loop of every global-mode sweep
+template <int C, int kColmax, bool kRec, bool kWide, bool kSemi>
 __global__ __launch_bounds__(64, C > 16 ? 2 : (kColmax != 0 ? RG_SWEEP16_FWD_WAVES : RG_SWEEP16_REV_WAVES)) void k_sweep16(SweepArgs a) {
     constexpr int H = C / 2;
     constexpr bool kTrack = kColmax != 0 || kRec;      // <0, false>: the -m 4 / -m 5 sweep — no best member, no thresholds, no emission
-    constexpr bool kRet = kRec && kColmax != 1 && !kWide && C <= 16;   // PATH RETIREMENT (record pipelines of -m 8, P <= 64): see retire_eval
+    constexpr bool kRet = kRec && kColmax != 1 && !kWide && C <= 16 && !kSemi;   // PATH RETIREMENT (record pipelines of -m 8, P <= 64): see retire_eval
     constexpr int KRUN = C <= 16 ? (kColmax != 0 ? RG_SWEEP16_KRUN : RG_SWEEP16_KRUN_REV) : 0;   // rows kept in registers across the inner rows of a segment
     const int rd = a.order ? a.order[blockIdx.x] : blockIdx.x;      // (launch order: see launch_order)
     const int lane = threadIdx.x;
@@ -404,7 +407,7 @@ __global__ __launch_bounds__(64, C > 16 ? 2 : (kColmax != 0 ? RG_SWEEP16_FWD_WAV
         //            hopeless  <=>  for all j: A[j] + mmx j < min_{j' <= j} (thr[j'] + mmx j')
         // Both are "max over the row of (z + constant per column) < 0" on the packed z-space rows: pseudo-row PR_RVL holds the
         // constants (saturating 16-bit; a constant that would have to be ROUNDED DOWN to fit switches the retirement off for the read).
-        if (kRet && a.retire && !a.semi) {
+        if (kRet && a.retire && !kSemi) {
             const int mmx = max(a.maxmatch, 0);
             int tv[C];
             bool ovf = false;
@@ -471,6 +474,33 @@ __global__ __launch_bounds__(64, C > 16 ? 2 : (kColmax != 0 ? RG_SWEEP16_FWD_WAV
     // (direction words of this read: at most 2^20 slots of 64 or 128 words)
     const __amdgpu_buffer_rsrc_t dirs_rsrc = uniform_rsrc(dirs, dirs ? (unsigned)min(a.dirs_stride * 4ll, 0x7fffffffll) : 0u);
 
+    // A record slot for (row i, this lane) when the lane has a column at its threshold: the position in the read's list (one
+    // ballot), the header, and where the lane's C keys go.  The callers whose keys are built on demand (rows in registers) write
+    // them in two halves — columns 0..H-1, then H..C-1 — so that only H key registers are live at a time.
+    auto rec_slot = [&](int i, bool lane_hit, bool& mine) -> int4* {
+        const unsigned long long has = __ballot(lane_hit);
+        mine = false;
+        int4* rp = nullptr;
+        if (has) {
+            const unsigned before = __builtin_amdgcn_mbcnt_hi((unsigned)(has >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)has, 0u));
+            const unsigned pos = ncand + before;
+            mine = ((has >> lane) & 1ull) && pos < a.frec_cap;
+            rp = reinterpret_cast<int4*>(reinterpret_cast<char*>(a.frec + (long long)rd * a.frec_cap * (4 + C)) + pos * (unsigned)((4 + C) * sizeof(int)));
+            if (mine) rp[0] = make_int4((i << 6) | lane, 0, 0, 0);
+            ncand += (unsigned)__popcll(has);
+        }
+        return rp;
+    };
+    auto rec_half = [&](int4* rp, bool mine, int half, const int (&k)[H]) {      // keys of columns half * H .. half * H + H - 1
+        if (!mine) return;
+        if constexpr (H >= 4) {
+#pragma unroll
+            for (int q4 = 0; q4 < H / 4; ++q4) rp[1 + half * (H / 4) + q4] = make_int4(k[4 * q4], k[4 * q4 + 1], k[4 * q4 + 2], k[4 * q4 + 3]);
+        } else {
+            reinterpret_cast<int2*>(rp + 1)[half] = make_int2(k[0], k[1]);
+        }
+    };
+
     // Per-row epilogue on the packed keys bkey = value << 16 | path (non-members of the reference's matrices hold 0,
     // so a cell is usable iff its winner is a member: value > 0, or value == 0 and path > knm, or no non-member
     // exists -> bkey > kthr with kthr = knm (>= 0) or INT32_MIN).  ckey keeps the best usable key per column and the
@@ -517,17 +547,13 @@ __global__ __launch_bounds__(64, C > 16 ? 2 : (kColmax != 0 ? RG_SWEEP16_FWD_WAV
                 }
                 lane_hit = ((unsigned)acc & 0x80008000u) != 0x80008000u;
             }
-            const unsigned long long has = __ballot(lane_hit);
-            if (has) {
-                const unsigned before = __builtin_amdgcn_mbcnt_hi((unsigned)(has >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)has, 0u));
-                const unsigned pos = ncand + before;
-                if (((has >> lane) & 1ull) && pos < a.frec_cap) {
-                    int4* rp = reinterpret_cast<int4*>(reinterpret_cast<char*>(a.frec + (long long)rd * a.frec_cap * (4 + C)) + pos * (unsigned)((4 + C) * sizeof(int)));
-                    rp[0] = make_int4((i << 6) | lane, 0, 0, 0);
+            bool mine;
+            int4* rp = rec_slot(i, lane_hit, mine);
+            if (mine) {
+                if constexpr (C >= 4) {
 #pragma unroll
                     for (int q4 = 0; q4 < C / 4; ++q4) rp[1 + q4] = make_int4(bkey[4 * q4], bkey[4 * q4 + 1], bkey[4 * q4 + 2], bkey[4 * q4 + 3]);
                 }
-                ncand += (unsigned)__popcll(has);
             }
             return;
         }
@@ -637,7 +663,7 @@ __global__ __launch_bounds__(64, C > 16 ? 2 : (kColmax != 0 ? RG_SWEEP16_FWD_WAV
     };
 
     // semiglobal end-row selection (see k_sweep)
-    const bool semi_end = a.semi && !rev;
+    const bool semi_end = kSemi && !rev;
     const int ln_end = n / C, ql_end = n % C;
     if (semi_end) for (int k = lane; k < EP; k += WAVE) { endv[k] = INT32_MIN; endr[k] = 0; }
     __syncthreads();
@@ -910,7 +936,7 @@ __global__ __launch_bounds__(64, C > 16 ? 2 : (kColmax != 0 ? RG_SWEEP16_FWD_WAV
             int ri = i, rli = li, rslot = slot, rw1 = w1;
             for (int step = 0;; ++step) {
                 const int g_i = gcost;
-                const int g0 = a.semi ? 0 : g_i;
+                const int g0 = kSemi ? 0 : g_i;
                 int s[H], MU[H], ML[H];
                 unsigned lmask;
                 int src;
@@ -950,13 +976,15 @@ __global__ __launch_bounds__(64, C > 16 ? 2 : (kColmax != 0 ? RG_SWEEP16_FWD_WAV
                     }
                     const bool lhit = ((unsigned)acc & 0x80008000u) != 0x80008000u;
                     if (__any(lhit)) {
-                        int tkey[C];         // (not bkey: see TAIL)
+                        bool mine;
+                        int4* rp = rec_slot(ri, lhit, mine);
+                        int hk[H];
 #pragma unroll
-                        for (int r = 0; r < H; ++r) {
-                            tkey[r] = (int)(((unsigned)bv[r] << 16) | ((unsigned)K2[r] & 0xffffu));
-                            tkey[r + H] = (int)(((unsigned)bv[r] & 0xffff0000u) | ((unsigned)K2[r] >> 16));
-                        }
-                        row_end(ri, knm_row, tkey, true, lhit);
+                        for (int r = 0; r < H; ++r) hk[r] = (int)(((unsigned)bv[r] << 16) | ((unsigned)K2[r] & 0xffffu));
+                        rec_half(rp, mine, 0, hk);
+#pragma unroll
+                        for (int r = 0; r < H; ++r) hk[r] = (int)(((unsigned)bv[r] & 0xffff0000u) | ((unsigned)K2[r] >> 16));
+                        rec_half(rp, mine, 1, hk);
                     }
                 }
 #endif
@@ -1067,7 +1095,7 @@ __global__ __launch_bounds__(64, C > 16 ? 2 : (kColmax != 0 ? RG_SWEEP16_FWD_WAV
             tail = false; rfl = 7;
             while (true) {
                 const int g_i = gcost;
-                const int g0 = a.semi ? 0 : g_i;
+                const int g0 = kSemi ? 0 : g_i;
                 int s[H], MU[H], ML[H];
                 unsigned lmask;
                 int src;
@@ -1127,11 +1155,27 @@ __global__ __launch_bounds__(64, C > 16 ? 2 : (kColmax != 0 ? RG_SWEEP16_FWD_WAV
                     }
                     const bool lhit = ((unsigned)acc & 0x80008000u) != 0x80008000u;
                     if (__any(lhit)) {      // some half >= its threshold
-                        int tkey[C];         // (not bkey: a row with several groups may be in progress around this run, see TAIL)
-                        set_keys(tkey, rr[0], mk[0]);
+                        // the (value, path) keys of the row, built only now and half a lane at a time (columns 0..H-1 from the low
+                        // halves of the members' words, then H..C-1 from the high halves): H key registers live, not C
+                        bool mine;
+                        int4* rp = rec_slot(ri, lhit, mine);
 #pragma unroll
-                        for (int kk = 1; kk < KRUN; ++kk) if (kk < rnm) fold_keys(tkey, rr[kk], mk[kk]);
-                        row_end(ri, knm_row, tkey, true, lhit);
+                        for (int half = 0; half < 2; ++half) {
+                            int hk[H];
+#pragma unroll
+                            for (int kk = 0; kk < KRUN; ++kk)
+                                if (kk < rnm) {
+                                    int kv = mk[kk];
+                                    asm volatile("" : "+v"(kv));      // (the path id through a VGPR: see set_keys)
+#pragma unroll
+                                    for (int r = 0; r < H; ++r) {
+                                        const int key = half == 0 ? (int)(((unsigned)rr[kk][r] << 16) | (unsigned)kv)
+                                                                  : (int)(((unsigned)rr[kk][r] & 0xffff0000u) | (unsigned)kv);
+                                        hk[r] = kk == 0 ? key : max(hk[r], key);
+                                    }
+                                }
+                            rec_half(rp, mine, half, hk);
+                        }
                     }
                 } else if (track) {
                     int key[C];
@@ -1216,7 +1260,7 @@ __global__ __launch_bounds__(64, C > 16 ? 2 : (kColmax != 0 ? RG_SWEEP16_FWD_WAV
             continue;           // (a tail's epilogue ran above)
         } else {
         const int g_i = gcost;
-        const int g0 = a.semi ? 0 : g_i;
+        const int g0 = kSemi ? 0 : g_i;
         int s[H];
         load_steps(li, s);       // (every record: register / gather runs of other rows may lie between the groups of one row)
         int MUl[kWide ? 1 : H], MLl[kWide ? 1 : H];
@@ -1324,7 +1368,7 @@ __global__ __launch_bounds__(64, C > 16 ? 2 : (kColmax != 0 ? RG_SWEEP16_FWD_WAV
     }
     if (a.ncand_out && lane == 0) a.ncand_out[rd] = ncand;
     __syncthreads();
-    if (!rev && !a.semi) {
+    if (!rev && !kSemi) {
         const int ql = n % C, ln = n / C;
         for (int k = lane; k < P; k += WAVE) {
             const int pv = rows[(long long)k * wrow + ln * H + (ql % H)];
@@ -1646,15 +1690,20 @@ void launch_layer16(const LayerArgs& a, int nreads, int C, hipStream_t s) {
     }
 }
 
-template <int kColmax, bool kRec, bool kWide>
-static void launch_sweep16_w(const SweepArgs& a, int nreads, int C, hipStream_t s) {
+template <int kColmax, bool kRec, bool kWide, bool kSemi>
+static void launch_sweep16_s(const SweepArgs& a, int nreads, int C, hipStream_t s) {
     const size_t bytes = (size_t)(64 + 2 * (kWide ? RG_MAXP : 64) + std::max(C * WAVE, 5 * 64) + 4 * WAVE * (C / 2)) * sizeof(int) + (size_t)options().lds_pad;
     switch (C) {
-        case 4: hipLaunchKernelGGL((k_sweep16<4, kColmax, kRec, kWide>), dim3(nreads), dim3(64), bytes, s, a); break;
-        case 8: hipLaunchKernelGGL((k_sweep16<8, kColmax, kRec, kWide>), dim3(nreads), dim3(64), bytes, s, a); break;
-        case 16: hipLaunchKernelGGL((k_sweep16<16, kColmax, kRec, kWide>), dim3(nreads), dim3(64), bytes, s, a); break;
-        default: hipLaunchKernelGGL((k_sweep16<32, kColmax, kRec, kWide>), dim3(nreads), dim3(64), bytes, s, a); break;
+        case 4: hipLaunchKernelGGL((k_sweep16<4, kColmax, kRec, kWide, kSemi>), dim3(nreads), dim3(64), bytes, s, a); break;
+        case 8: hipLaunchKernelGGL((k_sweep16<8, kColmax, kRec, kWide, kSemi>), dim3(nreads), dim3(64), bytes, s, a); break;
+        case 16: hipLaunchKernelGGL((k_sweep16<16, kColmax, kRec, kWide, kSemi>), dim3(nreads), dim3(64), bytes, s, a); break;
+        default: hipLaunchKernelGGL((k_sweep16<32, kColmax, kRec, kWide, kSemi>), dim3(nreads), dim3(64), bytes, s, a); break;
     }
+}
+template <int kColmax, bool kRec, bool kWide>
+static void launch_sweep16_w(const SweepArgs& a, int nreads, int C, hipStream_t s) {
+    if (a.semi) launch_sweep16_s<kColmax, kRec, kWide, true>(a, nreads, C, s);
+    else launch_sweep16_s<kColmax, kRec, kWide, false>(a, nreads, C, s);
 }
 template <int kColmax, bool kRec>
 static void launch_sweep16_c(const SweepArgs& a, int nreads, int C, hipStream_t s) {

@@ -10,16 +10,18 @@ def test_headline_sweep_variants_use_no_scratch():
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import kernel_resources
     ks = {k["name"]: k for k in kernel_resources.report("rg_sweep16.hip")}
-    headline = ["rg::k_sweep16<16, 2, true, false>",     # -m 8 forward: records + packed column maxima
-                "rg::k_sweep16<16, 0, true, false>",     # -m 8 reverse: records
-                "rg::k_sweep16<16, 0, false, false>"]    # -m 4 / -m 5: no tracking at all
+    # (template arguments: C, kColmax, kRec, kWide, kSemi)
+    headline = ["rg::k_sweep16<16, 0, true, false, false>",     # -m 8, both sweeps since round 5: records, no column maxima in the sweep
+                "rg::k_sweep16<16, 0, false, false, false>"]    # -m 4: no tracking at all
     for name in headline:
         k = ks[name]
         assert k["ScratchSize [bytes/lane]"] == 0 and k["VGPRs Spill"] == 0, (name, k)
         assert k["VGPRs"] <= 256 and k["Occupancy [waves/SIMD]"] >= 2, (name, k)
-    # the narrower instantiations of the same variants (shorter reads) do not spill either
+    # the -m 4 sweep fits three waves per SIMD (168 registers, 13 KB of LDS per wave)
+    assert ks["rg::k_sweep16<16, 0, false, false, false>"]["Occupancy [waves/SIMD]"] >= 3
+    # the narrower instantiations of the same variants (shorter reads) and their semiglobal forms do not spill either
     for c in (4, 8):
-        for v in ("2, true, false", "0, true, false", "0, false, false"):
+        for v in ("0, true, false, false", "0, false, false, false", "0, true, false, true", "0, false, false, true"):
             k = ks["rg::k_sweep16<%d, %s>" % (c, v)]
             assert k["ScratchSize [bytes/lane]"] == 0, (c, v, k)
 
