@@ -258,8 +258,9 @@ def haplotype_reads(graph, n_reads, length=1000, seed=5678, mosaic_frac=0.0):
     return reads
 
 
-def substring_reads(graph, n_reads, length, seed=5678):
-    """Substrings of a random source->sink walk at a uniform offset (configs 2/3)."""
+def substring_reads(graph, n_reads, length, seed=5678, anchored=False):
+    """Substrings of a random source->sink walk at a uniform offset (configs 2/3); ``anchored``: at offset 0, i.e. reads
+    that start at the graph's source (what a global alignment of a short read can actually place)."""
     rng = np.random.default_rng(seed)
     # stage alternatives recovered from the paths: walk = per stage a random alternative
     stages = list(zip(*graph.paths))
@@ -269,7 +270,7 @@ def substring_reads(graph, n_reads, length, seed=5678):
         walk = "".join(graph.seq_of[a[int(rng.integers(0, len(a)))]] for a in stage_alts)
         codes = _CODE[np.frombuffer(walk.encode(), dtype=np.uint8)]
         if len(codes) > length:
-            o = int(rng.integers(0, len(codes) - length + 1))
+            o = 0 if anchored else int(rng.integers(0, len(codes) - length + 1))
             codes = codes[o:o + length + 8]
         codes = _apply_errors(rng, codes)
         if len(codes) >= length:
