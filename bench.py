@@ -732,12 +732,18 @@ def main():
     # formatter on a real alignment.  `anchored`: the same shape with every read starting at the graph's source.
     anchored = None
     if mode in (0, 2) and not dist_on and not stub and not args.no_strong:
-        a_tiles = [pack(synth.substring_reads(sg, batch, cfg["n"], seed=777 + num + 31 * k, anchored=True)) for k in range(3)]
-        run_steps(main_stream, a_tiles[:1])
-        ares = timed_region(a_tiles, len(a_tiles))
-        anchored = {"reads": ares["reads_all"], "reads_per_s": round(ares["reads_all"] / ares["dt"], 1), "ms_per_tile": round(ares["dt"] / len(a_tiles) * 1e3, 3),
-                    "band_not_enough_fraction": round(ares["band_not_enough"] / max(1, ares["reads_all"]), 4),
-                    "note": "reads that start at the source of the graph: the walker and the GAF formatter run on real alignments"}
+        def region(make, nt=3):
+            tiles = [pack(make(k)) for k in range(nt)]
+            run_steps(main_stream, tiles[:1])
+            res = timed_region(tiles, len(tiles))
+            return {"reads": res["reads_all"], "reads_per_s": round(res["reads_all"] / res["dt"], 1), "ms_per_tile": round(res["dt"] / len(tiles) * 1e3, 3),
+                    "band_not_enough_fraction": round(res["band_not_enough"] / max(1, res["reads_all"]), 4)}
+        anchored = {"source_anchored": region(lambda k: synth.substring_reads(sg, batch, cfg["n"], seed=777 + num + 31 * k, anchored=True)),
+                    # whole source->sink walks (reads as long as the graph: ~%d bases): what a global alignment places inside the
+                    # configuration's band, so the walker and the GAF formatter run on real alignments
+                    "full_walks": region(lambda k: synth.full_walk_reads(sg, max(256, batch // 8), seed=991 + num + 31 * k)),
+                    "note": "same stream, same parameters; `source_anchored`: reads of the configuration's length that start at the graph's "
+                            "source; `full_walks`: whole source->sink walks"}
     if dist_on:
         # the ranks part here: rank 0's probe steps and CPU legs do not hold the other GPUs
         dist.barrier()

@@ -369,11 +369,8 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
         sa.semi = semi ? 1 : 0;
         sa.nwv = nwv;
         {
-            // gather runs of k_sweep16: z of a member lies in [-(rows + c) * maxabs, 2 c * maxabs]: the difference of two
-            // members at one cell is at most (rows + 3 c) * maxabs, which must fit a signed 16-bit half
-            long long maxabs = 0;
-            for (int i = 0; i < 35; ++i) if (p.scores[i] != RG_SCORE_MISSING) maxabs = std::max<long long>(maxabs, std::llabs((long long)p.scores[i]));
-            sa.gather_ok = use16 && !opt.no_gather && (long long)(h.max_path_rows + 3 * (max_n + 2)) * maxabs <= 32700 ? 1 : 0;
+            // (gather runs carry differences of two members' stored values: sweep16_admissible bounds every such difference)
+            sa.gather_ok = use16 && !opt.no_gather ? 1 : 0;
             // split tables: only where every run between the groups of a row is a register or a gather run of k_sweep16
             sa.fsplit = w.fsplit.p; sa.rsplit = w.rsplit.p;
             sa.use_split = w.have_split && sa.gather_ok && !semi && C <= 16 && !opt.no_split ? 1 : 0;

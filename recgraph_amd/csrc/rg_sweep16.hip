@@ -86,8 +86,9 @@ struct RowOps16 {
     // bit r = column r of the lane (low half), bit 16 + r = column H + r (high half)
     static constexpr unsigned FULL = H >= 16 ? 0xffffffffu : ((((1u << H) - 1u) << 16) | ((1u << H) - 1u));
 
+    // need_src (wave-uniform): the group has members besides its alpha (`src` is theirs alone)
     static __device__ __forceinline__ void alpha(int (&row)[H], const int (&s)[H], int g_i, int g0, int lane,
-                                                 int (&MU)[H], int (&ML)[H], unsigned& umask, unsigned& lmask, int& src) {
+                                                 int (&MU)[H], int (&ML)[H], unsigned& umask, unsigned& lmask, int& src, bool need_src = true) {
         const int GI = pack16(g_i, g_i);
         const int GI0 = lane == 0 ? pack16(g0, g_i) : GI;          // border column 0 adds g0
         int prev = __builtin_amdgcn_alignbit(row[H - 1], dpp_shr1(row[H - 1], NEGPAIR), 16);
@@ -124,8 +125,11 @@ struct RowOps16 {
             vprev = v;
         }
         // nearest lane to the left that owns a non-L column: highest set bit of the ballot below this lane (0 if none)
-        const unsigned long long have = __ballot((lm & FULL) != FULL) & ((1ull << lane) - 1ull);
-        src = have ? 63 - __clzll((long long)have) : 0;
+        src = 0;
+        if (need_src) {
+            const unsigned long long have = __ballot((lm & FULL) != FULL) & ((1ull << lane) - 1ull);
+            src = have ? 63 - __clzll((long long)have) : 0;
+        }
         umask = um; lmask = lm;
     }
 
@@ -182,6 +186,20 @@ struct RowOps16 {
 #define RG_SWEEP16_GATHER_FWD 1      // the forward record variant spills 121 registers with them compiled in and still gains 3 ms (47.7 -> 44.7)
 #endif
 
+// when a gather run pays (instructions): member by member a row costs PER_MEMBER_ROW per member; a gather run PER_ROW per
+// row (alpha + column map + best member per column) and PER_MEMBER_RUN per member once (a pass at each end of the run)
+#ifndef RG_GATHER_PER_MEMBER_ROW
+#define RG_GATHER_PER_MEMBER_ROW 84
+#endif
+#ifndef RG_GATHER_PER_ROW
+#define RG_GATHER_PER_ROW 160
+#endif
+#ifndef RG_GATHER_PER_MEMBER_RUN
+#define RG_GATHER_PER_MEMBER_RUN 90
+#endif
+#ifndef RG_SWEEP16_GATHER32
+#define RG_SWEEP16_GATHER32 0        // gather runs in the record variants at 32 columns per lane (see kGather)
+#endif
 #ifndef RG_SWEEP16_RUNWAIT
 #define RG_SWEEP16_RUNWAIT 1
 #endif
@@ -234,8 +252,12 @@ template <int C, int kColmax, bool kRec, bool kWide, bool kSemi>
 __global__ __launch_bounds__(64, C > 16 ? 2 : (kColmax != 0 ? RG_SWEEP16_FWD_WAVES : RG_SWEEP16_REV_WAVES)) void k_sweep16(SweepArgs a) {
     constexpr int H = C / 2;
     constexpr bool kTrack = kColmax != 0 || kRec;      // <0, false>: the -m 4 / -m 5 sweep — no best member, no thresholds, no emission
-    constexpr bool kRet = kRec && kColmax != 1 && !kWide && C <= 16 && !kSemi;   // PATH RETIREMENT (record pipelines of -m 8, P <= 64): see retire_eval
-    constexpr int KRUN = C <= 16 ? (kColmax != 0 ? RG_SWEEP16_KRUN : RG_SWEEP16_KRUN_REV) : 0;   // rows kept in registers across the inner rows of a segment
+    // gather runs: not at 32 columns per lane in the record variants (a row is 16 registers there: the run's A / G / masks / steps /
+    // values / paths alone are 112, and with retirement and register runs compiled in the variant spilled 78)
+    constexpr bool kGather = C <= 16 || !kRec || RG_SWEEP16_GATHER32;
+    constexpr bool kRet = kRec && kColmax != 1 && !kWide && !kSemi;   // PATH RETIREMENT (record pipelines of -m 8, P <= 64): see retire_eval
+    // rows kept in registers across the inner rows of a segment: groups of up to 4 paths (2 at 32 columns per lane: a row is 16 registers there)
+    constexpr int KRUN = C <= 16 ? (kColmax != 0 ? RG_SWEEP16_KRUN : RG_SWEEP16_KRUN_REV) : ((kRec && kColmax == 0 && !kWide) ? 2 : 0);
     const int rd = a.order ? a.order[blockIdx.x] : blockIdx.x;      // (launch order: see launch_order)
     const int lane = threadIdx.x;
     const PathGraphDev& g = a.g;
@@ -841,8 +863,10 @@ __global__ __launch_bounds__(64, C > 16 ? 2 : (kColmax != 0 ? RG_SWEEP16_FWD_WAV
         const int ga = kbase + ((flags & F_INNER) ? __builtin_ctzll(gmask | (1ull << 63)) : ((w0 >> 26) & 63));
         const int nm = __popcll(gmask);
         // (inner / head records: the alpha field holds the rows left in the run, this one included, capped at 63.)  A gather
-        // run costs ~180 instructions per member once per run (two passes) + ~160 per row, the member-by-member form ~77 per
-        // member and row: it pays when R * (77 (nm - 1) - 160) >= 200 (nm - 1)  (32 paths: 3 rows, 8 paths: 4, 5 paths: 6)
+        // run costs RG_GATHER_PER_MEMBER_RUN instructions per member once per run (two passes) + RG_GATHER_PER_ROW per row, the
+        // member-by-member form RG_GATHER_PER_MEMBER_ROW per member and row (row load + store, member operator, eager keys): it
+        // pays when R * (84 (nm - 1) - 160) >= 90 (nm - 1)  (16 or 32 paths: 2 rows, 8 paths: 2, 5 paths: 3; round 4 had
+        // 77 / 160 / 200: 3 / 4 / 6 rows.  Config 4's lone sweep 15.2 -> 14.8 ms, config 5 unchanged)
         const int run_left = (flags & F_INNER) ? ((w0 >> 26) & 63) : 0;
         const unsigned long long gm = kRet ? (gmask & needed) : gmask;     // the members still computed
         const int nme = kRet ? __popcll(gm) : nm;
@@ -863,8 +887,8 @@ __global__ __launch_bounds__(64, C > 16 ? 2 : (kColmax != 0 ? RG_SWEEP16_FWD_WAV
             ++t;
             continue;
         }
-        if (RG_SWEEP16_GATHER && (kRec ? (kColmax == 0 || (kColmax == 2 && RG_SWEEP16_GATHER_FWD)) : !track) && !kWide && a.gather_ok && !semi_end && (flags & F_INNER) && nm > KRUN &&
-            (!kRet || nme > KRUN) && run_left * (77 * (nm - 1) - 160) >= 200 * (nm - 1)) {
+        if (RG_SWEEP16_GATHER && kGather && (kRec ? (kColmax == 0 || (kColmax == 2 && RG_SWEEP16_GATHER_FWD)) : !track) && !kWide && a.gather_ok && !semi_end && (flags & F_INNER) && nm > KRUN &&
+            (!kRet || nme > KRUN) && run_left * (RG_GATHER_PER_MEMBER_ROW * (nm - 1) - RG_GATHER_PER_ROW) >= RG_GATHER_PER_MEMBER_RUN * (nm - 1)) {
             // ---- GATHER RUN: R consecutive inner rows of a segment that a wide group (nm paths, one group, alpha = its lowest
             // path) runs through.  Every member follows the alpha's directions, and a direction only MOVES values (D: from
             // column c - 1 of the row above, U: from column c, L: from column c - 1 of the new row) and adds a constant that
@@ -1053,8 +1077,8 @@ __global__ __launch_bounds__(64, C > 16 ? 2 : (kColmax != 0 ? RG_SWEEP16_FWD_WAV
         // (PATH RETIREMENT: a wide group of which <= KRUN members are left runs here too — a gather run costs two member
         // updates per row whatever is left of the group; like a gather run it leaves bkey alone, which is what the split
         // tables count on for the runs between the groups of a row)
-        if (KRUN > 0 && (flags & F_INNER) && (nm <= KRUN || (kRet && nme <= KRUN && RG_SWEEP16_GATHER && !kWide && a.gather_ok && !semi_end &&
-                                                             run_left * (77 * (nm - 1) - 160) >= 200 * (nm - 1))) && run_left > 0) {
+        if (KRUN > 0 && (flags & F_INNER) && (nm <= KRUN || (kRet && nme <= KRUN && RG_SWEEP16_GATHER && kGather && !kWide && a.gather_ok && !semi_end &&
+                                                             run_left * (RG_GATHER_PER_MEMBER_ROW * (nm - 1) - RG_GATHER_PER_ROW) >= RG_GATHER_PER_MEMBER_RUN * (nm - 1))) && run_left > 0) {
             // ---- inner rows of a segment with a small group: the same paths, one group, predecessor = previous row.
             // Their rows stay in registers for the whole run: no row load/store latency, no HBM traffic.  The group
             // alpha of an inner row is its lowest path (alphas[row] == alphas[pred], rg_graph.cpp) = member 0.
@@ -1090,6 +1114,7 @@ __global__ __launch_bounds__(64, C > 16 ? 2 : (kColmax != 0 ? RG_SWEEP16_FWD_WAV
             __builtin_amdgcn_s_waitcnt(0x0F70);
 #endif
             int ri = i, rli = li, rslot = slot, rw1 = w1, rfl = 7;
+            int rleft = run_left;               // rows left in the counted run, this one included (the record's run field)
             bool tail = false;
             for (;;) {          // (chained runs)
             tail = false; rfl = 7;
@@ -1101,7 +1126,8 @@ __global__ __launch_bounds__(64, C > 16 ? 2 : (kColmax != 0 ? RG_SWEEP16_FWD_WAV
                 int src;
                 load_steps(rli, s);
                 unsigned umask;
-                RowOps16<C>::alpha(rr[0], s, g_i, g0, lane, MU, ML, umask, lmask, src);
+                // (at 32 columns per lane `src` stays unconditional: the branch costs that variant 54 more spilled registers)
+                RowOps16<C>::alpha(rr[0], s, g_i, g0, lane, MU, ML, umask, lmask, src, C > 16 || rnm > 1);
                 if (dirs) store_dirs(rslot, umask, lmask);
                 if (rnm > 1) {
                     // (SEL is defined and used under ONE condition: with `if (rnm > 1) select_steps` beside member loops guarded
@@ -1191,6 +1217,16 @@ __global__ __launch_bounds__(64, C > 16 ? 2 : (kColmax != 0 ? RG_SWEEP16_FWD_WAV
                 }
                 ++t;
                 if (tail || t >= nsteps) break;                 // (a tail ends its run)
+                if (rleft > 1) {
+                    // the run goes on: a record whose run field counts more rows than itself is followed by the next inner row
+                    // of the same segment — same group, flags 7 (rg_steps.cpp builds the field that way and moves runs whole) —
+                    // so neither its flags nor its members are looked at, and only two of its four words are fetched
+                    if ((t >> 6) != blk) to_block(t >> 6);
+                    const int nw0 = __builtin_amdgcn_readlane(recs.x, t & (WAVE - 1)), nw1 = __builtin_amdgcn_readlane(recs.y, t & (WAVE - 1));
+                    ri = nw0 & 0xfffff; rli = (nw0 >> 20) & 7; rslot = nw1 & 0xfffff; rw1 = nw1;
+                    rleft = (nw0 >> 26) & 63;
+                    continue;
+                }
                 const int pw = peek_w0(t);
                 const int nf = (pw >> 23) & 7;
                 const bool to_tail = kRec && kColmax != 1 && (nf & F_INNER) && ((pw >> 26) & 63) == 0;
@@ -1203,6 +1239,7 @@ __global__ __launch_bounds__(64, C > 16 ? 2 : (kColmax != 0 ? RG_SWEEP16_FWD_WAV
                 fetch(t, nw0, nw1, ngm);
                 ri = nw0 & 0xfffff; rli = (nw0 >> 20) & 7; rslot = nw1 & 0xfffff; rw1 = nw1;
                 tail = to_tail; rfl = nf;
+                rleft = to_tail ? 0 : (nw0 >> 26) & 63;
             }
             // ---- the run (and its tail) is over: rows in rr, t = the next record
             if (tail) {
@@ -1247,6 +1284,7 @@ __global__ __launch_bounds__(64, C > 16 ? 2 : (kColmax != 0 ? RG_SWEEP16_FWD_WAV
                 unsigned long long ngm;
                 fetch(t, nw0, nw1, ngm);
                 ri = nw0 & 0xfffff; rli = (nw0 >> 20) & 7; rslot = nw1 & 0xfffff; rw1 = nw1;
+                rleft = (nw0 >> 26) & 63;
             }
             }                   // (chained runs)
 #ifdef RG_SWEEP16_KRUNNOST
@@ -1392,26 +1430,38 @@ __global__ __launch_bounds__(64, C > 16 ? 2 : (kColmax != 0 ? RG_SWEEP16_FWD_WAV
     }
 }
 
-// Host-side admission test: uniform read-gap cost and every absolute score provably inside the 16-bit budget.
-// A cell of path k at (row i, column j) is the score of an alignment of j read bases against at most `max_path_rows`
-// graph rows: |value| <= (max_path_rows + n) * max|entry|.  NEG16 plus a few steps of drift must not wrap either.
-// Gap entries must be <= 0: the border column then holds values <= 0, so that `d - max(d, u)` of lane 0's column 0
-// (d = NEG16 + s, u = the border value) stays above -32768 and the U mask keeps its sign (a positive border value of a
-// few thousand would wrap the 16-bit difference and flip the mask).
+// Host-side admission test: uniform gap cost and every STORED value provably inside the 16-bit budget.
+// What the rows hold is z = A - c * g (c: column, g: the gap cost), not A.  A row starts at z = 0 and changes only through
+//   U: z + g_i (= z + g, the gap column is uniform)        D: z_diagonal + (s - g)        L: z_left (a copy)
+// — whoever chose the move (members follow their alpha), every cell is its chain's start plus one such step per move.  So after
+// at most `rows` graph rows and n read bases
+//   zlo = -(rows + 2) * |g| - (n + 2) * max(0, g - min s)   <=   z   <=   (n + 2) * max(0, max s - g) = zhi
+// (round 4 bounded |A| <= (rows + n) * max|entry| <= 24 000 instead, which refused -X 6 at 1 kbp and every read longer than
+// ~1.2 kbp: the all-gap corner of A is -(rows + n) |g|, the same corner of z only -rows |g|).  Required:
+//   * zlo above the "minus infinity" of a 16-bit lane (NEG16 = -30 000) with a step of head-room, zhi below +29 000;
+//   * zhi - zlo <= 32 000: every difference of two stored values (direction masks from the sign of d - max(d, u), the
+//     gather runs' member deltas) fits a signed half;
+//   * |A| <= (rows + n + 2) * max|entry| <= 32 000: outputs convert back (A = z + c g) inside key << 16 arithmetic;
+//   * gap entries <= 0: the border column (c = 0: z = A = i * g) then holds values <= 0, so that d - max(d, u) of lane 0's
+//     column 0 (d = NEG16 + s, u = the border value) stays above -32768 and the U mask keeps its sign.
 bool sweep16_admissible(const DevScores& sc, int max_path_rows, int max_n, int C) {
     for (int b = 1; b < 5; ++b) if (sc.t[b * 6 + 5] != sc.t[5]) return false;
     for (int b = 0; b < 5; ++b) if (sc.t[b * 6 + 5] > 0 || sc.t[5 * 6 + b] > 0) return false;
-    long long maxabs = 0;
+    long long maxabs = 0, smin = INT32_MAX, smax = INT32_MIN;
     for (int x = 0; x < 6; ++x)
         for (int y = 0; y < 6; ++y) {
             if (x == 5 && y == 5) continue;
             const long long v = sc.t[x * 6 + y];
             maxabs = std::max(maxabs, v < 0 ? -v : v);
+            if (x < 5 && y < 5) { smin = std::min(smin, v); smax = std::max(smax, v); }
         }
     if (maxabs > 1000) return false;
-    if ((long long)(max_path_rows + max_n + 2) * maxabs > 24000) return false;      // |A| of every cell
-    // z = A - c * g <= max A + n * |g|: stay clear of the 16-bit top as well (thresholds and keys use z << 16)
-    if ((long long)(max_path_rows + max_n + 2) * maxabs + (long long)(max_n + 2) * maxabs > 30000) return false;
+    const long long g = sc.t[5];                 // <= 0
+    const long long rows = max_path_rows + 2, n = max_n + 2;
+    const long long zlo = rows * g - n * std::max(0ll, g - smin);
+    const long long zhi = n * std::max(0ll, smax - g);
+    if (zlo < -29000 || zhi > 29000 || zhi - zlo > 32000) return false;
+    if ((rows + n) * maxabs > 32000) return false;                 // |A| of every cell
     if ((long long)(C / 2 + 2) * maxabs > 2000) return false;
     return true;
 }
@@ -1723,8 +1773,9 @@ void launch_sweep16(const SweepArgs& a_, int nreads, int C, hipStream_t s) {
     if (!(a.rev ? a.rlead : a.flead)) a.retire = 0;
     a.table_members = a.rev ? a.rmembers : a.fmembers;
     // a sweep that writes records and is not asked for column maxima skips their tracking
+    // (kColmax = 2 — packed maxima without their cells — was the forward sweep of the record pipeline until round 5; the
+    // driver now reads both sweeps' maxima out of their records and nothing instantiates that form any more)
     if (a.frec && !a.colmax_out) launch_sweep16_c<0, true>(a, nreads, C, s);
-    else if (a.frec && !a.colarg_out) launch_sweep16_c<2, true>(a, nreads, C, s);     // maxima without their cells
     else if (a.frec) launch_sweep16_c<1, true>(a, nreads, C, s);
     // -m 4 / -m 5: no best-member tracking at all (the variant below carries the column-maxima / threshold registers it
     // would never use and spilled 57 of them)

@@ -281,6 +281,18 @@ def substring_reads(graph, n_reads, length, seed=5678, anchored=False):
     return reads
 
 
+def full_walk_reads(graph, n_reads, seed=5678):
+    """Whole source->sink walks with the same error model (reads that a GLOBAL alignment can place inside a narrow band)."""
+    rng = np.random.default_rng(seed)
+    stage_alts = [sorted(set(st)) for st in zip(*graph.paths)]
+    reads = []
+    for _ in range(n_reads):
+        walk = "".join(graph.seq_of[a[int(rng.integers(0, len(a)))]] for a in stage_alts)
+        codes = _apply_errors(rng, _CODE[np.frombuffer(walk.encode(), dtype=np.uint8)])
+        reads.append(BASES[codes].tobytes().decode())
+    return reads
+
+
 CONFIGS = {
     # name: (mode, graph builder, reads builder, n_reads of the full config)
     "C2": dict(mode=0, rows=1000, n=150, reads=10000),

@@ -19,6 +19,10 @@ def test_headline_sweep_variants_use_no_scratch():
         assert k["VGPRs"] <= 256 and k["Occupancy [waves/SIMD]"] >= 2, (name, k)
     # the -m 4 sweep fits three waves per SIMD (168 registers, 13 KB of LDS per wave)
     assert ks["rg::k_sweep16<16, 0, false, false, false>"]["Occupancy [waves/SIMD]"] >= 3
+    # reads of 1024-2047 bases (32 columns per lane): a row is 16 registers and the record variant is at the 256-register limit —
+    # a few spilled registers are tolerated, a relapse (one uniform branch in the alpha took it from 13 to 67) is not
+    k32 = ks["rg::k_sweep16<32, 0, true, false, false>"]
+    assert k32["VGPRs Spill"] <= 24 and k32["ScratchSize [bytes/lane]"] <= 96, k32
     # the narrower instantiations of the same variants (shorter reads) and their semiglobal forms do not spill either
     for c in (4, 8):
         for v in ("0, true, false, false", "0, false, false, false", "0, true, false, true", "0, false, false, true"):
