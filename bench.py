@@ -64,7 +64,9 @@ def parse_args(argv=None):
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--cpu-reads", type=int, default=-1, help="cap on the reads of every cpu_baseline leg (0 = skip the legs)")
     ap.add_argument("--no-cpu", action="store_true", help="skip cpu_baseline and the parity gate")
-    ap.add_argument("--handles", type=int, default=3, help="batch handles (work-buffer sets in HBM, host thread + HIP stream each) of the stream")
+    ap.add_argument("--handles", type=int, default=0, help="batch handles (work-buffer sets in HBM, host thread + HIP stream each) of the stream; default: 3, config 4: 6 "
+                    "(its sweep runs three waves per SIMD and leaves the small kernels of the other tiles little room: with six tiles in flight "
+                    "the stream is steady at ~300 k reads/s, with three it flips between 270 k and 298 k from run to run)")
     ap.add_argument("--no-probe", action="store_true", help="skip the probe steps (kernel durations then come from the timed region)")
     ap.add_argument("--sweep-i32", action="store_true", help="force the i32 sweep kernel (rg_set_option sweep_i32)")
     ap.add_argument("--no-strong", action="store_true", help="skip the strong_100k region (N > 1) / the strong_proxy region (N = 1)")
@@ -548,6 +550,8 @@ def main():
     mode = cfg["mode"]
     num = int(args.config[1])
     batch = args.batch or DEFAULT_BATCH[args.config]
+    if args.handles <= 0:
+        args.handles = 6 if args.config == "C4" else 3
     sg, _, _ = synth.make_config(args.config, n_reads=1)
     gfa = sg.gfa()
 

@@ -170,8 +170,8 @@ uint64_t rg_batch_cell_updates(const rg_batch* b);
 /* The cell updates the kernels actually performed for that workload: the same number except where k_sweep16 runs a
  * segment's rows as a gather run (per row the alpha and a column map instead of one update per member path) and where
  * its -m 8 sweeps retire paths (a path that provably cannot matter any more, and leads no path that can,
- * is not updated further; the results are the same bytes).  Updates of a second pass after a failed speculation are in
- * neither number. */
+ * is not updated further; the results are the same bytes).  The updates of a second pass after a failed speculation count
+ * here (they are work the device performed) and not in rg_batch_cell_updates (the workload did not grow). */
 uint64_t rg_batch_cell_updates_performed(const rg_batch* b);
 int32_t rg_batch_kernel_count(const rg_batch* b);
 const char* rg_batch_kernel_name(const rg_batch* b, int32_t k);
@@ -342,7 +342,10 @@ int32_t rg_stream_handles(rg_stream* s);      /* batch handles that aligned at l
  * every path to the end; 2 / 3: retirement in the forward / reverse sweep only), "no_pick2" (RG_NO_PICK2: the speculative
  * bound from one-path picks only), "no_order" (RG_NO_ORDER: the sweeps' waves in read order instead of longest first), "stripe_c" (RG_STRIPE_C: 8, 16 or 32 columns per lane for reads longer
  * than 2047 bases; 0 = 16 up to 8191 bases, 32 beyond), "spin_wait" (RG_SPIN_WAIT: hipStreamSynchronize instead of sleep-polling
- * for the long waits), "debug" (RG_DEBUG: list statistics on stderr).
+ * for the long waits), "debug" (RG_DEBUG: list statistics on stderr; the packed k_opt0 is cross-checked against its i32 form),
+ * "retire_shift" (RG_RETIRE_SHIFT, 2..12, default 8: the sweeps look for hopeless paths every 2^k step records; read when a
+ * handle builds its step tables — the test suite runs its small graphs at 4), "lds_pad" (RG_LDS_PAD, bytes, experiments only:
+ * extra dynamic LDS per k_sweep16 workgroup, which lowers the waves per CU).
  * The variants compute the same records byte for byte (tests/test_gpu_pathwise.py). */
 int32_t rg_set_option(const char* name, int64_t value);
 int64_t rg_get_option(const char* name);      /* -1: unknown option */

@@ -20,6 +20,9 @@ namespace rg {
         if (e_ != hipSuccess) { (void)hipGetLastError(); /* clears the sticky error */ return fail(RG_ERR_HIP, std::string(#x) + ": " + hipGetErrorString(e_)); } \
     } while (0)
 
+// (set by Buf::alloc when hipMalloc itself reported hipErrorOutOfMemory: the one failure the driver answers with smaller launches)
+static thread_local bool g_alloc_oom = false;
+
 template <typename T>
 struct Buf {
     T* p = nullptr;
@@ -29,7 +32,13 @@ struct Buf {
         if (p && count <= n) return RG_OK;
         if (p) { (void)hipFree(p); p = nullptr; n = 0; }
         if (!count) count = 1;
-        HIPCHK(hipMalloc((void**)&p, count * sizeof(T)));
+        const hipError_t e = hipMalloc((void**)&p, count * sizeof(T));
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            p = nullptr;
+            g_alloc_oom = e == hipErrorOutOfMemory;
+            return fail(RG_ERR_HIP, std::string("hipMalloc of ") + std::to_string(count * sizeof(T)) + " bytes: " + hipGetErrorString(e));
+        }
         n = count;
         return RG_OK;
     }
@@ -305,11 +314,15 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
     // still retire paths and emit few records: a second pass on the provable bound keeps one wave per read busy for two full
     // sweeps and a search over ~40 000 records); 2 = what fails even that, with the provable bound
     const bool allow_spec = spec_level < 2;
-    const bool spec = (use_rec || (two_sweep && nwv > 1)) && allow_spec && !semi && P <= 64 && !opt.no_spec;
+    // (round 5: the i32 sweep of reads that fit one wave takes it as well — score matrices outside the 16-bit budget, HOXD70 /
+    // HOXD55 with their -200 gaps, emitted every forward cell within (seed - path-0 score) of a diagonal as a Cand)
+    const bool spec = two_sweep && allow_spec && !semi && P <= 64 && !opt.no_spec;
     // (a follower path's sink value lies below its own NW optimum — measured up to 72 at 1 kbp — and the gap grows with the
     // read: long reads scale the margin with their length, or every read would fail the check and run again)
-    const int spec_margin = (nwv > 1 ? opt.spec_margin * ((max_n + 999) / 1000) : (int)opt.spec_margin) +
-                            (spec_level == 1 ? 320 * ((max_n + 999) / 1000) : 0);
+    // The margin is in units of the default scores (match 2): other matrices scale it with their best match (HOXD70: 100 -> x50).
+    const int score_scale = std::max(1, maxmatch / 2);
+    const int spec_margin = ((nwv > 1 ? opt.spec_margin * ((max_n + 999) / 1000) : (int)opt.spec_margin) +
+                             (spec_level == 1 ? 320 * ((max_n + 999) / 1000) : 0)) * (opt.spec_margin > 0 ? score_scale : 1);
     const int recw = 4 + C;
     if (w.fcap == 0) { w.fcap = (two_sweep && !use_rec) ? 1u << 20 : 1u << 15; w.rcap = use_rec ? 1u << 16 : 1u << 19; w.frec_cap = 1u << 16; w.rrec_cap = 1u << 15; }   // (reverse records at config 5: mean 2.7 k, largest read of a 4096-read tile 21-25 k)
     stats.clear();
@@ -350,9 +363,11 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
             }
             return RG_OK;
         };
+        g_alloc_oom = false;
         if ((rc = alloc_all())) {
-            // out of memory (the share was measured before other buffers of the device existed): smaller launches, like run_poa
-            if (rc == RG_ERR_HIP && chunk > 1 && oom_shift < 12) { ++oom_shift; continue; }
+            // out of memory (the share was measured before other buffers of the device existed): smaller launches, like run_poa.
+            // Any OTHER HIP failure is reported at once (it used to be retried up to twelve times with halved chunks).
+            if (rc == RG_ERR_HIP && g_alloc_oom && chunk > 1 && oom_shift < 12) { ++oom_shift; continue; }
             return rc;
         }
         const uint8_t* bad = d_bad + done;
@@ -407,7 +422,21 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
                     oa.pick = w.pick.p;
                     oa.margin = spec_margin;
                 }
-                TIMED(T, "k_opt0", launch_opt0(oa, chunk, C, stream));
+                // (packed rows whenever the sweep runs packed: a third of the i32 form's instructions)
+                const bool opt16 = use16 && nwv == 1;
+                TIMED(T, "k_opt0", opt16 ? launch_opt0_16(oa, chunk, C, stream) : launch_opt0(oa, chunk, C, stream));
+                if (opt16 && debug) {
+                    // RG_DEBUG: the i32 form beside it — the two must agree on every read (the bound only steers the pruning, so
+                    // no parity test would notice a wrong one: tests/test_gpu_pathwise.py runs this check)
+                    std::vector<int> h16(chunk), h32(chunk);
+                    HIPCHK(hipMemcpyAsync(h16.data(), w.lb.p, sizeof(int) * chunk, hipMemcpyDeviceToHost, stream));
+                    HIPCHK(hipStreamSynchronize(stream));
+                    launch_opt0(oa, chunk, C, stream);
+                    HIPCHK(hipMemcpyAsync(h32.data(), w.lb.p, sizeof(int) * chunk, hipMemcpyDeviceToHost, stream));
+                    HIPCHK(hipStreamSynchronize(stream));
+                    for (int k = 0; k < chunk; ++k)
+                        if (h16[k] != h32[k]) return fail(RG_ERR_HIP, "k_opt0_16 differs from k_opt0 at read " + std::to_string(k) + ": " + std::to_string(h16[k]) + " vs " + std::to_string(h32[k]));
+                }
                 SweepArgs f = sa;
                 f.rev = 0; f.track_best = 1; f.lb = w.lb.p; f.brc = p.base_rec_cost + opt.lb_bonus; f.maxmatch = maxmatch;
                 f.oob = spec ? 1 : 0;        // tight thresholds: most rows emit nothing (row_end tests the lane maximum first)
@@ -583,6 +612,7 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
                 return rc;
             launch_scatter_results(w.rt_idx.p, w.rt_rec.p, w.rt_ops.p, d_rec + done, d_ops + (long long)done * ops_stride, ops_stride, nr, stream);
             HIPCHK(hipStreamSynchronize(stream));
+            cells_perf += c2[1];             // the second pass is work the sweeps performed too (the counted figure stays the workload's)
             for (auto& e : st2) {
                 bool found = false;
                 for (auto& st : stats) if (st.first == e.first) { st.second.first += e.second.first; st.second.second += e.second.second; found = true; }

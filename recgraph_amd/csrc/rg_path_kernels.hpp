@@ -233,6 +233,7 @@ void launch_expand(const ExpandArgs& a, int nreads, int C, hipStream_t s);
 void launch_colmax_rec(const ExpandArgs& a, int* colmax_out, int* colarg_out, int nreads, int C, hipStream_t s);
 void launch_seed(const SeedArgs& a, hipStream_t s);
 void launch_opt0(const Opt0Args& a, int nreads, int C, hipStream_t s);
+void launch_opt0_16(const Opt0Args& a, int nreads, int C, hipStream_t s);   // packed rows (rg_sweep16.hip): batches the packed sweep admits
 void launch_pick(const PickArgs& a, int nreads, hipStream_t s);
 // Launch order of the sweeps' waves under path retirement: the work of a read grows with the highest id among its picked
 // paths (every lower path leads it somewhere), from a few percent of a full sweep to all of it — longest first,

@@ -1740,6 +1740,117 @@ void launch_layer16(const LayerArgs& a, int nreads, int C, hipStream_t s) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// k_opt0 on packed rows (k_opt0 of rg_pathwise.hip is the i32 form: one LDS lookup, two compares and a GP subtraction per
+// column, ~170 wave-instructions per row; this one ~55).  Same job: the plain NW score of the read against the rows of one
+// path — path 0 (the provable bound), the picked path, or p1's rows up to X followed by p2's (two-path picks) — in the
+// sweep's z-space with the sweep's score profile.  Only the final value leaves the kernel; no masks, no direction words.
+// Batches the packed sweep admits (sweep16_admissible: every stored value fits; the driver sends the others to k_opt0).
+template <int C>
+__global__ __launch_bounds__(64) void k_opt0_16(Opt0Args a) {
+    constexpr int H = C / 2;
+    const int rd = blockIdx.x;
+    const int lane = threadIdx.x;
+    const PathGraphDev& g = a.g;
+    const long long ro = a.read_off[rd];
+    const int n = (int)(a.read_off[rd + 1] - ro);
+    if (a.bad[rd] || n + 1 > C * WAVE) { if (lane == 0) a.lb[rd] = INT32_MIN / 2; return; }
+    const uint8_t* read = a.reads + ro - 1;
+    const int ncols = n + 1, GAP = 5;
+    extern __shared__ __attribute__((aligned(16))) int lds16[];
+    int* sct = lds16;                    // [36]
+    int* s2 = lds16 + 64;                // [5][64] packed (s - g) pairs by (code_lo | code_hi << 3)
+    int* sprof = s2 + 5 * 64;            // [5][64][H]
+    if (lane < 36) sct[lane] = a.sc.t[lane];
+    __syncthreads();
+    const int gcost = __builtin_amdgcn_readfirstlane(sct[GAP]);
+    for (int e = lane; e < 5 * 64; e += WAVE) {
+        const int li = e >> 6, cl = e & 7, ch = (e >> 3) & 7;
+        s2[e] = (cl < 6 && ch < 6) ? pack16(sct[li * 6 + cl] - gcost, sct[li * 6 + ch] - gcost) : 0;
+    }
+    __syncthreads();
+    int row[H];
+#pragma unroll
+    for (int r = 0; r < H; ++r) {
+        const int c0 = lane * C + r, c1 = c0 + H;
+        int k0 = 4, k1 = 4;
+        if (c0 >= 1 && c0 < ncols) k0 = read[c0];
+        if (c1 >= 1 && c1 < ncols) k1 = read[c1];
+#pragma unroll
+        for (int li = 0; li < 5; ++li) sprof[(li * WAVE + lane) * H + r] = s2[li * 64 + (k0 | (k1 << 3))];
+        row[r] = pack16(c0 < ncols ? 0 : NEG16, c1 < ncols ? 0 : NEG16);       // the gap-only start row: z = 0
+    }
+    __syncthreads();
+    const int GI = pack16(gcost, gcost);
+    const int GI0 = lane == 0 ? pack16(a.semi ? 0 : gcost, gcost) : GI;        // border column 0 (semiglobal: stays 0)
+    const int pk = a.pick ? a.pick[rd] : 0;
+    const int pk2 = (a.pick && a.pick2) ? a.pick2[2 * rd] : -1;
+    const int X = pk2 >= 0 ? a.pick2[2 * rd + 1] : INT32_MAX;
+    int beg = a.fpoff[pk], cnt = a.fpoff[pk + 1] - beg;
+    const int ln = n / C, ql = n % C;
+    int semibest = NEG32;
+    bool second = false;
+    int li_next = cnt > 0 ? g.lnz[a.fprow[beg]] : 4;
+    for (int t = 0; t < cnt; ++t) {
+        const int i = a.fprow[beg + t];
+        if (i > X && !second) {
+            // switch lists: first row of p2 above X (its list is ascending)
+            second = true;
+            beg = a.fpoff[pk2]; cnt = a.fpoff[pk2 + 1] - beg;
+            int lo = 0, hi = cnt;
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (a.fprow[beg + mid] <= X) lo = mid + 1; else hi = mid; }
+            t = lo - 1;
+            li_next = lo < cnt ? g.lnz[a.fprow[beg + lo]] : 4;
+            continue;
+        }
+        const int li = li_next;
+        if (t + 1 < cnt) li_next = g.lnz[a.fprow[beg + t + 1]];      // (one row ahead: off the dependency chain)
+        int s[H];
+        {
+            const int* sp = sprof + (li * WAVE + lane) * H;
+#pragma unroll
+            for (int r = 0; r < H; ++r) s[r] = sp[r];
+        }
+        int prev = __builtin_amdgcn_alignbit(row[H - 1], dpp_shr1(row[H - 1], NEGPAIR), 16);
+        int run = NEGPAIR;
+#pragma unroll
+        for (int r = 0; r < H; ++r) {
+            const int old = row[r];
+            const int du = pk_max(pk_add(prev, s[r]), pk_add(old, r == 0 ? GI0 : GI));     // (lane 0 column 0: d = -inf)
+            run = pk_max(du, run);
+            row[r] = du;
+            prev = old;
+        }
+        const int TL = lo16(run), TH = hi16(run);
+        const int ze = dpp_shr1(dpp_incl_max(max(TH, TL), INT32_MIN), INT32_MIN);
+        const int bl = max(ze, NEG16);
+        int vprev = pack16(bl, max(TL, bl));
+#pragma unroll
+        for (int r = 0; r < H; ++r) { vprev = pk_max(row[r], vprev); row[r] = vprev; }
+        if (a.semi) {   // free end row: best last-column value over the rows of the path
+            int pv = 0;
+#pragma unroll
+            for (int r = 0; r < H; ++r) if (r == ql % H) pv = row[r];
+            semibest = max(semibest, (ql >= H ? hi16(pv) : lo16(pv)) + n * gcost);
+        }
+    }
+    int pv = 0;
+#pragma unroll
+    for (int r = 0; r < H; ++r) if (r == ql % H) pv = row[r];
+    const int v = (ql >= H ? hi16(pv) : lo16(pv)) + n * gcost;
+    if (lane == ln) a.lb[rd] = (a.semi ? semibest : v) - (a.pick ? a.margin : 0) - (pk2 >= 0 ? a.rec_pen : 0);
+}
+
+void launch_opt0_16(const Opt0Args& a, int nreads, int C, hipStream_t s) {
+    const size_t bytes = (size_t)(64 + 5 * 64 + 5 * WAVE * (C / 2)) * sizeof(int);
+    switch (C) {
+        case 4: hipLaunchKernelGGL((k_opt0_16<4>), dim3(nreads), dim3(64), bytes, s, a); break;
+        case 8: hipLaunchKernelGGL((k_opt0_16<8>), dim3(nreads), dim3(64), bytes, s, a); break;
+        case 16: hipLaunchKernelGGL((k_opt0_16<16>), dim3(nreads), dim3(64), bytes, s, a); break;
+        default: hipLaunchKernelGGL((k_opt0_16<32>), dim3(nreads), dim3(64), bytes, s, a); break;
+    }
+}
+
 template <int kColmax, bool kRec, bool kWide, bool kSemi>
 static void launch_sweep16_s(const SweepArgs& a, int nreads, int C, hipStream_t s) {
     const size_t bytes = (size_t)(64 + 2 * (kWide ? RG_MAXP : 64) + std::max(C * WAVE, 5 * 64) + 4 * WAVE * (C / 2)) * sizeof(int) + (size_t)options().lds_pad;

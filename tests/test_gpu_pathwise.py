@@ -169,6 +169,35 @@ def test_sweep_kernel_variants_agree(oracle):
         assert texts[i] == og.align(oracle.M8_ABS, r, name="read%d" % i, scores=table)[0]
 
 
+def test_packed_opt0_equals_the_i32_form(oracle):
+    """`k_opt0_16` (the speculative / provable forward bound on packed rows) against `k_opt0` on every read: the bound only
+    steers the pruning — a wrong one would cost speed or a second pass, never bytes — so the driver's RG_DEBUG mode runs both
+    and fails the batch on any difference.  Global and semiglobal, one- and two-path picks, the provable path-0 bound, reads
+    of 16 / 32 columns per lane, non-default scores."""
+    from recgraph_amd import api, synth
+    cases = ((2500, 12, 400, 71, None), (4000, 32, 700, 73, None), (3000, 8, 1300, 74, None), (2500, 12, 400, 75, api.create_score_matrix_i32(3, -5)))
+    try:
+        api.set_option("debug", 1)
+        for rows, P, plen, seed, sm in cases:
+            g = synth.haplotype_graph(rows, P, path_len=plen, seed=seed)
+            rd = synth.haplotype_reads(g, 24, length=plen, seed=seed + 1, mosaic_frac=0.6) + [g.path_sequence(P - 1)[:plen // 2], "ACGT" * 5, "T"]
+            gg = api.Graph.from_gfa_text(g.gfa())
+            names = ["r%d" % i for i in range(len(rd))]
+            kw = {} if sm is None else {"score_matrix": sm}
+            for mode in (api.MODE_RECOMBINATION, api.MODE_RECOMBINATION_SEMI):
+                for opts in ((), (("no_pick2", 1),), (("no_spec", 1),)):
+                    try:
+                        for name, val in opts:
+                            api.set_option(name, val)
+                        texts, status = api.align_batch(gg, rd, names, mode=mode, **kw)       # raises if the two kernels disagree
+                    finally:
+                        for name, _ in opts:
+                            api.set_option(name, 0)
+                    assert len(texts) == len(rd)
+    finally:
+        api.set_option("debug", 0)
+
+
 def test_speculative_forward_bound(oracle):
     """-m 8, two-sweep record pipeline, P <= 64: the forward sweep prunes with a SPECULATIVE bound (score against the path
     k_pick votes for, minus a margin) that k_verify checks afterwards; reads whose search maximum stayed below it are

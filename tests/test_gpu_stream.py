@@ -3,6 +3,8 @@ CLI runs — delivers, tile by tile and in input order, exactly the bytes of the
 other GPU tests hold equal to the oracle)."""
 import os
 import subprocess
+import threading
+import time
 import sys
 
 import numpy as np
@@ -220,6 +222,52 @@ def test_bounded_stream_with_a_slow_consumer():
     th.join()
     assert peak[0] <= 10
     assert b"".join(t.text for t in got).decode() == "".join(one) and len(got) == 40
+    st.close()
+
+
+def test_abort_wakes_a_blocked_feeder_and_destroy_is_safe(example_gfa, example_reads):
+    """a bounded stream whose consumer gives up.  The feeder sits inside a push that waits for room in the queue
+    (nobody drains); `rg_stream_abort` makes that push — and every later call — return an error at once, `next` fails the same
+    way, and the stream can be closed while tiles are still on the device.  A failed `feed_fasta` leaves no stale carry."""
+    from recgraph_amd import api
+    names, reads = example_reads
+    g = api.Graph.from_gfa_text(example_gfa)
+    st = api.Stream(g, api.make_params(api.MODE_PATHWISE), device_ids=[0], handles_per_device=1, tile_reads=4, max_queued_tiles=1)
+    pushed, err = [0], []
+    started = threading.Event()
+
+    def feeder():
+        try:
+            for k in range(0, 400):
+                st.push(reads[(4 * k) % 48:(4 * k) % 48 + 4])         # blocks once one tile is queued and one is on the handle
+                pushed[0] += 1
+                started.set()
+        except Exception as ex:
+            err.append(ex)
+    th = threading.Thread(target=feeder)
+    th.start()
+    assert started.wait(60)
+    time.sleep(0.3)                                  # the feeder is now inside a blocked push
+    n_before = pushed[0]
+    assert th.is_alive() and n_before < 400
+    st.abort()
+    th.join(30)
+    assert not th.is_alive() and len(err) == 1 and "abort" in str(err[0])
+    with pytest.raises(Exception):
+        st.next()
+    with pytest.raises(Exception):
+        st.push(reads[:4])
+    st.close()
+    # a feed that fails in the middle (an empty read) resets the feeder: the same stream takes a new text from scratch
+    st = api.Stream(g, api.make_params(api.MODE_PATHWISE), device_ids=[0], tile_reads=3)
+    good = b"".join(b">%s\n%s\n" % (names[i].encode(), reads[i].encode()) for i in range(5))
+    with pytest.raises(Exception):
+        st.feed_fasta(good + b">empty\n\n>x\nACGT\n", final=True)
+    n = st.feed_fasta(good, final=True)
+    st.finish()
+    tiles = list(st)
+    texts = b"".join(t.text for t in tiles).decode()
+    assert texts.count("\n") >= 5 and all(nm.split()[0] in texts for nm in names[:5])
     st.close()
 
 

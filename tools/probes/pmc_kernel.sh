@@ -1,7 +1,7 @@
 #!/bin/bash
 # Per-read instruction / cycle counters of one kernel family of a configuration (one rocprofv3 --pmc pass):
 #   tools/probes/pmc_kernel.sh C2 k_m0_simd [reads per launch = 10000]
-cd "$GRAFT_REPO_ROOT" || exit 1
+cd "$(dirname "$0")/../.." || exit 1
 export TMPDIR=/tmp
 CFG=$1; KERN=$2; RPL=${3:-10000}
 O=gpurun_out/pmc_probe_$CFG; rm -rf $O; mkdir -p $O

@@ -3,7 +3,7 @@
 #   tools/profile_round.sh TAG ["C5 C4 C3 C2"]
 # calibrations (VALU issue rate, FETCH_SIZE / WRITE_SIZE units), then per config: rocprofv3 --kernel-trace --stats of a
 # short bench and three separate --pmc passes; tools/make_counters.py digests everything into gpurun_out/TAG/.
-cd "$GRAFT_REPO_ROOT" || exit 1
+cd "$(dirname "$0")/.." || exit 1
 export TMPDIR=/tmp
 TAG=${1:-r02}
 CFGS=${2:-"C5 C4 C3 C2"}
