@@ -169,7 +169,7 @@ struct RowOps {
 // kStripes: a.nwv waves per read, wave w owns columns [w * 64 * C, (w + 1) * 64 * C) (see StripeFifo above).
 template <int C, bool kUni, bool kStripes = false>
 __global__ __launch_bounds__(kStripes ? 512 : 64, kStripes ? 1 : RG_SWEEP_WAVES) void k_sweep(SweepArgs a) {
-    const int rd = blockIdx.x;
+    const int rd = (!kStripes && a.order) ? a.order[blockIdx.x] : blockIdx.x;       // (launch order: see launch_order)
     const int wl = kStripes ? (int)(threadIdx.x & (WAVE - 1)) : (int)threadIdx.x;      // lane inside the wave
     const int wv = kStripes ? (int)(threadIdx.x >> 6) : 0;                             // stripe of this wave
     const int nwv = kStripes ? a.nwv : 1;
@@ -249,6 +249,44 @@ __global__ __launch_bounds__(kStripes ? 512 : 64, kStripes ? 1 : RG_SWEEP_WAVES)
 #pragma unroll
             for (int q = 0; q < C; ++q) rows.st(k, q * WAVE + wl, wpadw, (lane * C + q) < ncols ? gpl[q] : NEG);
         }
+    }
+    // PATH RETIREMENT (round 5: the i32 form of k_sweep16's; one wave per read, P <= 64, global modes).  A path
+    // whose every future cell is provably below every threshold is hopeless — forward: max_j (A[j] + mmx (n - j)) < lb;
+    // reverse: A[j] + mmx j < min_{j' <= j} (thr[j'] + mmx j') for every j — and stops being computed unless it still
+    // leads a group with a needed member (lead tables of the plain step table).  The per-column constants wait in LDS.
+    int* rvc = g_lds + 64 + 2 * RG_MAXP;             // [C][64] (the launcher allocates them for the one-wave variants)
+    int next_eval = INT32_MAX;
+    unsigned long long needed = P >= 64 ? ~0ull : ((1ull << P) - 1ull);
+    if (!kStripes && a.retire && !a.semi && P <= 64 && (rev ? a.thr != nullptr && a.rlead != nullptr : a.lb != nullptr && a.flead != nullptr)) {
+        const int mmx = max(a.maxmatch, 0);
+        if (!rev) {
+            const int lbv = a.lb[rd];
+#pragma unroll
+            for (int q = 0; q < C; ++q) {
+                const int c = lane * C + q;
+                rvc[q * WAVE + wl] = c < ncols ? mmx * (n - c) - lbv : INT32_MIN / 2;
+            }
+        } else {
+            int tq[C], ltot = INT32_MAX;
+#pragma unroll
+            for (int q = 0; q < C; ++q) {
+                const int c = lane * C + q;
+                tq[q] = thr[q] == INT32_MAX ? INT32_MAX : thr[q] + mmx * (n - c);      // (j = n - c)
+                ltot = min(ltot, tq[q]);
+            }
+            int suf = ltot;
+#pragma unroll
+            for (int d = 1; d < WAVE; d <<= 1) { const int o = __shfl_down(suf, d, WAVE); if (lane + d < WAVE) suf = min(suf, o); }
+            int run = __shfl_down(suf, 1, WAVE);
+            if (lane == WAVE - 1) run = INT32_MAX;
+#pragma unroll
+            for (int q = C - 1; q >= 0; --q) {
+                run = min(run, tq[q]);
+                const int c = lane * C + q;
+                rvc[q * WAVE + wl] = (c < ncols && run != INT32_MAX) ? mmx * (n - c) - run : INT32_MIN / 2;
+            }
+        }
+        next_eval = 1 << a.retire_shift;
     }
     __syncthreads();
 
@@ -389,9 +427,34 @@ __global__ __launch_bounds__(kStripes ? 512 : 64, kStripes ? 1 : RG_SWEEP_WAVES)
     unsigned dmask = 0, lmask = 0;       // directions of the current group's alpha (live across continuation entries)
     int src = 0;
     StripeIO io{NEG, NEG, NEG, NEG};
+    unsigned long long performed = 0;
+    int srow = -1;                       // the row `s` / bkey were set up for (a row's first record may be skipped)
+    bool row_has = false;                // some group of the current row was computed: its epilogue is due at the row's last record
+    auto retire_eval = [&](int e) {
+        unsigned long long hop = 0;
+        for (unsigned long long todo = needed; todo; todo &= todo - 1) {
+            const int k = __builtin_ctzll(todo);
+            int m = INT32_MIN;
+#pragma unroll
+            for (int q = 0; q < C; ++q) m = max(m, rows.ld(k, q * WAVE + wl, wpadw) + rvc[q * WAVE + wl]);
+            if (__builtin_amdgcn_readlane(dpp_incl_max(m, INT32_MIN), WAVE - 1) < 0) hop |= 1ull << k;
+        }
+        const unsigned long long lead_k = wl < P ? (rev ? a.rlead : a.flead)[(long long)e * 64 + wl] : 0ull;
+        unsigned long long nd = needed & ~hop;
+        for (;;) {
+            const unsigned long long ad = __ballot(((needed >> wl) & 1ull) && !((nd >> wl) & 1ull) && (lead_k & nd) != 0ull);
+            if (!ad) break;
+            nd |= ad;
+        }
+        needed = nd;
+    };
     while (t < nsteps) {
         int w0, w1;
         unsigned long long gmask;
+        if (!kStripes && t >= next_eval) [[unlikely]] {
+            retire_eval(t >> a.retire_shift);
+            next_eval = (t | ((1 << a.retire_shift) - 1)) + 1;
+        }
         fetch(t, w0, w1, gmask);
         int i = w0 & 0xfffff;
         int li = (w0 >> 20) & 7;
@@ -403,16 +466,22 @@ __global__ __launch_bounds__(kStripes ? 512 : 64, kStripes ? 1 : RG_SWEEP_WAVES)
         // (an inner row of a one-entry segment run: the alpha is the lowest member, the field holds the run length left)
         int ga = kbase + ((flags & 4) ? __builtin_ctzll(gmask | (1ull << 63)) : ((w0 >> 26) & 63));
         const int nm = __popcll(gmask);
+        cells += (unsigned long long)nm;
+        // (path retirement: the members still computed; a group whose members are all retired — its alpha with them — is skipped)
+        const unsigned long long gm = (!kStripes && next_eval != INT32_MAX) ? (gmask & needed) : gmask;
+        if (gm != 0ull) {
         // ---- general (row, group) step ----
         const int g_i = __builtin_amdgcn_readfirstlane(sct[li * 6 + GAP]);
         const int g0 = a.semi ? 0 : g_i;
-        if (flags & F_FIRST) {
+        if ((flags & F_FIRST) || i != srow) {
 #pragma unroll
             for (int q = 0; q < C; ++q) { s[q] = sct[li * 6 + (int)((erp[q / 16] >> (4 * (q % 16))) & 7)]; bkey[q] = INT32_MIN; }
+            srow = i;
         }
+        row_has = true;
         {
-            unsigned long long rest = cont ? gmask : gmask & ~(1ull << (ga - kbase));
-            cells += (unsigned long long)nm;
+            unsigned long long rest = cont ? gm : gm & ~(1ull << (ga - kbase));
+            performed += (unsigned long long)__popcll(gm);
             // loads: alpha row, and the first member's row in flight while the alpha recurrence runs
             int nxt[C];
             int knext = -1;
@@ -461,8 +530,10 @@ __global__ __launch_bounds__(kStripes ? 512 : 64, kStripes ? 1 : RG_SWEEP_WAVES)
             }
             // no barrier: every lane only ever re-reads the row words it wrote itself
         }
+        }
         if (semi_end && (flags & F_LAST)) end_row_done(i);
-        if (track && (flags & F_LAST)) row_end(i, ((w1 >> 20) & 511) - 1, bkey);
+        if (track && (flags & F_LAST) && row_has) row_end(i, ((w1 >> 20) & 511) - 1, bkey);
+        if (flags & F_LAST) row_has = false;
         ++t;
     }
 
@@ -482,8 +553,10 @@ __global__ __launch_bounds__(kStripes ? 512 : 64, kStripes ? 1 : RG_SWEEP_WAVES)
     if (!rev && !a.semi) {
         // value of every path at its sink row, column n (lane/slot that owns column n)
         const int cn = n, ql = cn % C, ln = cn / C;         // ln: global lane that owns column n
+        // (a retired path's row is stale: its true final score is below the bound k_verify checks the result against)
         if (wv == ln / WAVE)
-            for (int k = wl; k < P; k += WAVE) rs->sink_val[k] = rows.ld(k, ql * WAVE + (ln % WAVE), wpadw);
+            for (int k = wl; k < P; k += WAVE)
+                rs->sink_val[k] = (!kStripes && next_eval != INT32_MAX && !((needed >> k) & 1ull)) ? NEG : rows.ld(k, ql * WAVE + (ln % WAVE), wpadw);
     }
     if (semi_end && wv == ln_end / WAVE) {       // the stripe that owns column n folded every value
         for (int k = wl; k < P; k += WAVE) { rs->sink_val[k] = endv[k]; rs->path_end_row[k] = endr[k]; }
@@ -491,7 +564,7 @@ __global__ __launch_bounds__(kStripes ? 512 : 64, kStripes ? 1 : RG_SWEEP_WAVES)
     }
     if (lane == 0 && a.count_cells) {
         atomicAdd(a.cells, cells * (unsigned long long)(n + 1));
-        atomicAdd(a.cells + 1, cells * (unsigned long long)(n + 1));       // (every member update is performed as such here)
+        atomicAdd(a.cells + 1, (kStripes ? cells : performed) * (unsigned long long)(n + 1));       // (every member update that is not retired is performed as such here)
     }
 }
 
@@ -1294,7 +1367,7 @@ static void launch_sweep_c(const SweepArgs& a, int nreads, hipStream_t s) {
     // uniform read-gap cost: every (base, '-') entry equal (reads hold ACGTN only)
     bool uni = true;
     for (int b = 1; b < 5; ++b) uni = uni && a.sc.t[b * 6 + 5] == a.sc.t[5];
-    const size_t sct_bytes = (64 + 2 * RG_MAXP) * sizeof(int);
+    const size_t sct_bytes = (64 + 2 * RG_MAXP + C * WAVE) * sizeof(int);       // (+ the path-retirement constants)
     if (uni) hipLaunchKernelGGL((k_sweep<C, true>), dim3(nreads), dim3(64), sct_bytes, s, a);
     else hipLaunchKernelGGL((k_sweep<C, false>), dim3(nreads), dim3(64), sct_bytes, s, a);
 }

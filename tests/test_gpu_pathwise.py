@@ -169,6 +169,58 @@ def test_sweep_kernel_variants_agree(oracle):
         assert texts[i] == og.align(oracle.M8_ABS, r, name="read%d" % i, scores=table)[0]
 
 
+def _sweep16_admissible(scores36, max_path_rows, max_n, C):
+    """The admission rule of rg_sweep16.hip (sweep16_admissible), restated: the range of what the rows store."""
+    t = scores36
+    if any(t[b * 6 + 5] != t[5] for b in range(1, 5)) or any(t[b * 6 + 5] > 0 or t[5 * 6 + b] > 0 for b in range(5)):
+        return False
+    ent = [t[x * 6 + y] for x in range(6) for y in range(6) if not (x == 5 and y == 5)]
+    sub = [t[x * 6 + y] for x in range(5) for y in range(5)]
+    maxabs = max(abs(v) for v in ent)
+    if maxabs > 1000:
+        return False
+    g, rows, n = t[5], max_path_rows + 2, max_n + 2
+    zlo = rows * g - n * max(0, g - min(sub))
+    zhi = n * max(0, max(sub) - g)
+    return zlo >= -29000 and zhi <= 29000 and zhi - zlo <= 32000 and (rows + n) * maxabs <= 32000 and (C // 2 + 2) * maxabs <= 2000
+
+
+def test_scores_at_the_edge_of_the_16_bit_budget(oracle):
+    """`sweep16_admissible` since round 5 bounds what the rows STORE (z = A - c g), not A: -X 6 / -X 7 and -M 3 -X 5 at 1 kbp run
+    packed, -X 8 does not; shorter reads admit larger scores.  Every case prints the oracle's bytes on whichever side of the line
+    it falls, and the kernel statistics say which sweep ran — the one the rule (restated above) predicts."""
+    from recgraph_amd import api, synth
+    cases = ((9000, 12, 1000, (2, -6)), (9000, 12, 1000, (3, -5)), (9000, 12, 1000, (2, -7)), (9000, 12, 1000, (2, -8)),
+             (4500, 8, 500, (2, -14)), (4500, 8, 500, (2, -16)), (4500, 8, 500, (5, -3)))
+    seen = set()
+    for rows, P, plen, (m, x) in cases:
+        g = synth.haplotype_graph(rows, P, path_len=plen, seed=400 + plen + abs(x))
+        rd = synth.haplotype_reads(g, 7, length=plen, seed=401 + abs(x), mosaic_frac=0.6) + [g.path_sequence(P - 1)[:plen]]
+        sm = api.create_score_matrix_i32(m, x)
+        osc = oracle.scores_from_dict({k: int(v) for k, v in sm.items()})
+        gg = api.Graph.from_gfa_text(g.gfa())
+        og = oracle.Graph.from_gfa_text(g.gfa())
+        path_rows = max(len(lst.split(",")) for lst in gg.dump(30).strip(";").split(";") if lst)
+        n = max(len(r) for r in rd)
+        C = 4
+        while C * 64 < n + 1 and C < 32:
+            C *= 2
+        packed = _sweep16_admissible(osc, path_rows, n, C)
+        seen.add(packed)
+        names = ["q%d" % i for i in range(len(rd))]
+        for mode, om in ((api.MODE_RECOMBINATION, oracle.M8_ABS), (api.MODE_PATHWISE, oracle.M4_ABS)):
+            b = api.Batch(gg, rd, api.make_params(mode, score_matrix=sm))
+            b.run()
+            b.fetch()
+            ks = b.kernel_stats()
+            assert any(k.startswith("k_sweep16") for k in ks) == packed and any(k.startswith("k_sweep_") for k in ks) == (not packed), (m, x, plen, path_rows, sorted(ks))
+            for i, r in enumerate(rd):
+                exp = og.align(om, r, name=names[i], idx=i + 1, scores=osc)[0]
+                assert b.gaf_text(i, names[i], i + 1) == exp, (m, x, plen, mode, i)
+    assert seen == {True, False}
+    assert _sweep16_admissible(oracle.scores_match_mis(2, -6), 1000, 1000, 16) and not _sweep16_admissible(oracle.scores_match_mis(2, -8), 1000, 1000, 16)
+
+
 def test_packed_opt0_equals_the_i32_form(oracle):
     """`k_opt0_16` (the speculative / provable forward bound on packed rows) against `k_opt0` on every read: the bound only
     steers the pruning — a wrong one would cost speed or a second pass, never bytes — so the driver's RG_DEBUG mode runs both
@@ -340,7 +392,11 @@ def test_random_dag_graphs_in_every_switch_family(oracle):
              (("no_pick2", 1), ("spec_margin", 0)), (("no_retire", 3), ("no_split", 1)),
              # evaluation every 16 / 4 records: graphs of this size only retire paths with a short period
              (("retire_shift", 4), ("spec_margin", 0)), (("retire_shift", 3), ("no_split", 1)), (("retire_shift", 4), ("no_retire", 2)),
-             (("retire_shift", 4), ("no_retire", 3)), (("retire_shift", 4), ("no_gather", 1)), (("retire_shift", 4), ("no_pick2", 1)))
+             (("retire_shift", 4), ("no_retire", 3)), (("retire_shift", 4), ("no_gather", 1)), (("retire_shift", 4), ("no_pick2", 1)),
+             # the i32 sweep's own path retirement and speculative bound (round 5)
+             (("sweep_i32", 1), ("retire_shift", 4)), (("sweep_i32", 1), ("retire_shift", 3), ("spec_margin", 0)), (("sweep_i32", 1), ("no_retire", 1)),
+             (("sweep_i32", 1), ("retire_shift", 4), ("no_retire", 2)), (("sweep_i32", 1), ("retire_shift", 4), ("no_retire", 3)),
+             (("sweep_i32", 1), ("retire_shift", 4), ("no_spec", 1)), (("sweep_i32", 1), ("retire_shift", 2), ("no_order", 1)))
     defaults = {"spec_margin": SPEC_MARGIN_DEFAULT, "retire_shift": 8}
     for nseg, P, seed, kw in cases:
         g = synth.random_dag_graph(nseg, P, seed=seed, **kw)

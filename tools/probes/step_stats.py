@@ -30,7 +30,7 @@ while t < len(recs):
         R = field
         if nm <= KRUN:
             kind = "regrun_nm%d" % nm
-        elif R * (77 * (nm - 1) - 160) >= 200 * (nm - 1):
+        elif R * (84 * (nm - 1) - 160) >= 90 * (nm - 1):          # (RG_GATHER_PER_* of rg_sweep16.hip)
             kind = "gather"
         else:
             kind = "general_inner"
