@@ -469,11 +469,15 @@ __global__ __launch_bounds__(kStripes ? 512 : 64, kStripes ? 1 : RG_SWEEP_WAVES)
         cells += (unsigned long long)nm;
         // (path retirement: the members still computed; a group whose members are all retired — its alpha with them — is skipped)
         const unsigned long long gm = (!kStripes && next_eval != INT32_MAX) ? (gmask & needed) : gmask;
-        if (gm != 0ull) {
+        // (kStripes: the striped instantiations keep the exact control flow they had before the retirement was added — with the
+        // skip, the `i != srow` set-up and `row_has` compiled in, k_sweep<32, true, true> (691 spilled VGPRs, 325 spilled SGPRs)
+        // returned sink values 12 too low while every direction word stayed right: tests/test_gpu_pathwise.py::
+        // test_reads_longer_than_2047_bases at stripe_c = 32; the narrower stripes were unaffected)
+        if (kStripes || gm != 0ull) {
         // ---- general (row, group) step ----
         const int g_i = __builtin_amdgcn_readfirstlane(sct[li * 6 + GAP]);
         const int g0 = a.semi ? 0 : g_i;
-        if ((flags & F_FIRST) || i != srow) {
+        if (kStripes ? (flags & F_FIRST) != 0 : ((flags & F_FIRST) || i != srow)) {
 #pragma unroll
             for (int q = 0; q < C; ++q) { s[q] = sct[li * 6 + (int)((erp[q / 16] >> (4 * (q % 16))) & 7)]; bkey[q] = INT32_MIN; }
             srow = i;
@@ -532,7 +536,7 @@ __global__ __launch_bounds__(kStripes ? 512 : 64, kStripes ? 1 : RG_SWEEP_WAVES)
         }
         }
         if (semi_end && (flags & F_LAST)) end_row_done(i);
-        if (track && (flags & F_LAST) && row_has) row_end(i, ((w1 >> 20) & 511) - 1, bkey);
+        if (track && (flags & F_LAST) && (kStripes || row_has)) row_end(i, ((w1 >> 20) & 511) - 1, bkey);
         if (flags & F_LAST) row_has = false;
         ++t;
     }

@@ -434,13 +434,19 @@ def test_kilobase_reads_on_nested_bubbles(oracle):
         names = ["r%d" % i for i in range(len(rd))]
         base = _check(oracle, g.gfa(), rd, api.MODE_RECOMBINATION, oracle.M8_ABS)
         _check(oracle, g.gfa(), rd[:3], api.MODE_PATHWISE, oracle.M4_ABS)
-        for name, val in (("spec_margin", 0), ("no_split", 1), ("no_gather", 1)):
+        # (32 columns per lane when the reads exceed 1023 bases: the packed record variant with register runs of two rows and
+        # path retirement, and — sweep_i32 — the i32 sweep's one-wave form with its own retirement; every 16 records here)
+        defaults = {"spec_margin": SPEC_MARGIN_DEFAULT, "retire_shift": 8}
+        for combo in ((("spec_margin", 0),), (("no_split", 1),), (("no_gather", 1),), (("retire_shift", 4),), (("retire_shift", 4), ("spec_margin", 0)),
+                      (("sweep_i32", 1),), (("sweep_i32", 1), ("retire_shift", 4)), (("no_retire", 1),)):
             try:
-                api.set_option(name, val)
+                for name, val in combo:
+                    api.set_option(name, val)
                 texts, _ = api.align_batch(gg, rd, names, mode=api.MODE_RECOMBINATION)
             finally:
-                api.set_option(name, SPEC_MARGIN_DEFAULT if name == "spec_margin" else 0)
-            assert texts == base, (P, name)
+                for name, _ in combo:
+                    api.set_option(name, defaults.get(name, 0))
+            assert texts == base, (P, combo)
 
 
 def test_three_sweep_pipeline(oracle):
