@@ -70,7 +70,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-probe", action="store_true", help="skip the probe steps (kernel durations then come from the timed region)")
     ap.add_argument("--sweep-i32", action="store_true", help="force the i32 sweep kernel (rg_set_option sweep_i32)")
     ap.add_argument("--no-strong", action="store_true", help="skip the strong_100k region (N > 1) / the strong_proxy region (N = 1)")
-    ap.add_argument("--strong-ramp", type=int, default=0, help="first tiles of a share cut in two, a short one first (shard.even_tiles)")
+    ap.add_argument("--strong-ramp", type=int, default=1, help="first tiles of a share cut in two, a short one first (shard.even_tiles): the handles start out of phase, so the fill of a short tile sequence costs less (12 800 reads on one GPU: 126 ms with one ramp tile against 139 ms without, profiles/r05_notes.md)")
     ap.add_argument("--strong-tile", type=int, default=0, help="largest tile of a rank's share in the strong regions (default: see STRONG_TILE)")
     return ap.parse_args(argv)
 
@@ -705,7 +705,7 @@ def main():
     if args.scaling == "weak" and dist_on and not args.no_strong:
         tb = DISTINCT_BATCHES
         spans = [shard_bounds(tb * batch, r, world) for r in range(world)]
-        tpr = [len(even_tiles(b - a, strong_tile)) for a, b in spans]
+        tpr = [len(even_tiles(b - a, strong_tile, args.strong_ramp)) for a, b in spans]
         s_tiles, _ = share_tiles(tb, *spans[rank], ramp=args.strong_ramp, max_tile=strong_tile)
         sres = timed_region(s_tiles, max(tpr))
         strong = {"reads": sres["reads_all"], "reads_per_s": round(sres["reads_all"] / sres["dt"], 2), "ms": round(sres["dt"] * 1e3, 2),

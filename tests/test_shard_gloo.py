@@ -89,8 +89,10 @@ def test_bench_launcher_runs_the_world_2_path():
     # the stated target beside the headline, in the same run (the driver passes no flags): the 25 x 64 canonical reads split
     # EVENLY over the ranks (reads, not tiles), even tiles of at most 64 reads
     s100 = weak["strong_100k"]
-    assert s100["reads"] == 25 * 64 and s100["reads_per_rank"] == [800, 800] and s100["tiles_per_rank"] == [13, 13]
-    assert sum(s100["tile_reads"]) == 800 and max(s100["tile_reads"]) - min(s100["tile_reads"]) <= 1 and s100["reads_per_s"] > 0
+    # (13 even tiles, the first cut in two — a short one first — so that the handles start out of phase: --strong-ramp 1)
+    assert s100["reads"] == 25 * 64 and s100["reads_per_rank"] == [800, 800] and s100["tiles_per_rank"] == [14, 14]
+    assert sum(s100["tile_reads"]) == 800 and max(s100["tile_reads"]) <= 64 and s100["tile_reads"][0] < s100["tile_reads"][1] and s100["reads_per_s"] > 0
+    assert max(s100["tile_reads"][2:]) - min(s100["tile_reads"][2:]) <= 1
     # --scaling strong: the steps x batch reads of the N = 1 run split evenly: 192 reads -> 96 per rank -> two tiles of 48
     tile = lambda k: sum(len("read%d\t" % i) + 16 + 1 for i in range(k))
     strong = _run_bench(["--gpus", "2", "--scaling", "strong"], {})
