@@ -30,6 +30,18 @@ def test_headline_sweep_variants_use_no_scratch():
             assert k["ScratchSize [bytes/lane]"] == 0, (c, v, k)
 
 
+def test_no_valu_write_into_a_wide_buffer_store_in_flight():
+    """The gfx950 hazard of round 5 (rg_sweep16.hip, st_row): no buffer_store_dwordx3/x4 of any k_sweep16 variant has its
+    data registers overwritten by the instruction behind it — and the scan itself still finds the pattern when the s_nop
+    is compiled out."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import kernel_resources
+    hits, stores = kernel_resources.store_hazards("rg_sweep16.hip")
+    assert stores > 100 and not hits, hits[:4]
+    hits, _ = kernel_resources.store_hazards("rg_sweep16.hip", ["-DRG_SWEEP16_NO_STORE_NOP"])
+    assert any("k_sweep16<16, 0, false, false, false>" in h[0] for h in hits), hits[:4]
+
+
 def test_poa_kernels_use_no_scratch():
     """`k_m0_simd` and `k_poa_banded` keep the previous row's chunks in registers — the compiler once fused the select chains
     that pick a chunk into a dynamically indexed vector it kept in scratch (32 / 48 bytes per lane, dependent scratch loads in

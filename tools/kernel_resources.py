@@ -4,6 +4,8 @@
     python3 tools/kernel_resources.py [file.hip ...] [-D...]      # default: rg_sweep16.hip; extra -D flags go to hipcc
     python3 tools/kernel_resources.py --isa [file.hip] [kernel name part ...] [-D...] [--json=out.json]
                                                                   # issue-class histogram of the kernels' loops (see isa_report)
+    python3 tools/kernel_resources.py --hazards [file.hip ...] [-D...]
+                                                                  # wide buffer stores whose data registers the NEXT instruction overwrites
 
 Prints one line per kernel: VGPRs, spilled VGPRs / SGPRs, scratch bytes per lane, occupancy.  tests/test_kernel_resources.py
 asserts that the headline variants of k_sweep16 use no scratch."""
@@ -163,7 +165,58 @@ def isa_main(argv):
         json.dump(allr, open(js, "w"), indent=1)
 
 
+def _vregs(tok):
+    m = re.match(r"v\[(\d+):(\d+)\]", tok)
+    if m:
+        return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    m = re.match(r"v(\d+)$", tok)
+    return {int(m.group(1))} if m else set()
+
+
+def store_hazards(src, defines=()):
+    """gfx950: a VALU write to the data registers of a buffer_store_dwordx3/x4 within the ONE wait state behind it corrupts
+    the store — also when the store's scalar offset is an SGPR, the case LLVM's hazard recognizer exempts (found in round 5:
+    rg_sweep16.hip, st_row).  Returns [(kernel, line, store, overwriting instruction)] over every kernel of `src`; the
+    kernels keep an `s_nop` behind such stores, so the list must be empty."""
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "k.s")
+        cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off", "--cuda-device-only", "-S",
+               os.path.join(CSRC, src), "-o", out] + list(defines)
+        subprocess.run(cmd, capture_output=True, text=True, cwd=CSRC, check=True)
+        text = open(out).read().split("\n")
+    hits, cur, stores = [], None, 0
+    for i, ln in enumerate(text):
+        m = re.match(r"^(_Z[A-Za-z0-9_]+):", ln)
+        if m:
+            cur = m.group(1)
+        t = ln.strip()
+        if not t.startswith(("buffer_store_dwordx4", "buffer_store_dwordx3")):
+            continue
+        stores += 1
+        data = _vregs(t.split()[1].rstrip(","))
+        j = i + 1
+        while j < len(text):      # the next INSTRUCTION (labels, comments and directives are not wait states)
+            u = text[j].split(";")[0].strip()
+            j += 1
+            if not u or u.startswith(".") or u.endswith(":"):
+                continue
+            if u.startswith("v_") and _vregs(u.split()[1].rstrip(",")) & data:
+                hits.append((cur, i + 1, t, u))
+            break
+    names = demangle(sorted({h[0] for h in hits}))
+    return [(names.get(k, k), ln, st, u) for k, ln, st, u in hits], stores
+
+
 def main():
+    if "--hazards" in sys.argv:
+        files = [a for a in sys.argv[1:] if not a.startswith("-")] or ["rg_sweep16.hip"]
+        defs = [a for a in sys.argv[1:] if a.startswith("-D")]
+        for f in files:
+            hits, stores = store_hazards(f, defs)
+            print("%s: %d wide buffer stores, %d with their data overwritten by the next instruction" % (f, stores, len(hits)))
+            for h in hits:
+                print("  %s  line %d: %s  ||  %s" % h)
+        return
     if "--isa" in sys.argv:
         return isa_main([a for a in sys.argv[1:] if a != "--isa"])
     files = [a for a in sys.argv[1:] if not a.startswith("-")] or ["rg_sweep16.hip"]
