@@ -143,9 +143,12 @@ struct RowOps16 {
     }
 
     // kMove: pure data movement (no step added): what a gather run applies to its column map
+    // A member update is two passes over the row with ONE cross-lane fetch between them (the z of the nearest non-L column to
+    // the left: a ds_bpermute, ~100 cycles before its result can be used).  The passes are separate functions so that a group
+    // of several members issues every fetch before it waits for the first (the register runs, round 5).
     template <bool kMove = false>
-    static __device__ __forceinline__ void member(int (&row)[H], const int (&SEL)[H], int lane,
-                                                  const int (&MU)[H], const int (&ML)[H], unsigned lmask, int src) {
+    static __device__ __forceinline__ void member_p1(int (&row)[H], const int (&SEL)[H], const int (&MU)[H], const int (&ML)[H], unsigned lmask,
+                                                     int& zl, int& v_lo) {
         int prev = __builtin_amdgcn_alignbit(row[H - 1], dpp_shr1(row[H - 1], NEGPAIR), 16);
         int lastv = NEGPAIR;                                        // z of the last non-L column of each half
 #pragma unroll
@@ -159,9 +162,12 @@ struct RowOps16 {
         // z of the lane's last non-L column, fetched by the lanes to the right that start with L columns
         const unsigned nl = ~lmask & FULL;
         const unsigned nl_lo = nl & 0xffffu, nl_hi = nl >> 16;
-        const int v_lo = lo16(lastv), v_hi = hi16(lastv);
-        const int zl = nl_hi ? v_hi : (nl_lo ? v_lo : NEG32);
-        const int cur = __shfl(zl, src, WAVE);
+        v_lo = lo16(lastv);
+        const int v_hi = hi16(lastv);
+        zl = nl_hi ? v_hi : (nl_lo ? v_lo : NEG32);
+    }
+    static __device__ __forceinline__ void member_p2(int (&row)[H], const int (&ML)[H], unsigned lmask, int cur, int v_lo) {
+        const unsigned nl_lo = ~lmask & FULL & 0xffffu;
         const int bl = max(cur, NEG16);
         const int bh = nl_lo ? max(v_lo, NEG16) : bl;
         int vprev = pack16(bl, bh);
@@ -171,6 +177,13 @@ struct RowOps16 {
             row[r] = v;
             vprev = v;
         }
+    }
+    template <bool kMove = false>
+    static __device__ __forceinline__ void member(int (&row)[H], const int (&SEL)[H], int lane,
+                                                  const int (&MU)[H], const int (&ML)[H], unsigned lmask, int src) {
+        int zl, v_lo;
+        member_p1<kMove>(row, SEL, MU, ML, lmask, zl, v_lo);
+        member_p2(row, ML, lmask, __shfl(zl, src, WAVE), v_lo);
     }
 };
 
@@ -202,6 +215,9 @@ struct RowOps16 {
 #endif
 #ifndef RG_SWEEP16_RUNWAIT
 #define RG_SWEEP16_RUNWAIT 1
+#endif
+#ifndef RG_SWEEP16_PROFILE_AHEAD
+#define RG_SWEEP16_PROFILE_AHEAD 0    // register runs: the next row's score profile is read from LDS behind this row's member steps
 #endif
 #ifndef RG_SWEEP16_CHAIN
 // chained register runs: next run's loads before this run's stores (see CHAINED RUNS).  1: in the -m 4 / -m 5 variant only
@@ -259,6 +275,18 @@ __global__ __launch_bounds__(64, C > 16 ? 2 : (kColmax != 0 ? RG_SWEEP16_FWD_WAV
     // rows kept in registers across the inner rows of a segment: groups of up to 4 paths (2 at 32 columns per lane: a row is 16 registers there)
     constexpr int KRUN = C <= 16 ? (kColmax != 0 ? RG_SWEEP16_KRUN : RG_SWEEP16_KRUN_REV) : ((kRec && kColmax == 0 && !kWide) ? 2 : 0);
     const int rd = a.order ? a.order[blockIdx.x] : blockIdx.x;      // (launch order: see launch_order)
+#ifdef RG_SWEEP16_STALLSTAT
+    // (statistics build, tools/probes/stall_stat.py: shader-clock cycles a wave spends in the waits for row loads; the cell
+    // counters carry  total >> 8 | general-path waits >> 8 << 32  and  run-start waits >> 8 | run starts << 32)
+    const unsigned long long st_t0 = __builtin_amdgcn_s_memtime();
+    unsigned long long st_run = 0, st_nrun = 0, st_gen = 0;
+#define RG_STALL_BEGIN() const unsigned long long st_b = __builtin_amdgcn_s_memtime()
+#define RG_STALL_END(acc) do { __builtin_amdgcn_s_waitcnt(0x0F70); acc += __builtin_amdgcn_s_memtime() - st_b; } while (0)
+#define RG_STALL_END_LGKM(acc) do { __builtin_amdgcn_s_waitcnt(0xC07F); acc += __builtin_amdgcn_s_memtime() - st_b; } while (0)
+#else
+#define RG_STALL_BEGIN() ((void)0)
+#define RG_STALL_END(acc) ((void)0)
+#endif
     const int lane = threadIdx.x;
     const PathGraphDev& g = a.g;
     const int P = g.P;
@@ -945,6 +973,9 @@ __global__ __launch_bounds__(64, C > 16 ? 2 : (kColmax != 0 ? RG_SWEEP16_FWD_WAV
 #pragma unroll
             for (int r = 0; r < H; ++r) A[r] = 0;
             ld_row(ka, A);            // (the rolling row itself keeps the run-start values until phase (3) stores the new ones)
+#if defined(RG_SWEEP16_STALLSTAT) && RG_SWEEP16_STALLSTAT == 2
+            { RG_STALL_BEGIN(); RG_STALL_END(st_run); ++st_nrun; }
+#endif
             // (1) best (delta, path) per column over the members at the run start; ties -> highest path id: members in
             // ascending order, a later one replaces on >=.  Packed: delta = row_k - A0 (saturating: |delta| fits, gather_ok)
 #ifndef RG_G_NOPH1
@@ -1151,20 +1182,39 @@ __global__ __launch_bounds__(64, C > 16 ? 2 : (kColmax != 0 ? RG_SWEEP16_FWD_WAV
 #if RG_SWEEP16_RUNWAIT
             // wait for the run's rows HERE: otherwise the compiler's wait sits at the top of the row loop as vmcnt(0) (one
             // counter for loads and stores on gfx9) and every row also waits for the direction-word store of the row before
-            __builtin_amdgcn_s_waitcnt(0x0F70);
+            {
+                RG_STALL_BEGIN();
+                __builtin_amdgcn_s_waitcnt(0x0F70);
+#if defined(RG_SWEEP16_STALLSTAT) && RG_SWEEP16_STALLSTAT == 1
+                RG_STALL_END(st_run); ++st_nrun;
+#endif
+            }
+#endif
+#if defined(RG_SWEEP16_STALLSTAT) && RG_SWEEP16_STALLSTAT == 3
+            const unsigned long long st_rb = __builtin_amdgcn_s_memtime();
 #endif
             int ri = i, rli = li, rslot = slot, rw1 = w1, rfl = 7;
             int rleft = run_left;               // rows left in the counted run, this one included (the record's run field)
             bool tail = false;
+            // The row's score profile (two 16-byte LDS reads per lane, ~100 cycles before the diagonal step can use them) is
+            // fetched a row AHEAD: a record whose run field counts more rows than itself is followed by the next inner row of
+            // its run, so its profile row is known — and `s` is dead — as soon as the members have their steps.
+            // (not at 32 columns per lane: a row is 16 registers there and the variant is out of them)
+            constexpr bool kAhead = RG_SWEEP16_PROFILE_AHEAD && C <= 16;
+            int s[H];
+            if (kAhead) load_steps(rli, s);
             for (;;) {          // (chained runs)
             tail = false; rfl = 7;
             while (true) {
                 const int g_i = gcost;
                 const int g0 = kSemi ? 0 : g_i;
-                int s[H], MU[H], ML[H];
+                int MU[H], ML[H];
                 unsigned lmask;
                 int src;
-                load_steps(rli, s);
+#if defined(RG_SWEEP16_STALLSTAT) && RG_SWEEP16_STALLSTAT == 3
+                ++st_nrun;
+#endif
+                if (!kAhead) load_steps(rli, s);
                 unsigned umask;
                 // (at 32 columns per lane `src` stays unconditional: the branch costs that variant 54 more spilled registers)
                 RowOps16<C>::alpha(rr[0], s, g_i, g0, lane, MU, ML, umask, lmask, src, C > 16 || rnm > 1);
@@ -1174,9 +1224,19 @@ __global__ __launch_bounds__(64, C > 16 ? 2 : (kColmax != 0 ? RG_SWEEP16_FWD_WAV
                     // by `kk < rnm` the compiler carried its eight registers around the whole record loop)
                     int SEL[H];
                     RowOps16<C>::select_steps(SEL, s, MU, g_i, g0, lane);
+                    // every member's first pass and cross-lane fetch before the first wait (see member_p1)
+                    int zl[KRUN > 0 ? KRUN : 1], vlo[KRUN > 0 ? KRUN : 1];
 #pragma unroll
                     for (int kk = 1; kk < KRUN; ++kk)
-                        if (kk < rnm) RowOps16<C>::member(rr[kk], SEL, lane, MU, ML, lmask, src);
+                        if (kk < rnm) { RowOps16<C>::member_p1(rr[kk], SEL, MU, ML, lmask, zl[kk], vlo[kk]); zl[kk] = __shfl(zl[kk], src, WAVE); }
+#pragma unroll
+                    for (int kk = 1; kk < KRUN; ++kk)
+                        if (kk < rnm) RowOps16<C>::member_p2(rr[kk], ML, lmask, zl[kk], vlo[kk]);
+                }
+                if (kAhead && !tail && rleft > 1) {
+                    const int tn = t + 1;
+                    if ((tn >> 6) != blk) to_block(tn >> 6);
+                    load_steps((__builtin_amdgcn_readlane(recs.x, tn & (WAVE - 1)) >> 20) & 7, s);
                 }
                 cells += (unsigned long long)__popcll(rgm);
                 done += (unsigned long long)rnm;
@@ -1280,6 +1340,7 @@ __global__ __launch_bounds__(64, C > 16 ? 2 : (kColmax != 0 ? RG_SWEEP16_FWD_WAV
                 ri = nw0 & 0xfffff; rli = (nw0 >> 20) & 7; rslot = nw1 & 0xfffff; rw1 = nw1;
                 tail = to_tail; rfl = nf;
                 rleft = to_tail ? 0 : (nw0 >> 26) & 63;
+                if (kAhead) load_steps(rli, s);
             }
             // ---- the run (and its tail) is over: rows in rr, t = the next record
             if (tail) {
@@ -1325,6 +1386,7 @@ __global__ __launch_bounds__(64, C > 16 ? 2 : (kColmax != 0 ? RG_SWEEP16_FWD_WAV
                 fetch(t, nw0, nw1, ngm);
                 ri = nw0 & 0xfffff; rli = (nw0 >> 20) & 7; rslot = nw1 & 0xfffff; rw1 = nw1;
                 rleft = (nw0 >> 26) & 63;
+                if (kAhead) load_steps(rli, s);
             }
             }                   // (chained runs)
 #ifdef RG_SWEEP16_KRUNNOST
@@ -1334,6 +1396,9 @@ __global__ __launch_bounds__(64, C > 16 ? 2 : (kColmax != 0 ? RG_SWEEP16_FWD_WAV
 #pragma unroll
             for (int kk = 0; kk < KRUN; ++kk)
                 if (kk < rnm) RG_ROW_ST(mk[kk], rr[kk]);
+#endif
+#if defined(RG_SWEEP16_STALLSTAT) && RG_SWEEP16_STALLSTAT == 3
+            st_gen += __builtin_amdgcn_s_memtime() - st_rb;
 #endif
             continue;           // (a tail's epilogue ran above)
         } else {
@@ -1377,6 +1442,9 @@ __global__ __launch_bounds__(64, C > 16 ? 2 : (kColmax != 0 ? RG_SWEEP16_FWD_WAV
                 for (int r = 0; r < H; ++r) rowa[r] = s[r];
 #endif
                 RG_ROW_LD(ga, rowa);
+#if defined(RG_SWEEP16_STALLSTAT) && RG_SWEEP16_STALLSTAT == 1
+                { RG_STALL_BEGIN(); RG_STALL_END(st_gen); }
+#endif
                 unsigned umask;
                 RowOps16<C>::alpha(rowa, s, g_i, g0, lane, MU, ML, umask, lmask, src);
                 RG_ROW_ST(ga, rowa);
@@ -1462,6 +1530,14 @@ __global__ __launch_bounds__(64, C > 16 ? 2 : (kColmax != 0 ? RG_SWEEP16_FWD_WAV
         // counted: every member row of the table (what the reference updates) — from the table builder when records may have
         // been jumped over; performed: what this wave carried out
         const unsigned long long all = kRet && a.table_members ? a.table_members : cells;
+#ifdef RG_SWEEP16_STALLSTAT
+        {
+            const unsigned long long tot = __builtin_amdgcn_s_memtime() - st_t0;
+            atomicAdd(a.cells, (tot >> 8) | ((st_gen >> 8) << 32));
+            atomicAdd(a.cells + 1, (st_run >> 8) | (st_nrun << 32));
+            return;
+        }
+#endif
 #ifdef RG_SWEEP16_RETSTAT
         if (kRet) { atomicAdd(a.cells, stat_e | (stat_n << 32)); atomicAdd(a.cells + 1, stat_h | ((unsigned long long)(rev ? 0 : 1) << 48)); return; }
 #endif

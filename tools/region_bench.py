@@ -32,6 +32,7 @@ def main():
     from oracle import oracle as O
     names = [a for a in sys.argv[1:] if not a.startswith("-")] or list(CASES)
     check = 3
+    handles = int(os.environ.get("RG_REGION_HANDLES", "3"))      # (1: the kernels' lone durations)
     for name in names:
         mode, rows, paths, rlen, sk, tile, tiles = CASES[name]
         g = synth.haplotype_graph(rows, paths, path_len=rlen, seed=1234)
@@ -45,7 +46,7 @@ def main():
         params = api.make_params(mode, score_matrix=sm)
         sets = [api.Batch.pack_reads(synth.haplotype_reads(g, tile, length=rlen, seed=900 + k, mosaic_frac=0.5 if mode == 8 else 0.0)) for k in range(min(tiles, 3))]
         first_reads = synth.haplotype_reads(g, tile, length=rlen, seed=900, mosaic_frac=0.5 if mode == 8 else 0.0)[:check]
-        st = api.Stream(gg, params, device_ids=[0], handles_per_device=3, tile_reads=tile)
+        st = api.Stream(gg, params, device_ids=[0], handles_per_device=handles, tile_reads=tile)
         for k in range(3):
             st.push(sets[k % len(sets)])
         for k in range(3):
@@ -71,7 +72,7 @@ def main():
         cu = sum(t.cell_updates for t in got)
         cp = sum(t.cell_updates_performed for t in got)
         print(json.dumps({"case": name, "mode": mode, "rows": gg.rows, "paths": paths, "read_len": rlen, "scores": sk or "default",
-                          "tile_reads": tile, "tiles": tiles, "reads_per_s": round(tile * tiles / dt, 1), "ms_per_tile": round(dt / tiles * 1e3, 2),
+                          "tile_reads": tile, "tiles": tiles, "handles": handles, "reads_per_s": round(tile * tiles / dt, 1), "ms_per_tile": round(dt / tiles * 1e3, 2),
                           "cell_updates_per_s": round(cu / dt), "performed_over_counted": round(cp / cu, 3) if cu else None, "sweep_kernels": sweeps, "kernel_ms_per_tile": ks, "parity_checked": check if ok else "FAILED"}), flush=True)
 
 
