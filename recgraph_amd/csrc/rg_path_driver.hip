@@ -391,7 +391,7 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
             sa.use_split = w.have_split && sa.gather_ok && !semi && C <= 16 && !opt.no_split ? 1 : 0;
             // path retirement: the record pipelines of -m 8 (global), P <= 64
             sa.flead = w.flead.p; sa.rlead = w.rlead.p; sa.fslead = w.fslead.p; sa.rslead = w.rslead.p;
-            sa.retire = (use16 || nwv == 1) && P <= 64 && !semi && mode == RG_MODE_RECOMBINATION && gaps_nonpos && opt.no_retire != 1 ? 1 : 0;   // (round 5: the one-wave i32 sweep too)
+            sa.retire = (use16 || nwv == 1 || C <= 16) && P <= 64 && !semi && mode == RG_MODE_RECOMBINATION && gaps_nonpos && opt.no_retire != 1 ? 1 : 0;   // (round 5: the i32 sweep too — one wave, or stripes of <= 16 columns per lane)
             sa.retire_shift = w.retire_shift;
             sa.fmembers = w.fmembers; sa.rmembers = w.rmembers;
             sa.maxmatch = maxmatch;      // (both sweeps: the retirement bound; the forward sweep's speculative thresholds)

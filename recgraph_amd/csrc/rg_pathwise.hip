@@ -254,11 +254,28 @@ __global__ __launch_bounds__(kStripes ? 512 : 64, kStripes ? 1 : RG_SWEEP_WAVES)
     // whose every future cell is provably below every threshold is hopeless — forward: max_j (A[j] + mmx (n - j)) < lb;
     // reverse: A[j] + mmx j < min_{j' <= j} (thr[j'] + mmx j') for every j — and stops being computed unless it still
     // leads a group with a needed member (lead tables of the plain step table).  The per-column constants wait in LDS.
-    int* rvc = g_lds + 64 + 2 * RG_MAXP;             // [C][64] (the launcher allocates them for the one-wave variants)
+    // STRIPES (stripes of <= 16 columns per lane): every stripe sees its own columns only, and the stripes of a read must
+    // skip exactly the same records (their FIFOs carry one entry per row update).  So a decision is taken from what ALL
+    // stripes published — at evaluation point e every stripe writes, per needed path, the maximum of (row + constant) over
+    // its columns into rt_val[e][stripe][path] — and it is applied two points later, by which time the slowest stripe has
+    // published (a stripe runs at most 64 row updates behind its left neighbour: the FIFO's capacity; the counters below make
+    // that a wait, not an assumption).  Hopeless stays hopeless, so a late decision is still a correct one; the closure uses
+    // the lead table of the point it is applied at.
+    constexpr bool kRetOK = !kStripes || C <= 16;     // (k_sweep<32, true, true> keeps the control flow it had: see below)
+    constexpr bool kOld = kStripes && !kRetOK;
+    constexpr int RT_SLOTS = 4, RT_LAG = 2;
+    int* rt_base = fifo_lds + 8 * (FIFO_WORDS + 2);                 // stripes only: [pub 4 | app 4 | smin 8 | val 4 x 8 x 64]
+    unsigned* rt_pub = (unsigned*)rt_base;
+    unsigned* rt_app = rt_pub + RT_SLOTS;
+    int* rt_smin = rt_base + 2 * RT_SLOTS;
+    int* rt_val = rt_smin + 8;
+    int* rvc = kStripes ? rt_val + RT_SLOTS * 8 * WAVE + wv * C * WAVE : g_lds + 64 + 2 * RG_MAXP;   // [C][64] of this wave
     int next_eval = INT32_MAX;
     unsigned long long needed = P >= 64 ? ~0ull : ((1ull << P) - 1ull);
-    if (!kStripes && a.retire && !a.semi && P <= 64 && (rev ? a.thr != nullptr && a.rlead != nullptr : a.lb != nullptr && a.flead != nullptr)) {
+    unsigned long long hop_all = 0;      // (stripes) every path found hopeless so far
+    if (kRetOK && a.retire && !a.semi && P <= 64 && (rev ? a.thr != nullptr && a.rlead != nullptr : a.lb != nullptr && a.flead != nullptr)) {
         const int mmx = max(a.maxmatch, 0);
+        if (kStripes && wl < 2 * RT_SLOTS && wv == 0) rt_pub[wl] = 0u;
         if (!rev) {
             const int lbv = a.lb[rd];
 #pragma unroll
@@ -276,9 +293,17 @@ __global__ __launch_bounds__(kStripes ? 512 : 64, kStripes ? 1 : RG_SWEEP_WAVES)
             }
             int suf = ltot;
 #pragma unroll
-            for (int d = 1; d < WAVE; d <<= 1) { const int o = __shfl_down(suf, d, WAVE); if (lane + d < WAVE) suf = min(suf, o); }
+            for (int d = 1; d < WAVE; d <<= 1) { const int o = __shfl_down(suf, d, WAVE); if (wl + d < WAVE) suf = min(suf, o); }
             int run = __shfl_down(suf, 1, WAVE);
-            if (lane == WAVE - 1) run = INT32_MAX;
+            if (wl == WAVE - 1) run = INT32_MAX;
+            if (kStripes) {
+                // ... and the columns of the stripes to the right
+                if (wl == 0) rt_smin[wv] = suf;
+                __syncthreads();
+                int right = INT32_MAX;
+                for (int w2 = wv + 1; w2 < nwv; ++w2) right = min(right, rt_smin[w2]);
+                run = min(run, right);
+            }
 #pragma unroll
             for (int q = C - 1; q >= 0; --q) {
                 run = min(run, tq[q]);
@@ -448,11 +473,49 @@ __global__ __launch_bounds__(kStripes ? 512 : 64, kStripes ? 1 : RG_SWEEP_WAVES)
         }
         needed = nd;
     };
+    auto rt_wait = [&](unsigned* cnt, unsigned want) {
+        if (wl == 0) while (__hip_atomic_load(cnt, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < want) __builtin_amdgcn_s_sleep(1);
+    };
+    auto retire_eval_striped = [&](int e) {
+        // (1) apply what every stripe published at point e - RT_LAG
+        const int eo = e - RT_LAG;
+        if (eo >= 1) {
+            const int so = (eo - 1) % RT_SLOTS, go = (eo - 1) / RT_SLOTS;
+            rt_wait(rt_pub + so, (unsigned)(nwv * (go + 1)));
+            int v = INT32_MIN;
+            for (int w2 = 0; w2 < nwv; ++w2) v = max(v, ((volatile int*)rt_val)[(so * 8 + w2) * WAVE + wl]);
+            // (entries of paths that were not needed at that point are stale: `needed` only ever shrinks)
+            hop_all |= __ballot(v < 0) & needed;
+            if (wl == 0) __hip_atomic_fetch_add(rt_app + so, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const unsigned long long lead_k = wl < P ? (rev ? a.rlead : a.flead)[(long long)e * 64 + wl] : 0ull;
+            unsigned long long nd = needed & ~hop_all;
+            for (;;) {
+                const unsigned long long ad = __ballot(((needed >> wl) & 1ull) && !((nd >> wl) & 1ull) && (lead_k & nd) != 0ull);
+                if (!ad) break;
+                nd |= ad;
+            }
+            needed = nd;
+        }
+        // (2) publish this point: the slot is free once every stripe has applied its previous use
+        const int sl = (e - 1) % RT_SLOTS, gen = (e - 1) / RT_SLOTS;
+        rt_wait(rt_app + sl, (unsigned)(nwv * gen));
+        int mine = INT32_MIN;
+        for (unsigned long long todo = needed; todo; todo &= todo - 1) {
+            const int k = __builtin_ctzll(todo);
+            int m = INT32_MIN;
+#pragma unroll
+            for (int q = 0; q < C; ++q) m = max(m, rows.ld(k, q * WAVE + wl, wpadw) + rvc[q * WAVE + wl]);
+            const int mk = __builtin_amdgcn_readlane(dpp_incl_max(m, INT32_MIN), WAVE - 1);
+            if (wl == k) mine = mk;
+        }
+        ((volatile int*)rt_val)[(sl * 8 + wv) * WAVE + wl] = mine;
+        if (wl == 0) __hip_atomic_fetch_add(rt_pub + sl, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
     while (t < nsteps) {
         int w0, w1;
         unsigned long long gmask;
-        if (!kStripes && t >= next_eval) [[unlikely]] {
-            retire_eval(t >> a.retire_shift);
+        if (kRetOK && t >= next_eval) [[unlikely]] {
+            if (kStripes) retire_eval_striped(t >> a.retire_shift); else retire_eval(t >> a.retire_shift);
             next_eval = (t | ((1 << a.retire_shift) - 1)) + 1;
         }
         fetch(t, w0, w1, gmask);
@@ -468,16 +531,16 @@ __global__ __launch_bounds__(kStripes ? 512 : 64, kStripes ? 1 : RG_SWEEP_WAVES)
         const int nm = __popcll(gmask);
         cells += (unsigned long long)nm;
         // (path retirement: the members still computed; a group whose members are all retired — its alpha with them — is skipped)
-        const unsigned long long gm = (!kStripes && next_eval != INT32_MAX) ? (gmask & needed) : gmask;
-        // (kStripes: the striped instantiations keep the exact control flow they had before the retirement was added — with the
+        const unsigned long long gm = (!kOld && next_eval != INT32_MAX) ? (gmask & needed) : gmask;
+        // (kOld, stripes of 32 columns per lane: the instantiation keeps the exact control flow it had before the retirement was added — with the
         // skip, the `i != srow` set-up and `row_has` compiled in, k_sweep<32, true, true> (691 spilled VGPRs, 325 spilled SGPRs)
         // returned sink values 12 too low while every direction word stayed right: tests/test_gpu_pathwise.py::
         // test_reads_longer_than_2047_bases at stripe_c = 32; the narrower stripes were unaffected)
-        if (kStripes || gm != 0ull) {
+        if (kOld || gm != 0ull) {
         // ---- general (row, group) step ----
         const int g_i = __builtin_amdgcn_readfirstlane(sct[li * 6 + GAP]);
         const int g0 = a.semi ? 0 : g_i;
-        if (kStripes ? (flags & F_FIRST) != 0 : ((flags & F_FIRST) || i != srow)) {
+        if (kOld ? (flags & F_FIRST) != 0 : ((flags & F_FIRST) || i != srow)) {
 #pragma unroll
             for (int q = 0; q < C; ++q) { s[q] = sct[li * 6 + (int)((erp[q / 16] >> (4 * (q % 16))) & 7)]; bkey[q] = INT32_MIN; }
             srow = i;
@@ -536,7 +599,7 @@ __global__ __launch_bounds__(kStripes ? 512 : 64, kStripes ? 1 : RG_SWEEP_WAVES)
         }
         }
         if (semi_end && (flags & F_LAST)) end_row_done(i);
-        if (track && (flags & F_LAST) && (kStripes || row_has)) row_end(i, ((w1 >> 20) & 511) - 1, bkey);
+        if (track && (flags & F_LAST) && (kOld || row_has)) row_end(i, ((w1 >> 20) & 511) - 1, bkey);
         if (flags & F_LAST) row_has = false;
         ++t;
     }
@@ -560,7 +623,7 @@ __global__ __launch_bounds__(kStripes ? 512 : 64, kStripes ? 1 : RG_SWEEP_WAVES)
         // (a retired path's row is stale: its true final score is below the bound k_verify checks the result against)
         if (wv == ln / WAVE)
             for (int k = wl; k < P; k += WAVE)
-                rs->sink_val[k] = (!kStripes && next_eval != INT32_MAX && !((needed >> k) & 1ull)) ? NEG : rows.ld(k, ql * WAVE + (ln % WAVE), wpadw);
+                rs->sink_val[k] = (!kOld && next_eval != INT32_MAX && !((needed >> k) & 1ull)) ? NEG : rows.ld(k, ql * WAVE + (ln % WAVE), wpadw);
     }
     if (semi_end && wv == ln_end / WAVE) {       // the stripe that owns column n folded every value
         for (int k = wl; k < P; k += WAVE) { rs->sink_val[k] = endv[k]; rs->path_end_row[k] = endr[k]; }
@@ -568,7 +631,7 @@ __global__ __launch_bounds__(kStripes ? 512 : 64, kStripes ? 1 : RG_SWEEP_WAVES)
     }
     if (lane == 0 && a.count_cells) {
         atomicAdd(a.cells, cells * (unsigned long long)(n + 1));
-        atomicAdd(a.cells + 1, (kStripes ? cells : performed) * (unsigned long long)(n + 1));       // (every member update that is not retired is performed as such here)
+        atomicAdd(a.cells + 1, (kOld ? cells : performed) * (unsigned long long)(n + 1));       // (every member update that is not retired is performed as such here)
     }
 }
 
@@ -1379,7 +1442,9 @@ void launch_sweep(const SweepArgs& a, int nreads, int C, hipStream_t s) {
     if (a.nwv > 1) {
         // striped long reads: a.nwv waves per read, C columns per lane (16: the rows and keys fit the registers; 32 spills
         // 800 of them and only serves reads beyond 8 x 1024 columns), uniform read-gap cost (checked by the driver)
-        const size_t bytes = (64 + 2 * RG_MAXP + a.nwv * (FIFO_WORDS + 2)) * sizeof(int);
+        // (score table, end arrays, 8 FIFOs; path retirement across stripes: counters, suffix minima, 4 x 8 x 64 published
+        // maxima, C x 64 constants per stripe)
+        const size_t bytes = (64 + 2 * RG_MAXP + 8 * (FIFO_WORDS + 2) + 16 + 4 * 8 * WAVE + (size_t)a.nwv * C * WAVE) * sizeof(int);
         switch (C) {
             case 8: hipLaunchKernelGGL((k_sweep<8, true, true>), dim3(nreads), dim3(64 * a.nwv), bytes, s, a); break;
             case 16: hipLaunchKernelGGL((k_sweep<16, true, true>), dim3(nreads), dim3(64 * a.nwv), bytes, s, a); break;

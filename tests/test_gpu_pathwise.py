@@ -550,3 +550,43 @@ def test_reads_longer_than_2047_bases(oracle):
     rd = synth.haplotype_reads(g, 1, length=8400, seed=164, mosaic_frac=1.0)
     _check(oracle, g.gfa(), rd, api.MODE_PATHWISE, oracle.M4_ABS)
     _check(oracle, g.gfa(), rd, api.MODE_RECOMBINATION, oracle.M8_ABS)
+
+
+def test_striped_long_reads_retire_paths(oracle):
+    """Path retirement ACROSS the stripes of a long read (round 5): every stripe publishes, per needed path, the maximum over
+    its own columns; the decision is applied two evaluation points later by all stripes at the same record (their FIFOs
+    carry one entry per row update: a stripe that skipped a record alone would hang the read).  Evaluation periods from 8 to
+    256 records — short periods make the leading stripe wait for the slowest one at every point — stripes of 512 and 1024
+    columns, against the oracle; and the retirement must actually bite."""
+    from recgraph_amd import api, synth
+    g = synth.haplotype_graph(5200, 8, path_len=2600, seed=71)
+    rd = synth.haplotype_reads(g, 6, length=2600, seed=171, mosaic_frac=0.5)
+    rd += [g.path_sequence(3)[:2300], g.path_sequence(0)[:700]]
+    gg = api.Graph.from_gfa_text(g.gfa())
+    names = ["r%d" % i for i in range(len(rd))]
+    try:
+        for shift, stripe_c in ((8, 0), (5, 0), (3, 0), (4, 8), (6, 8)):
+            api.set_option("retire_shift", shift)
+            api.set_option("stripe_c", stripe_c)
+            _check(oracle, g.gfa(), rd, api.MODE_RECOMBINATION, oracle.M8_ABS)
+            _check(oracle, g.gfa(), rd[:3], api.MODE_RECOMBINATION, oracle.M8_ABS, R=2, r=0.3, B=0.8)
+        api.set_option("stripe_c", 0)
+        api.set_option("retire_shift", 6)
+        base = api.align_batch(gg, rd, names, mode=api.MODE_RECOMBINATION)[0]
+        got = {}
+        for key, val in (("on", 0), ("off", 1), ("forward_only", 2), ("reverse_only", 3)):
+            api.set_option("no_retire", val)
+            b = api.Batch(gg, rd, api.make_params(api.MODE_RECOMBINATION))
+            b.run()
+            b.fetch()
+            got[key] = (b.cell_updates, b.cell_updates_performed)
+            assert api.align_batch(gg, rd, names, mode=api.MODE_RECOMBINATION)[0] == base, key
+        assert got["on"][0] == got["off"][0]
+        assert got["off"][1] == got["off"][0]
+        assert got["on"][1] < 0.8 * got["off"][1], got
+        assert got["on"][1] < got["forward_only"][1] < got["off"][1], got
+        assert got["on"][1] < got["reverse_only"][1] < got["off"][1], got
+    finally:
+        api.set_option("no_retire", 0)
+        api.set_option("stripe_c", 0)
+        api.set_option("retire_shift", 8)

@@ -24,6 +24,7 @@ CASES = {
     "len600": (8, 6000, 32, 600, {}, 4096, 6),
     "p128": (8, 10000, 128, 1000, {}, 1024, 4),
     "m4_len1500": (4, 15000, 32, 1500, {}, 2048, 6),
+    "len5000": (8, 50000, 32, 5000, {}, 256, 4),
 }
 
 
@@ -33,6 +34,9 @@ def main():
     names = [a for a in sys.argv[1:] if not a.startswith("-")] or list(CASES)
     check = 3
     handles = int(os.environ.get("RG_REGION_HANDLES", "3"))      # (1: the kernels' lone durations)
+    opts = [kv.split("=") for kv in os.environ.get("RG_REGION_OPTS", "").split(",") if kv]      # e.g. sweep_i32=1,no_retire=1
+    for k, v in opts:
+        api.set_option(k, int(v))
     for name in names:
         mode, rows, paths, rlen, sk, tile, tiles = CASES[name]
         g = synth.haplotype_graph(rows, paths, path_len=rlen, seed=1234)
@@ -72,7 +76,7 @@ def main():
         cu = sum(t.cell_updates for t in got)
         cp = sum(t.cell_updates_performed for t in got)
         print(json.dumps({"case": name, "mode": mode, "rows": gg.rows, "paths": paths, "read_len": rlen, "scores": sk or "default",
-                          "tile_reads": tile, "tiles": tiles, "handles": handles, "reads_per_s": round(tile * tiles / dt, 1), "ms_per_tile": round(dt / tiles * 1e3, 2),
+                          "tile_reads": tile, "tiles": tiles, "handles": handles, "options": dict((k, int(v)) for k, v in opts), "reads_per_s": round(tile * tiles / dt, 1), "ms_per_tile": round(dt / tiles * 1e3, 2),
                           "cell_updates_per_s": round(cu / dt), "performed_over_counted": round(cp / cu, 3) if cu else None, "sweep_kernels": sweeps, "kernel_ms_per_tile": ks, "parity_checked": check if ok else "FAILED"}), flush=True)
 
 
