@@ -38,6 +38,10 @@ def test_no_valu_write_into_a_wide_buffer_store_in_flight():
     import kernel_resources
     hits, stores = kernel_resources.store_hazards("rg_sweep16.hip")
     assert stores > 100 and not hits, hits[:4]
+    # (the other sources use no buffer intrinsics: the compiler's own wide stores are FLAT / scratch, whose wait state it inserts)
+    csrc = os.path.join(ROOT, "recgraph_amd", "csrc")
+    users = [f for f in os.listdir(csrc) if f.endswith((".hip", ".hpp", ".cpp")) and "raw_buffer_store" in open(os.path.join(csrc, f)).read()]
+    assert users == ["rg_sweep16.hip"], users
     hits, _ = kernel_resources.store_hazards("rg_sweep16.hip", ["-DRG_SWEEP16_NO_STORE_NOP"])
     assert any("k_sweep16<16, 0, false, false, false>" in h[0] for h in hits), hits[:4]
 
