@@ -181,6 +181,38 @@ def test_full_launch_every_wave_slot_vs_oracle(oracle, cfg):
         assert not bad, (cfg, attempt, len(bad), bad[:12])
 
 
+@pytest.mark.parametrize("case", ["c8_400bp", "c4_200bp", "semi_1kbp", "wide_70_paths", "m4_semi_600bp"])
+def test_full_launches_of_the_other_sweep_variants_vs_oracle(oracle, case):
+    """The same for the variants configs 4 and 5 do not reach — 8 and 4 columns per lane (four and six-plus waves per SIMD: more
+    row stores in flight per CU than anywhere else), the semiglobal flag, more than 64 paths — each as ONE launch that fills
+    every wave slot of the chip at the variant's occupancy, reads of the whole index range against the oracle."""
+    from recgraph_amd import api, synth
+    mode, om, rows, P, rlen, nreads, mosaic = {
+        "c8_400bp": (api.MODE_RECOMBINATION, oracle.M8_ABS, 4000, 16, 400, 8192, 0.5),
+        "c4_200bp": (api.MODE_RECOMBINATION, oracle.M8_ABS, 2000, 12, 200, 16384, 0.5),
+        "semi_1kbp": (api.MODE_RECOMBINATION_SEMI, oracle.M9_ABS, 10000, 32, 1000, 4096, 0.5),
+        "wide_70_paths": (api.MODE_RECOMBINATION, oracle.M8_ABS, 6000, 70, 600, 4096, 0.5),
+        "m4_semi_600bp": (api.MODE_PATHWISE_SEMI, oracle.M5_ABS, 6000, 16, 600, 8192, 0.0),
+    }[case]
+    sg = synth.haplotype_graph(rows, P, path_len=rlen, seed=4242)
+    g = api.Graph.from_gfa_text(sg.gfa())
+    reads = synth.haplotype_reads(sg, nreads, rlen, seed=777, mosaic_frac=mosaic)
+    if "semi" in case:
+        reads = [r[: len(r) * 3 // 4] for r in reads]
+    names = ["read%d" % i for i in range(len(reads))]
+    check = sorted(set(list(range(0, nreads, nreads // 96)) + [nreads - 1]))
+    og = oracle.Graph.from_gfa_text(sg.gfa())
+    _, _, exp = og.bench_text(om, [reads[i] for i in check], nthreads=min(os.cpu_count() or 1, 96), name_prefix="x")
+    texts, status = api.align_batch(g, reads, names, mode=mode)
+    assert not any(status)
+    bad = []
+    for k, i in enumerate(check):
+        e = exp[k].decode().replace("x%d\t" % k, "read%d\t" % i, 1)
+        if texts[i].rsplit("\t", 1)[0] != e.rsplit("\t", 1)[0]:
+            bad.append(i)
+    assert not bad, (case, len(bad), bad[:12])
+
+
 def test_c2_m0_full_config_vs_oracle(oracle):
     """Config 2 at full size (10 000 reads); the oracle is fast enough to compare a 2 000-read stride."""
     from recgraph_amd import api, synth
