@@ -219,6 +219,11 @@ def _cpu_worker(rfd, wfd):
             CpuPool._send(wfd, og.bench_faithful([msg[1]], nthreads=1, col_stride=msg[2]))
 
 
+# what the same leg measured on the boxes of the pool over the last round (a range, not one number; the boxes
+# run it at 0.68-0.93 per-thread efficiency under their 16-CPU quota)
+CPU_RANGE_NOTE = {8: "; the same 16-process leg across the round-5 boxes of this pool: 35.6-44.0 reads/s"}
+
+
 def cpu_legs(args, mode, gfa, reads, first, gpu_text_of, cores, pool):
     """cpu_baseline legs on the host cores (oracle = CPU restatement, kind "port") + the in-run parity gate: every read a
     leg aligns is compared byte for byte with the GPU text of the same read.  `first`: stream index of reads[0] (the
@@ -275,8 +280,9 @@ def cpu_legs(args, mode, gfa, reads, first, gpu_text_of, cores, pool):
     best = full[0]
     cpu = {"value": best["reads_per_s"], "unit": "reads/s", "cores": best["threads"], "kind": "port",
            "sample": "%s; reads of the last timed step; %d single-threaded worker processes (forked before the GPU was touched, "
-                     "pinned to distinct CPUs) = the %d usable host CPUs (%d reads, %.1f s); thread_sweep has the other legs %s"
-                     % (what, best["threads"], cores, best["reads"], best["secs"], [e["threads"] for e in sweep]),
+                     "pinned to distinct CPUs) = the %d usable host CPUs (%d reads, %.1f s); thread_sweep has the other legs %s%s"
+                     % (what, best["threads"], cores, best["reads"], best["secs"], [e["threads"] for e in sweep],
+                        CPU_RANGE_NOTE.get(mode, "")),
            "single_thread": {"value": round(v1, 4), "unit": "reads/s", "reads": n1, "secs": round(s1, 2)},
            "all_cores": {"value": best["reads_per_s"], "unit": "reads/s", "threads": best["threads"]},
            "thread_sweep": sweep}
