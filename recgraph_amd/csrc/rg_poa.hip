@@ -35,6 +35,8 @@ __device__ void band_simd(int i, unsigned ms, unsigned me, int r_val, unsigned s
         band_end = min(seq_len, me + bta);
     }
     unsigned nr = band_end, nl = band_start;
+#ifdef RG_BAND_SIMD_LOOPS
+    // (the reference's three loops as written, utils.rs:77-97: what the closed form below replaces)
     while ((nr - nl) % 8 != 0) {
         if ((nr - nl) % 2 == 0 && nr < seq_len) nr += 1;
         else if (nl > 0) nl -= 1;
@@ -44,6 +46,32 @@ __device__ void band_simd(int i, unsigned ms, unsigned me, int r_val, unsigned s
         while ((nr - 1) % 8 != 0 && nr < seq_len) nr += 1;
     if (nr == seq_len)
         while ((nr - nl) % 8 != 0 && nl > 1) nl -= 1;
+#else
+    // The reference widens the band to a multiple of 8 one column at a time (utils.rs:77-85): an even width takes a column
+    // on the right while there is one, an odd width (or no room on the right) one on the left, and it gives up when it needs
+    // the left and the left is 0.  As scalar loops that was up to 7 iterations of ~25 instructions and branches per DP ROW
+    // on the CU's one scalar unit — what bounds this kernel.  Closed form (checked against the loops for every
+    // (left, right, length) up to 40 and a few long ones, profiles/r05_notes.md): k steps are needed, the steps alternate
+    // E(ven), O(dd) starting with the parity of the width; E takes from the right's room R first, O from the left's room;
+    // with s steps taken the left gave b(s) = #O(s) + max(0, #E(s) - R) columns, and the loop stops at the largest s <= k
+    // with b(s) <= left.
+    {
+        const unsigned d = (nr - nl) & 7u, k = (8u - d) & 7u, p0 = d & 1u;
+        const unsigned R = seq_len - nr, Lr = nl;
+        const unsigned s1 = 2u * R + p0;                    // steps until the right's room is used up
+        const unsigned m = min(k, s1);
+        const unsigned lim = 2u * Lr + 1u - p0;             // steps until the left's room is, while the right still has room
+        const unsigned st = lim < m ? lim : (m == k ? k : min(k, R + Lr));
+        const unsigned nE = p0 ? st >> 1 : (st + 1u) >> 1;
+        const unsigned a = min(nE, R);
+        nr += a;
+        nl -= st - a;
+    }
+    // utils.rs:86-90: a band that starts at column 0 ends at a column = 1 (mod 8) — or at the read's end
+    if (nl == 0) nr = min(seq_len, nr + ((1u - nr) & 7u));
+    // utils.rs:91-96: a band that ends at the read's end takes the missing columns on the left, down to column 1
+    if (nr == seq_len) nl -= min((nl - nr) & 7u, nl > 1u ? nl - 1u : 0u);
+#endif
     left = nl;
     right = nr;
 }
