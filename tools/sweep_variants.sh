@@ -12,7 +12,7 @@ if [ "$1" = build ]; then
   mkdir -p tools/build
   for v in $VARIANTS; do
     flags=""; [ $v != BASE ] && for f in ${v//_/ }; do
-      case $f in PFD1) flags="$flags -DRG_SWEEP16_PFD=1";; PFDFWD) flags="$flags -DRG_SWEEP16_PFD_FWD=1";; KRUNNOST|KRUNNOLD) flags="$flags -DRG_SWEEP16_$f";; NORUNWAIT) flags="$flags -DRG_SWEEP16_RUNWAIT=0";; CHAIN0) flags="$flags -DRG_SWEEP16_CHAIN=0";; CHAIN2) flags="$flags -DRG_SWEEP16_CHAIN=2";; PF1) flags="$flags -DRG_SWEEP16_PF=1";; KRUN*) flags="$flags -DRG_SWEEP16_KRUN=${f#KRUN}";; THRLDS0) flags="$flags -DRG_SWEEP16_THRLDS=0";; REVK*) flags="$flags -DRG_SWEEP16_KRUN_REV=${f#REVK}";; REVW*) flags="$flags -DRG_SWEEP16_REV_WAVES=${f#REVW}";; FWDW*) flags="$flags -DRG_SWEEP16_FWD_WAVES=${f#FWDW}";; LANEMIN) flags="$flags -DRG_SWEEP16_LANEMIN";; STALL2) flags="$flags -DRG_SWEEP16_STALLSTAT=2";; NOAHEAD) flags="$flags -DRG_SWEEP16_PROFILE_AHEAD=0";; STALL3) flags="$flags -DRG_SWEEP16_STALLSTAT=3";; G32) flags="$flags -DRG_SWEEP16_GATHER32=1";; REVKRUN0) flags="$flags -DRG_SWEEP16_KRUN_REV=0 -DRG_SWEEP16_KRUN=0";; GR*) v2=${f#GR}; flags="$flags -DRG_GATHER_PER_MEMBER_ROW=${v2%%x*} -DRG_GATHER_PER_MEMBER_RUN=${v2##*x}";; GFWD) flags="$flags -DRG_SWEEP16_GATHER_FWD=1";; NOGATHER) flags="$flags -DRG_SWEEP16_GATHER=0";; NOPF) flags="$flags -DRG_SWEEP16_PF=0";; GNOPH1) flags="$flags -DRG_G_NOPH1";; GNOPH3) flags="$flags -DRG_G_NOPH3";; RSH*) flags="$flags -DRG_SWEEP16_RETIRE_SHIFT=${f#RSH}";; *) flags="$flags -DRG_SWEEP16_$f";; esac; done
+      case $f in PFD1) flags="$flags -DRG_SWEEP16_PFD=1";; PFDFWD) flags="$flags -DRG_SWEEP16_PFD_FWD=1";; KRUNNOST|KRUNNOLD) flags="$flags -DRG_SWEEP16_$f";; NORUNWAIT) flags="$flags -DRG_SWEEP16_RUNWAIT=0";; CHAIN0) flags="$flags -DRG_SWEEP16_CHAIN=0";; CHAIN2) flags="$flags -DRG_SWEEP16_CHAIN=2";; PF1) flags="$flags -DRG_SWEEP16_PF=1";; KRUN*) flags="$flags -DRG_SWEEP16_KRUN=${f#KRUN}";; THRLDS0) flags="$flags -DRG_SWEEP16_THRLDS=0";; REVK*) flags="$flags -DRG_SWEEP16_KRUN_REV=${f#REVK}";; REVW*) flags="$flags -DRG_SWEEP16_REV_WAVES=${f#REVW}";; FWDW*) flags="$flags -DRG_SWEEP16_FWD_WAVES=${f#FWDW}";; LANEMIN) flags="$flags -DRG_SWEEP16_LANEMIN";; STALL2) flags="$flags -DRG_SWEEP16_STALLSTAT=2";; BANDLOOPS) flags="$flags -DRG_BAND_SIMD_LOOPS";; NOAHEAD) flags="$flags -DRG_SWEEP16_PROFILE_AHEAD=0";; STALL3) flags="$flags -DRG_SWEEP16_STALLSTAT=3";; G32) flags="$flags -DRG_SWEEP16_GATHER32=1";; REVKRUN0) flags="$flags -DRG_SWEEP16_KRUN_REV=0 -DRG_SWEEP16_KRUN=0";; GR*) v2=${f#GR}; flags="$flags -DRG_GATHER_PER_MEMBER_ROW=${v2%%x*} -DRG_GATHER_PER_MEMBER_RUN=${v2##*x}";; GFWD) flags="$flags -DRG_SWEEP16_GATHER_FWD=1";; NOGATHER) flags="$flags -DRG_SWEEP16_GATHER=0";; NOPF) flags="$flags -DRG_SWEEP16_PF=0";; GNOPH1) flags="$flags -DRG_G_NOPH1";; GNOPH3) flags="$flags -DRG_G_NOPH3";; RSH*) flags="$flags -DRG_SWEEP16_RETIRE_SHIFT=${f#RSH}";; *) flags="$flags -DRG_SWEEP16_$f";; esac; done
     rm -rf /tmp/rgvar_$v; mkdir -p /tmp/rgvar_$v
     cp -r recgraph_amd/csrc /tmp/rgvar_$v/csrc; mkdir -p /tmp/rgvar_$v/include; cp include/recgraph_hip.h /tmp/rgvar_$v/include/
     mkdir -p /tmp/rgvar_$v/x; mv /tmp/rgvar_$v/csrc /tmp/rgvar_$v/x/csrc; mkdir -p /tmp/rgvar_$v/include
