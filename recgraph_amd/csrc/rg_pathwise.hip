@@ -1444,7 +1444,8 @@ void launch_sweep(const SweepArgs& a, int nreads, int C, hipStream_t s) {
         // 800 of them and only serves reads beyond 8 x 1024 columns), uniform read-gap cost (checked by the driver)
         // (score table, end arrays, 8 FIFOs; path retirement across stripes: counters, suffix minima, 4 x 8 x 64 published
         // maxima, C x 64 constants per stripe)
-        const size_t bytes = (64 + 2 * RG_MAXP + 8 * (FIFO_WORDS + 2) + 16 + 4 * 8 * WAVE + (size_t)a.nwv * C * WAVE) * sizeof(int);
+        // (the 32-column stripes do not retire paths and get no constants: eight of them would pass the 64 KB a launch may ask for)
+        const size_t bytes = (64 + 2 * RG_MAXP + 8 * (FIFO_WORDS + 2) + 16 + 4 * 8 * WAVE + (C <= 16 ? (size_t)a.nwv * C * WAVE : 0)) * sizeof(int);
         switch (C) {
             case 8: hipLaunchKernelGGL((k_sweep<8, true, true>), dim3(nreads), dim3(64 * a.nwv), bytes, s, a); break;
             case 16: hipLaunchKernelGGL((k_sweep<16, true, true>), dim3(nreads), dim3(64 * a.nwv), bytes, s, a); break;

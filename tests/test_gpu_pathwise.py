@@ -590,3 +590,21 @@ def test_striped_long_reads_retire_paths(oracle):
         api.set_option("no_retire", 0)
         api.set_option("stripe_c", 0)
         api.set_option("retire_shift", 8)
+
+
+def test_longest_supported_reads_eight_stripes_of_2048_columns(oracle):
+    """A read near the 16 383-base limit: EIGHT stripes of 2048 columns in one workgroup (the launch with the largest LDS and
+    register footprint of the library).  `-m 4` against the oracle; `-m 8` (81 s per read in the oracle) against `-m 4`: with
+    a recombination cost no pair can pay for, its best score is the best single path's."""
+    import re
+    from recgraph_amd import api, synth
+    g = synth.haplotype_graph(19000, 2, path_len=16000, seed=65)
+    rd = synth.haplotype_reads(g, 1, length=16000, seed=165, mosaic_frac=1.0)
+    assert 14336 < len(rd[0]) <= 16383
+    t4 = _check(oracle, g.gfa(), rd, api.MODE_PATHWISE, oracle.M4_ABS)
+    gg = api.Graph.from_gfa_text(g.gfa())
+    t8, st = api.align_batch(gg, rd, ["r0"], mode=api.MODE_RECOMBINATION, R=100000)
+    assert not any(st) and "recombination path" not in t8[0]
+    assert int(re.search(r"score: (-?\d+)\t", t8[0]).group(1)) == int(re.search(r"score: (-?\d+)\t", t4[0]).group(1))
+    t8d, st = api.align_batch(gg, rd, ["r0"], mode=api.MODE_RECOMBINATION)
+    assert not any(st)
