@@ -221,7 +221,7 @@ def _cpu_worker(rfd, wfd):
 
 # what the same leg measured on the boxes of the pool over the last round (a range, not one number; the boxes
 # run it at 0.68-0.93 per-thread efficiency under their 16-CPU quota)
-CPU_RANGE_NOTE = {8: "; the same 16-process leg across the round-5 boxes of this pool: 35.6-44.0 reads/s"}
+CPU_RANGE_NOTE = {8: "; the same 16-process leg across the round-5 boxes of this pool: 35.6-45.0 reads/s"}
 
 
 def cpu_legs(args, mode, gfa, reads, first, gpu_text_of, cores, pool):
