@@ -511,6 +511,24 @@ def slice_packed(packed, lo, hi):
     return blob[int(offs[lo]):int(offs[hi])], (offs[lo:hi + 1] - offs[lo]).copy()
 
 
+def blocking_sync(device):
+    """N > 1: host waits of THIS process on the device sleep instead of spinning (hipDeviceScheduleBlockingSync, set before
+    torch creates the context).  The per-step gather calls `.item()` / `.cpu()` on device tensors while the collective waits
+    for its peers: spinning, that is up to one CPU per rank besides the stream's 0.6 — 8 ranks share a 16-CPU quota on the
+    pool's boxes.  The library's own waits already sleep on events (rg_host.hpp).  Errors are ignored: the flag is
+    an optimisation, RG_BENCH_SPIN_SYNC=1 leaves the default."""
+    if os.environ.get("RG_BENCH_SPIN_SYNC") == "1":
+        return False
+    try:
+        import ctypes
+        hip = ctypes.CDLL("libamdhip64.so")
+        if hip.hipSetDevice(ctypes.c_int(device)) != 0:
+            return False
+        return hip.hipSetDeviceFlags(ctypes.c_uint(0x4)) == 0        # hipDeviceScheduleBlockingSync
+    except Exception:
+        return False
+
+
 def main():
     args = parse_args()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -542,6 +560,8 @@ def main():
     if not stub and torch.cuda.device_count() <= local_rank:
         sys.stderr.write("bench.py: rank %d needs GPU %d, %d visible\n" % (rank, local_rank, torch.cuda.device_count()))
         sys.exit(2)
+    if not stub and (dist_on or os.environ.get("RG_BENCH_BLOCKING_SYNC") == "1"):
+        blocking_sync(local_rank)
     if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if stub:
