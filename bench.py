@@ -521,7 +521,11 @@ def blocking_sync(device):
         return False
     try:
         import ctypes
-        hip = ctypes.CDLL("libamdhip64.so")
+        import torch
+        # THE runtime torch loaded (its wheel ships one; by soname the library's HIP calls resolve to the same copy) — a bare
+        # "libamdhip64.so" would map the system's copy as a second runtime and set the flag there
+        own = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+        hip = ctypes.CDLL(own if os.path.exists(own) else "libamdhip64.so.7")
         if hip.hipSetDevice(ctypes.c_int(device)) != 0:
             return False
         return hip.hipSetDeviceFlags(ctypes.c_uint(0x4)) == 0        # hipDeviceScheduleBlockingSync
