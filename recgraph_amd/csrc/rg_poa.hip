@@ -270,12 +270,17 @@ __global__ __launch_bounds__(64) void k_m0_simd(PoaArgs a) {
             }
             // predecessor values of the rows that take the memory path (listed predecessors / wide bands)
             if (!fast && act) {
+                // (opaque copies of the row and of the list start: otherwise the compiler computes the 64-bit addresses of
+                // rinfo[i - 1], col0[i - 1] and pred_rows[pb] in front of the chunk loop of EVERY row — ~20 instructions on the
+                // scalar unit that bounds this kernel, for a path inner rows never take)
+                int io = i, pbo = pb;
+                asm volatile("" : "+s"(io), "+s"(pbo));
                 if (!nwp) {
-                    bu = m_at(cx, i - 1, c); bd = m_at(cx, i - 1, c - 1);
+                    bu = m_at(cx, io - 1, c); bd = m_at(cx, io - 1, c - 1);
                 } else {
-                    int p0 = g.pred_rows[pb];
+                    int p0 = g.pred_rows[pbo];
                     bu = m_at(cx, p0, c); bd = m_at(cx, p0, c - 1); pu = pd = p0;
-                    for (int e = pb + 1; e < pe; ++e) {  // strict '>' : first predecessor wins ties (:127-139)
+                    for (int e = pbo + 1; e < pe; ++e) {  // strict '>' : first predecessor wins ties (:127-139)
                         int p = g.pred_rows[e];
                         int u = m_at(cx, p, c), d = m_at(cx, p, c - 1);
                         if (u > bu) { bu = u; pu = p; }
