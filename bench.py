@@ -219,11 +219,6 @@ def _cpu_worker(rfd, wfd):
             CpuPool._send(wfd, og.bench_faithful([msg[1]], nthreads=1, col_stride=msg[2]))
 
 
-# what the same leg measured on the boxes of the pool over the last round (a range, not one number; the boxes
-# run it at 0.68-0.93 per-thread efficiency under their 16-CPU quota)
-CPU_RANGE_NOTE = {8: "; the same 16-process leg across the round-5 boxes of this pool: 35.6-45.0 reads/s"}
-
-
 def cpu_legs(args, mode, gfa, reads, first, gpu_text_of, cores, pool):
     """cpu_baseline legs on the host cores (oracle = CPU restatement, kind "port") + the in-run parity gate: every read a
     leg aligns is compared byte for byte with the GPU text of the same read.  `first`: stream index of reads[0] (the
@@ -280,9 +275,8 @@ def cpu_legs(args, mode, gfa, reads, first, gpu_text_of, cores, pool):
     best = full[0]
     cpu = {"value": best["reads_per_s"], "unit": "reads/s", "cores": best["threads"], "kind": "port",
            "sample": "%s; reads of the last timed step; %d single-threaded worker processes (forked before the GPU was touched, "
-                     "pinned to distinct CPUs) = the %d usable host CPUs (%d reads, %.1f s); thread_sweep has the other legs %s%s"
-                     % (what, best["threads"], cores, best["reads"], best["secs"], [e["threads"] for e in sweep],
-                        CPU_RANGE_NOTE.get(mode, "")),
+                     "pinned to distinct CPUs) = the %d usable host CPUs (%d reads, %.1f s); thread_sweep has the other legs %s"
+                     % (what, best["threads"], cores, best["reads"], best["secs"], [e["threads"] for e in sweep]),
            "single_thread": {"value": round(v1, 4), "unit": "reads/s", "reads": n1, "secs": round(s1, 2)},
            "all_cores": {"value": best["reads_per_s"], "unit": "reads/s", "threads": best["threads"]},
            "thread_sweep": sweep}
@@ -830,7 +824,10 @@ def main():
     rc = 0
     kroof = probe if probe else kstats
     ksteps = probe_steps if probe else steps_here
-    kern = {k: v for k, v in kroof.items() if not k.startswith("host:")}
+    kern = {k: v for k, v in kroof.items() if not k.startswith(("host:", "mem:"))}
+    # HBM work buffers per read as the path driver sized them (a pseudo-kernel: bytes summed per chunk | chunks)
+    memstat = kstats.get("mem:work_bytes_per_read")
+    hbm_per_read = int(memstat[0] / memstat[1]) if memstat and memstat[1] else None
     sweeps = {k: v for k, v in kern.items() if k.startswith(("k_sweep", "k_m0", "k_m2"))}
     roof = None
     if sweeps:
@@ -919,7 +916,9 @@ def main():
                       batch * (world if args.scaling == "weak" else 1),
                       batch * min(args.steps, nb) * (world if args.scaling == "weak" else 1), handles_used,
                       "/".join(str(x) for x in tile_sizes) if tile_sizes else str(batch)),
-                   "parallelism": "read-shard x%d" % world},
+                   "parallelism": "read-shard x%d" % world,
+                   # what shapes the headline besides the workload: the defaults depend on the configuration
+                   "handles": handles_used, "strong_ramp": args.strong_ramp},
         # member-row cell updates of the WORKLOAD per second (sum over rows of |paths(row)| x (n + 1), forward + reverse: the
         # reference's unit of work) ...
         "cell_updates_per_s": round(cells_all / dt, 1),
@@ -930,7 +929,7 @@ def main():
         # region include the other streams' kernels (their sum exceeds the step), the probe figures are the kernels' own
         # durations (their sum is the GPU time one step would take alone)
         "kernel_ms_per_step": {k: round(v[0] / max(1, ksteps), 3) for k, v in kern.items()},
-        "kernel_ms_per_step_in_timed_region": {k: round(v[0] / steps_here, 3) for k, v in kstats.items() if not k.startswith("host:")} if probe else None,
+        "kernel_ms_per_step_in_timed_region": {k: round(v[0] / steps_here, 3) for k, v in kstats.items() if not k.startswith(("host:", "mem:"))} if probe else None,
         # host wall time per step, summed over the stream's worker threads (they overlap each other and the device):
         # set_reads = canonicalise + upload, run = kernels (waiting for the device), fetch = records D2H, format = GAF text
         "host_ms_per_step": {k[5:]: round(v[0] / steps_here, 3) for k, v in kstats.items() if k.startswith("host:")},
@@ -938,6 +937,9 @@ def main():
         # summed over the ranks: what an N-GPU run asks of the host
         "host_cpu_s_per_step": round(head["cpu_s_all"] / max(1, args.steps), 4),
         "host_cpus_busy": round(head["cpu_s_all"] / dt, 2),
+        # work buffers in HBM per read of a chunk (pathwise modes; x tile reads x handles = what the stream holds)
+        "hbm_work_bytes_per_read": hbm_per_read,
+        "hbm_work_GB_held": round(hbm_per_read * batch * handles_used / 1e9, 2) if hbm_per_read else None,
         "tiles_per_rank": tiles_per_rank,
         "gather_ms_per_step": round((head["gather_busy"] if dist_on else 0.0) / steps_here * 1e3, 3),
         "gather_wait_ms": round(head["gather_wait"] * 1e3, 3),

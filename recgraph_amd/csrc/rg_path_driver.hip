@@ -324,7 +324,7 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
     const int spec_margin = ((nwv > 1 ? opt.spec_margin * ((max_n + 999) / 1000) : (int)opt.spec_margin) +
                              (spec_level == 1 ? 320 * ((max_n + 999) / 1000) : 0)) * (opt.spec_margin > 0 ? score_scale : 1);
     const int recw = 4 + C;
-    if (w.fcap == 0) { w.fcap = (two_sweep && !use_rec) ? 1u << 20 : 1u << 15; w.rcap = use_rec ? 1u << 16 : 1u << 19; w.frec_cap = 1u << 16; w.rrec_cap = 1u << 15; }   // (reverse records at config 5: mean 2.7 k, largest read of a 4096-read tile 21-25 k)
+    if (w.fcap == 0) { w.fcap = (two_sweep && !use_rec) ? 1u << 20 : 1u << 15; w.rcap = use_rec ? 1u << 16 : 1u << 19; w.frec_cap = 1u << 14; w.rrec_cap = 1u << 13; }   // (round 6: 16 Ki / 8 Ki records of 80 B to start with instead of 64 Ki / 32 Ki — 2 MB per read instead of 7.9; a read that needs more regrows the lists and the chunk runs again, once per handle.  Config 5 with the two-path pick: forward mean ~11 k)
     stats.clear();
     Timer T{&w, stream, pw.spin_wait};
     int done = 0;
@@ -621,6 +621,9 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
         }
         cells_done += chunk_cells;
         done += chunk;
+        // HBM work buffers of one read of this chunk (rolling rows, direction words, layers, candidate and record lists): reported
+        // as a pseudo-kernel so that callers see the footprint without another ABI entry ("ms" holds bytes, summed per chunk)
+        stats.push_back({"mem:work_bytes_per_read", {(double)per_read_all, 1}});
     }
     if (cells_out) { cells_out[0] = cells_done; cells_out[1] = cells_perf; }
     return RG_OK;

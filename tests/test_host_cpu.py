@@ -30,6 +30,12 @@ def test_library_exports_every_declared_symbol(rg):
     for sym in sorted(declared):
         assert hasattr(lib, sym), sym
     assert declared == set(_lib.SYMBOLS)
+    # ... and NOTHING else: a drop-in library exports its ABI, not its kernels' host stubs, launchers or C++ helpers
+    # (csrc/exports.map)
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.library_path()], capture_output=True, text=True, check=True).stdout
+    exported = {ln.split()[-1] for ln in out.splitlines() if ln.strip()}
+    assert exported == declared, sorted(exported ^ declared)
 
 
 def test_flattening_matches_oracle(rg, oracle, example_gfa):

@@ -8,22 +8,24 @@ cd "$(dirname "$0")/../.." || exit 1
 export TMPDIR=/tmp
 CFG=${1:-C5}; METHOD=${2:-host_trap}; INTERVAL=${3:-1}; UNIT=${4:-time}
 O=gpurun_out/pcs_${CFG}_${METHOD}; rm -rf $O; mkdir -p $O
+RAW=$(mktemp -d /tmp/pcs_raw.XXXXXX)      # per run: an earlier run's CSVs must not be folded into this one's histogram
 rocprofv3-avail list --pc-sampling > $O/avail.txt 2>&1 || rocprofv3-avail list > $O/avail.txt 2>&1
 timeout 600 rocprofv3 --pc-sampling-beta-enabled --pc-sampling-method $METHOD --pc-sampling-unit $UNIT --pc-sampling-interval $INTERVAL \
-  --kernel-trace --output-format csv -d /tmp/pcs_raw -o p -- python3 bench.py --config $CFG --steps 3 --warmup 1 --no-cpu --no-strong --no-probe --handles 1 \
+  --kernel-trace --output-format csv -d $RAW -o p -- python3 bench.py --config $CFG --steps 3 --warmup 1 --no-cpu --no-strong --no-probe --handles 1 \
   > $O/bench.json 2> $O/rocprof.log
 echo "rocprofv3 exit $?" >> $O/rocprof.log
-find /tmp/pcs_raw -type f | head -50 > $O/files.txt
-python3 - "$O" <<'PY'
+find $RAW -type f | head -50 > $O/files.txt
+python3 - "$O" "$RAW" <<'PY'
 import collections, csv, glob, json, sys
 out = sys.argv[1]
+raw = sys.argv[2]
 csv.field_size_limit(1 << 30)
 kern = {}
-for f in glob.glob("/tmp/pcs_raw/**/*kernel_trace.csv", recursive=True):
+for f in glob.glob(raw + "/**/*kernel_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         kern[r.get("Dispatch_Id")] = r.get("Kernel_Name", "")
 res = {}
-for f in glob.glob("/tmp/pcs_raw/**/*pc_sampling*.csv", recursive=True):
+for f in glob.glob(raw + "/**/*pc_sampling*.csv", recursive=True):
     hist = collections.Counter()
     extra = collections.defaultdict(collections.Counter)
     cols = None

@@ -61,7 +61,7 @@ def main():
         got = [st.next() for _ in range(tiles)]
         dt = time.perf_counter() - t0
         k1 = st.kernel_stats()
-        ks = {k: round((v[0] - k0.get(k, (0, 0))[0]) / tiles, 2) for k, v in k1.items() if not k.startswith("host:")}
+        ks = {k: round((v[0] - k0.get(k, (0, 0))[0]) / tiles, 2) for k, v in k1.items() if not k.startswith(("host:", "mem:"))}
         st.close()
         # parity: reads spread over the whole index range of the LAST timed tile (every wave slot of a full launch: the round's
         # one wrong result only showed behind index 768 of a 4096-read launch), against the oracle's threaded runner
