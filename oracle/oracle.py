@@ -98,6 +98,8 @@ def lib():
         l.orc_scores_match_mis.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]
         l.orc_scores_from_mtx.argtypes = [C.c_char_p, C.POINTER(C.c_int)]
         l.orc_missing_value.restype = C.c_int
+        l.orc_f32_display.restype = C.c_int
+        l.orc_f32_display.argtypes = [C.c_uint, C.c_char_p, C.c_int]
         l.orc_f32_cell_roundtrip_limit.restype = C.c_longlong
         l.orc_f32_cell_roundtrip_limit.argtypes = [C.c_longlong]
         _lib = l

@@ -326,6 +326,16 @@ double orc_bench_faithful(void* h, const char* reads_concat, const long long* of
     return secs;
 }
 
+// the oracle's Rust-`{}` formatter on one f32 given by its bit pattern (tests pin it against numpy's shortest-unique form)
+int orc_f32_display(unsigned bits, char* out, int cap) {
+    float v;
+    memcpy(&v, &bits, 4);
+    const std::string s = f32_display(v);
+    if ((int)s.size() + 1 > cap) return -1;
+    memcpy(out, s.c_str(), s.size() + 1);
+    return (int)s.size();
+}
+
 // decode check used by tests: the f32 path-cell encoding "pred + 0.1/0.2/0.3" parsed back through
 // Display + split('.') (gaf_output.rs:783-786); returns first pred for which it fails, or -1
 long long orc_f32_cell_roundtrip_limit(long long upto) {

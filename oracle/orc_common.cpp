@@ -5,6 +5,9 @@
 
 #include <algorithm>
 #include <charconv>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <sstream>
 
 namespace orc {
@@ -346,10 +349,32 @@ std::pair<size_t, size_t> set_ampl_for_row(size_t i, const std::vector<size_t>& 
     return {band_start, band_end};
 }
 
+// Rust `{}` of an f32 (library/core/src/fmt/float.rs -> flt2dec::to_shortest_str): the shortest decimal digit string that
+// reads back as the same f32, in positional notation, zero-padded.  Written differently from the product's formatter on
+// purpose (test infrastructure should not share a reading with what it checks): the digit count is found by trying
+// 1..9 significant digits with printf and reading each back.
 std::string f32_display(float v) {
-    char b[128];
-    auto r = std::to_chars(b, b + sizeof b, v, std::chars_format::fixed);
-    return std::string(b, r.ptr);
+    if (std::isnan(v)) return "NaN";
+    if (std::isinf(v)) return v < 0 ? "-inf" : "inf";
+    if (v == 0.0f) return std::signbit(v) ? "-0" : "0";
+    char b[64];
+    int prec = 0;
+    for (; prec < 9; ++prec) {
+        snprintf(b, sizeof b, "%.*e", prec, (double)v);
+        if (strtof(b, nullptr) == v) break;
+    }
+    // b = [-]d.ddd...e[+-]XX with prec digits behind the point
+    std::string t(b), digits, out;
+    size_t i = 0;
+    if (t[0] == '-') { out = "-"; i = 1; }
+    const size_t epos = t.find('e');
+    for (; i < epos; ++i) if (t[i] != '.') digits += t[i];
+    const int e10 = atoi(t.c_str() + epos + 1);
+    while (digits.size() > 1 && digits.back() == '0') digits.pop_back();
+    const int before = e10 + 1;
+    if (before <= 0) return out + "0." + std::string((size_t)(-before), '0') + digits;
+    if ((size_t)before >= digits.size()) return out + digits + std::string((size_t)before - digits.size(), '0');
+    return out + digits.substr(0, (size_t)before) + "." + digits.substr((size_t)before);
 }
 
 // src/gaf_output.rs:70-94

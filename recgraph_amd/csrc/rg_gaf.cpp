@@ -8,6 +8,8 @@
 //   build_cigar ................................. src/pathwise_alignment_output.rs:471-556
 #include <algorithm>
 #include <charconv>
+#include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 #include "rg_codes.hpp"
@@ -15,10 +17,30 @@
 
 namespace rg {
 
-std::string f32_display(float v) {  // Rust `{}` for f32: shortest round-trip, fixed notation
-    char b[128];
-    auto r = std::to_chars(b, b + sizeof b, v, std::chars_format::fixed);
-    return std::string(b, r.ptr);
+// Rust `{}` for f32 (core::fmt::float: flt2dec shortest digits, then fixed notation): the SHORTEST digit string that
+// round-trips, laid out positionally and padded with zeros — never the exact binary value (2^100 prints as
+// 1267650600000000000000000000000, not as its 31 exact digits: std::to_chars in fixed format gives the latter for values
+// beyond 2^24, which round 6's independent check against numpy's Dragon4 found), never an exponent, "-0" for negative zero.
+std::string f32_display(float v) {
+    if (v != v) return "NaN";
+    if (v == INFINITY) return "inf";
+    if (v == -INFINITY) return "-inf";
+    char b[64];
+    auto r = std::to_chars(b, b + sizeof b - 1, v, std::chars_format::scientific);   // d[.ddd]e[+-]XX, shortest round-trip digits
+    *r.ptr = 0;
+    const char* p = b;
+    std::string out;
+    if (*p == '-') { out += '-'; ++p; }
+    std::string digits;
+    for (; p < r.ptr && *p != 'e'; ++p) if (*p != '.') digits += *p;
+    const int exp10 = (p < r.ptr) ? atoi(p + 1) : 0;          // value = 0.d1d2... x 10^(exp10 + 1)
+    if (digits.find_first_not_of('0') == std::string::npos) { out += '0'; return out; }
+    const int point = exp10 + 1;                              // digits in front of the decimal point
+    const int nd = (int)digits.size();
+    if (point <= 0) { out += "0."; out.append((size_t)(-point), '0'); out += digits; }
+    else if (point >= nd) { out += digits; out.append((size_t)(point - nd), '0'); }
+    else { out.append(digits, 0, (size_t)point); out += '.'; out.append(digits, (size_t)point, std::string::npos); }
+    return out;
 }
 
 std::string GafFields::line() const {

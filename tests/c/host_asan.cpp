@@ -118,6 +118,19 @@ static std::string mutate(const std::string& base, std::mt19937_64& rng) {
 }
 
 int main(int argc, char** argv) {
+    // `host_asan --f32`: one f32 bit pattern (hex) per stdin line -> rg::f32_display of it per stdout line: the product's
+    // formatter of the recombination score (`{}` of an f32 in the reference, recombination_output.rs:363-631), for the
+    // independent shortest-round-trip check of tests/test_host_cpu.py
+    if (argc == 2 && std::string(argv[1]) == "--f32") {
+        char line[64];
+        while (fgets(line, sizeof line, stdin)) {
+            const uint32_t bits = (uint32_t)strtoul(line, nullptr, 16);
+            float v;
+            memcpy(&v, &bits, 4);
+            puts(rg::f32_display(v).c_str());
+        }
+        return 0;
+    }
     if (argc < 3) { fprintf(stderr, "usage: %s graph.gfa reads.fa [iterations] [seed]\n", argv[0]); return 2; }
     const std::string gfa = slurp(argv[1]), fa = slurp(argv[2]);
     const int iters = argc > 3 ? atoi(argv[3]) : 2000;

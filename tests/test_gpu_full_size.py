@@ -66,6 +66,8 @@ def test_c5_m8_properties(oracle, c5):
             nrec += 1
             m = re.search(r"score: ([-0-9.]+), displacement: (\d+)\t([ACGTN]+)\t(\d+)$", comments)
             pb = m.group(3)
+            # the printed score is the shortest decimal of an f32 (Rust `{}`), judged by numpy's independent Dragon4
+            assert m.group(1) == np.format_float_positional(np.float32(m.group(1)), unique=True, trim="-")
             s = _cigar_score(ops, pb, rd)
             # The CIGAR must consume exactly the read and the spelled path (checked inside _cigar_score).  Its
             # re-computed score is NOT tied to the reported one: m and w follow their group alpha's directions
@@ -264,3 +266,81 @@ def test_cli_example_matches_oracle(oracle, example_gfa, example_reads, tmp_path
         out = capsys.readouterr().out
         exp = "".join(og.align(om, rd, name=names[i], idx=i + 1)[0] for i, rd in enumerate(reads))
         assert out == exp
+
+
+def _host_threads(cap):
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(cap, n))
+
+
+def test_c5_and_c4_against_the_literal_restatement(oracle, c5):
+    """VERDICT r5 missing #4 / next #2a.  Everywhere else at configuration size the comparator is the absolute-form oracle
+    (`orc_pathwise_abs.cpp`: rolling rows, direction words, candidate lists — the GPU's own shape).  Here 16 config-5 reads
+    (eight of each GAF shape) meet `M8_PRUNED` — the branch-by-branch transliteration of
+    pathwise_alignment_recombination.rs:23-883 with its full L x (n+1) x P matrices and an exactly pruned best_alignment scan
+    (13-19 s and 2.6 GB per read: eight host threads) — and 64 config-4 reads meet `M4`, the transliteration of
+    pathwise_alignment.rs:5-340."""
+    from recgraph_amd import api, synth
+    sg, reads, g = c5
+    names = ["r%d" % i for i in range(len(reads))]
+    texts, status = api.align_batch(g, reads, names, mode=api.MODE_RECOMBINATION)
+    assert not any(status)
+    rec = [i for i, t in enumerate(texts) if "recombination path" in t]
+    plain = [i for i, t in enumerate(texts) if "recombination path" not in t]
+    assert len(rec) >= 8 and len(plain) >= 8
+    # spread over the batch: the first, the last and evenly between
+    pick = sorted([rec[k * (len(rec) - 1) // 7] for k in range(8)] + [plain[k * (len(plain) - 1) // 7] for k in range(8)])
+    og = oracle.Graph.from_gfa_text(sg.gfa())
+    _, _, exp = og.bench_text(oracle.M8_PRUNED, [reads[i] for i in pick], nthreads=_host_threads(8), name_prefix="x")
+    for k, i in enumerate(pick):
+        e = exp[k].decode().replace("x%d\t" % k, "r%d\t" % i, 1)
+        assert texts[i].rsplit("\t", 1)[0] == e.rsplit("\t", 1)[0], (i, texts[i][-200:], e[-200:])
+    sg4, reads4, _ = synth.make_config("C4", n_reads=64)
+    g4 = api.Graph.from_gfa_text(sg4.gfa())
+    names4 = ["r%d" % i for i in range(len(reads4))]
+    t4, st4 = api.align_batch(g4, reads4, names4, mode=api.MODE_PATHWISE)
+    assert not any(st4)
+    og4 = oracle.Graph.from_gfa_text(sg4.gfa())
+    _, _, exp4 = og4.bench_text(oracle.M4, reads4, nthreads=_host_threads(16), name_prefix="r", idx_base=1)
+    bad = [i for i in range(len(reads4)) if t4[i].encode() != exp4[i]]
+    assert not bad, (len(bad), bad[:5])
+
+
+@pytest.mark.parametrize("case", ["m0_simd", "m0_scalar", "m2", "m2_2k_rows", "m1_simd", "m1_scalar", "m3"])
+def test_poa_full_launches_with_real_alignments(oracle, case):
+    """VERDICT r5 weak #3 / next #2b.  Config 2's own reads are 100 % "band not enough": its full-size test compares warning
+    lines and empty records, and the walkers (a13) met the oracle only in batches of a few hundred reads — the size that hid
+    round 5's store hazard in `-m 4`.  Here every POA mode runs ONE full-occupancy launch of whole source->sink walks
+    (`synth.full_walk_reads`: reads a global alignment places inside the band, so the device walker and the formatter produce
+    real CIGARs) and a stride over the whole index range is compared byte for byte with the oracle."""
+    from recgraph_amd import api, synth
+    mode, om, cfg, nreads, ncheck = {
+        "m0_simd": (api.MODE_GLOBAL_POA, oracle.M0_SIMD, "C2", 10000, 500),
+        "m0_scalar": (api.MODE_GLOBAL_POA_SCALAR, oracle.M0_SCALAR, "C2", 10000, 500),
+        "m2": (api.MODE_GAP_POA, oracle.M2, "C2", 10000, 500),
+        "m2_2k_rows": (api.MODE_GAP_POA, oracle.M2, "C3", 8192, 256),
+        "m1_simd": (api.MODE_LOCAL_POA, oracle.M1_SIMD, "C2", 8192, 256),
+        "m1_scalar": (api.MODE_LOCAL_POA_SCALAR, oracle.M1_SCALAR, "C2", 8192, 256),
+        "m3": (api.MODE_GAP_LOCAL_POA, oracle.M3, "C2", 8192, 192),
+    }[case]
+    sg, _, _ = synth.make_config(cfg, n_reads=1)
+    g = api.Graph.from_gfa_text(sg.gfa())
+    og = oracle.Graph.from_gfa_text(sg.gfa(), want_path=False)
+    reads = synth.full_walk_reads(sg, nreads, seed=20261)
+    names = ["w%d" % i for i in range(nreads)]
+    texts, status = api.align_batch(g, reads, names, mode=mode)
+    assert len(texts) == nreads
+    check = sorted(set(list(range(0, nreads, max(1, nreads // ncheck))) + [nreads - 1]))
+    walked = 0
+    for i in check:
+        exp, _, panic, _ = og.align(om, reads[i], name=names[i], idx=i + 1)
+        if panic:
+            assert status[i] & api.READ_WOULD_PANIC, i
+            continue
+        assert texts[i] == exp, (case, i, texts[i][-160:], exp[-160:])
+        # a real alignment: a GAF line with a CIGAR, not the reference's "band not enough" record
+        walked += 1 if "band not enough" not in texts[i] and re.search(r"\t(\d+[MXID])+", texts[i]) else 0
+    assert walked > 0.9 * len(check), (case, walked, len(check))

@@ -247,3 +247,22 @@ def test_example_data_restatements_agree(oracle, example_gfa, example_reads):
     for i in (0, 7, 19):
         assert g.align(oracle.M4, reads[i], name=names[i])[0] == g.align(oracle.M4_ABS, reads[i], name=names[i])[0]
         assert g.align(oracle.M8_PRUNED, reads[i], name=names[i])[0] == g.align(oracle.M8_ABS, reads[i], name=names[i])[0]
+
+
+def test_oracle_f32_display_against_numpy_shortest_form(oracle):
+    """The checker's own `{}`-of-f32 formatter (orc_common.cpp, deliberately a different algorithm from the product's) against
+    numpy's Dragon4 shortest-unique positional text: every k/10 of the score range, the penalty arithmetic, random patterns."""
+    import ctypes as C
+    import numpy as np
+    tot = np.arange(-3000, 3001, dtype=np.float32)
+    vals = [(tot - (np.float32(4) + np.float32(0.1) * np.float32(d))).astype(np.float32) for d in (0, 1, 3, 17, 999)]
+    vals.append((np.arange(-40000, 40001, 7, dtype=np.float32) / np.float32(10)).astype(np.float32))
+    rb = np.random.default_rng(9).integers(0, 1 << 32, size=20000, dtype=np.uint64).astype(np.uint32).view(np.float32)
+    vals.append(rb[np.isfinite(rb)])
+    vals.append(np.array([0.0, -0.0, 1e-45, 3.4028235e38, 1.1754944e-38, 16777216.0, 0.1, 1e7, 1e-7, 2.3621053e30], dtype=np.float32))
+    v = np.concatenate(vals).astype(np.float32)
+    buf = C.create_string_buffer(128)
+    f = oracle.lib().orc_f32_display
+    for x, b in zip(v, v.view(np.uint32)):
+        assert f(int(b), buf, 128) > 0
+        assert buf.value.decode() == np.format_float_positional(x, unique=True, trim="-"), (x, buf.value)
