@@ -22,6 +22,7 @@
 // the argument recorded for a column maximum may be a different cell with the same value (k_bound only needs a real
 // cell: any candidate pair gives a valid lower bound).  Everything downstream is shared.
 #include <algorithm>
+#include <type_traits>
 
 #include "rg_path_kernels.hpp"
 
@@ -186,6 +187,17 @@ struct RowOps16 {
         member_p2(row, ML, lmask, __shfl(zl, src, WAVE), v_lo);
     }
 };
+
+// run_dispatch(f, n): f(std::integral_constant<int, k>) for k = min(n, KMAX) — the register runs of k_sweep16, one loop body per
+// member count
+template <int K, int KMAX, class F>
+__device__ __forceinline__ void run_dispatch_from(F& f, int n) {
+    if constexpr (K >= KMAX) f(std::integral_constant<int, (KMAX > 0 ? KMAX : 1)>{});
+    else {
+        if (n <= K) f(std::integral_constant<int, K>{});
+        else run_dispatch_from<K + 1, KMAX>(f, n);
+    }
+}
 
 }  // namespace
 
@@ -1205,6 +1217,13 @@ __global__ __launch_bounds__(64, C > 16 ? 2 : (kColmax != 0 ? RG_SWEEP16_FWD_WAV
             if (kAhead) load_steps(rli, s);
             for (;;) {          // (chained runs)
             tail = false; rfl = 7;
+            // ONE LOOP BODY PER GROUP SIZE (round 6): the rows of a run with RN members, RN a compile-time constant.  With the
+            // member count a run-time value the `kk < rnm` tests compiled to ~13 branches per row, the conditions re-materialised as
+            // v_cndmask / v_cmp pairs, and the members' rows were shuffled through v_mov pairs where the paths of different counts
+            // meet (profiles/r05_isa_sweep16.txt: 25 % of the hot loop's issue slots were SALU / branch / wait)
+            auto run_rows = [&](auto rn_tag) __attribute__((always_inline)) {
+            constexpr int RN = decltype(rn_tag)::value;
+            unsigned nrows = 0;                 // rows of this run: the cell counters move once per run, not once per row
             while (true) {
                 const int g_i = gcost;
                 const int g0 = kSemi ? 0 : g_i;
@@ -1217,9 +1236,9 @@ __global__ __launch_bounds__(64, C > 16 ? 2 : (kColmax != 0 ? RG_SWEEP16_FWD_WAV
                 if (!kAhead) load_steps(rli, s);
                 unsigned umask;
                 // (at 32 columns per lane `src` stays unconditional: the branch costs that variant 54 more spilled registers)
-                RowOps16<C>::alpha(rr[0], s, g_i, g0, lane, MU, ML, umask, lmask, src, C > 16 || rnm > 1);
+                RowOps16<C>::alpha(rr[0], s, g_i, g0, lane, MU, ML, umask, lmask, src, C > 16 || RN > 1);
                 if (dirs) store_dirs(rslot, umask, lmask);
-                if (rnm > 1) {
+                if constexpr (RN > 1) {
                     // (SEL is defined and used under ONE condition: with `if (rnm > 1) select_steps` beside member loops guarded
                     // by `kk < rnm` the compiler carried its eight registers around the whole record loop)
                     int SEL[H];
@@ -1228,25 +1247,24 @@ __global__ __launch_bounds__(64, C > 16 ? 2 : (kColmax != 0 ? RG_SWEEP16_FWD_WAV
                     int zl[KRUN > 0 ? KRUN : 1], vlo[KRUN > 0 ? KRUN : 1];
 #pragma unroll
                     for (int kk = 1; kk < KRUN; ++kk)
-                        if (kk < rnm) { RowOps16<C>::member_p1(rr[kk], SEL, MU, ML, lmask, zl[kk], vlo[kk]); zl[kk] = __shfl(zl[kk], src, WAVE); }
+                        if (kk < RN) { RowOps16<C>::member_p1(rr[kk], SEL, MU, ML, lmask, zl[kk], vlo[kk]); zl[kk] = __shfl(zl[kk], src, WAVE); }
 #pragma unroll
                     for (int kk = 1; kk < KRUN; ++kk)
-                        if (kk < rnm) RowOps16<C>::member_p2(rr[kk], ML, lmask, zl[kk], vlo[kk]);
+                        if (kk < RN) RowOps16<C>::member_p2(rr[kk], ML, lmask, zl[kk], vlo[kk]);
                 }
                 if (kAhead && !tail && rleft > 1) {
                     const int tn = t + 1;
                     if ((tn >> 6) != blk) to_block(tn >> 6);
                     load_steps((__builtin_amdgcn_readlane(recs.x, tn & (WAVE - 1)) >> 20) & 7, s);
                 }
-                cells += (unsigned long long)__popcll(rgm);
-                done += (unsigned long long)rnm;
+                ++nrows;
                 if (kRec && kColmax != 1 && tail) {
                     if (track) {
                         if (rfl & F_FIRST) row_open = false;
                         int key[C];
                         if (row_open) { keys_ld(key); fold_keys(key, rr[0], mk[0]); } else set_keys(key, rr[0], mk[0]);
 #pragma unroll
-                        for (int kk = 1; kk < KRUN; ++kk) if (kk < rnm) fold_keys(key, rr[kk], mk[kk]);
+                        for (int kk = 1; kk < KRUN; ++kk) if (kk < RN) fold_keys(key, rr[kk], mk[kk]);
                         row_open = true;
                         // the tail's row: its epilogue when this was its last group
                         if (rfl & F_LAST) { row_end(ri, ((rw1 >> 20) & 511) - 1, key); row_open = false; }
@@ -1262,7 +1280,7 @@ __global__ __launch_bounds__(64, C > 16 ? 2 : (kColmax != 0 ? RG_SWEEP16_FWD_WAV
                     for (int r = 0; r < H; ++r) bv[r] = rr[0][r];
 #pragma unroll
                     for (int kk = 1; kk < KRUN; ++kk)
-                        if (kk < rnm) {
+                        if (kk < RN) {
 #pragma unroll
                             for (int r = 0; r < H; ++r) bv[r] = pk_max(bv[r], rr[kk][r]);
                         }
@@ -1272,12 +1290,17 @@ __global__ __launch_bounds__(64, C > 16 ? 2 : (kColmax != 0 ? RG_SWEEP16_FWD_WAV
                     }
                     const int knm_row = ((rw1 >> 20) & 511) - 1;
                     int acc = -1;
-                    if (knm_row >= 0) {
+                    if (knm_row >= 0) [[likely]] {
 #pragma unroll
                         for (int r = 0; r < H; ++r) acc &= pk_sub_sat(bv[r], thz[kRec ? r : 0]);
                     } else {
+                        // (a row every path visits whose group retirement has thinned out to <= KRUN members: one threshold for the
+                        // lane.  Written as a maximum, not as the loop above with another operand: the compiler merged the two
+                        // loops into one behind eight v_mov selects of the threshold registers in EVERY row)
+                        int m = bv[0];
 #pragma unroll
-                        for (int r = 0; r < H; ++r) acc &= pk_sub_sat(bv[r], minplain2);
+                        for (int r = 1; r < H; ++r) m = pk_max(m, bv[r]);
+                        acc = pk_sub_sat(m, minplain2);
                     }
                     const bool lhit = ((unsigned)acc & 0x80008000u) != 0x80008000u;
                     if (__any(lhit)) {      // some half >= its threshold
@@ -1290,7 +1313,7 @@ __global__ __launch_bounds__(64, C > 16 ? 2 : (kColmax != 0 ? RG_SWEEP16_FWD_WAV
                             int hk[H];
 #pragma unroll
                             for (int kk = 0; kk < KRUN; ++kk)
-                                if (kk < rnm) {
+                                if (kk < RN) {
                                     int kv = mk[kk];
                                     asm volatile("" : "+v"(kv));      // (the path id through a VGPR: see set_keys)
 #pragma unroll
@@ -1307,12 +1330,12 @@ __global__ __launch_bounds__(64, C > 16 ? 2 : (kColmax != 0 ? RG_SWEEP16_FWD_WAV
                     int key[C];
                     set_keys(key, rr[0], mk[0]);
 #pragma unroll
-                    for (int kk = 1; kk < KRUN; ++kk) if (kk < rnm) fold_keys(key, rr[kk], mk[kk]);
+                    for (int kk = 1; kk < KRUN; ++kk) if (kk < RN) fold_keys(key, rr[kk], mk[kk]);
                     row_end(ri, ((rw1 >> 20) & 511) - 1, key);
                 }
                 if (semi_end) {
 #pragma unroll
-                    for (int kk = 0; kk < KRUN; ++kk) if (kk < rnm) end_fold(mk[kk], ri, rr[kk]);
+                    for (int kk = 0; kk < KRUN; ++kk) if (kk < RN) end_fold(mk[kk], ri, rr[kk]);
                     end_row_done(ri);
                 }
                 ++t;
@@ -1342,6 +1365,10 @@ __global__ __launch_bounds__(64, C > 16 ? 2 : (kColmax != 0 ? RG_SWEEP16_FWD_WAV
                 rleft = to_tail ? 0 : (nw0 >> 26) & 63;
                 if (kAhead) load_steps(rli, s);
             }
+            cells += (unsigned long long)nrows * (unsigned long long)__popcll(rgm);
+            done += (unsigned long long)nrows * (unsigned long long)RN;
+            };
+            run_dispatch_from<1, (KRUN > 0 ? KRUN : 1)>(run_rows, rnm);
             // ---- the run (and its tail) is over: rows in rr, t = the next record
             if (tail) {
                 if (semi_end && (rfl & F_LAST)) end_row_done(ri);
