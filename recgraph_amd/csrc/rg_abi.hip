@@ -44,6 +44,8 @@ Options& options() {
         o.layer_i32 = env("RG_LAYER_I32");
         { const char* v = getenv("RG_NO_RETIRE"); o.no_retire = v ? atoi(v) : 0; }
         o.no_pick2 = env("RG_NO_PICK2");
+        o.no_dsel = env("RG_NO_DSEL");
+        if (getenv("RG_DSEL_EDGE")) o.dsel_edge = std::max(1, atoi(getenv("RG_DSEL_EDGE")));
         o.no_order = env("RG_NO_ORDER");
         o.spin_wait = env("RG_SPIN_WAIT");
         { const char* v = getenv("RG_SPEC_MARGIN"); if (v) o.spec_margin = atoi(v); }
@@ -373,6 +375,8 @@ static std::atomic<int>* option_slot(const char* name) {
     if (!strcmp(name, "layer_i32")) return &o.layer_i32;
     if (!strcmp(name, "no_retire")) return &o.no_retire;
     if (!strcmp(name, "no_pick2")) return &o.no_pick2;
+    if (!strcmp(name, "no_dsel")) return &o.no_dsel;
+    if (!strcmp(name, "dsel_edge")) return &o.dsel_edge;
     if (!strcmp(name, "no_order")) return &o.no_order;
     if (!strcmp(name, "spin_wait")) return &o.spin_wait;
     if (!strcmp(name, "spec_margin")) return &o.spec_margin;

@@ -36,6 +36,8 @@ struct Options {
     std::atomic<int> stripe_c{0};       // RG_STRIPE_C: columns per lane of the striped long-read kernels (8, 16, 32; 0: 16 up to 8191 bases, else 32)
     std::atomic<int> no_retire{0};      // RG_NO_RETIRE: k_sweep16 computes every path to the end (no path retirement)
     std::atomic<int> no_order{0};       // RG_NO_ORDER: the sweeps' waves in read order (no longest-first launch order)
+    std::atomic<int> dsel_edge{8};      // RG_DSEL_EDGE: the 1 / dsel_edge of the rows each sweep visits first always store their direction words
+    std::atomic<int> no_dsel{0};        // RG_NO_DSEL: every (row, group) record of the packed sweeps stores its direction word (round 6: only those with a picked path)
     std::atomic<int> no_pick2{0};       // RG_NO_PICK2: the speculative bound from one-path picks only (no two-path picks)
     std::atomic<int> layer_i32{0};      // RG_LAYER_I32: k_layer in its i32 form even when the sweep ran packed (test hook)
     std::atomic<int> lds_pad{0};        // RG_LDS_PAD (experiments only): extra dynamic LDS bytes per k_sweep16 workgroup — lowers the waves per CU

@@ -323,6 +323,10 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
     const int score_scale = std::max(1, maxmatch / 2);
     const int spec_margin = ((nwv > 1 ? opt.spec_margin * ((max_n + 999) / 1000) : (int)opt.spec_margin) +
                              (spec_level == 1 ? 320 * ((max_n + 999) / 1000) : 0)) * (opt.spec_margin > 0 ? score_scale : 1);
+    // direction words on demand (k_sweep16, DIRECTION WORDS ON DEMAND): the record variants at <= 16 columns per lane, first pass
+    // only — a read that comes back because its final paths were not the picked ones stores every word the second time
+    const bool pick_two_used = spec && !semi && !opt.no_pick2;
+    const bool dsel = spec && use_rec && C <= 16 && nwv == 1 && spec_level == 0 && !opt.no_dsel;
     const int recw = 4 + C;
     if (w.fcap == 0) { w.fcap = (two_sweep && !use_rec) ? 1u << 20 : 1u << 15; w.rcap = use_rec ? 1u << 16 : 1u << 19; w.frec_cap = 1u << 14; w.rrec_cap = 1u << 13; }   // (round 6: 16 Ki / 8 Ki records of 80 B to start with instead of 64 Ki / 32 Ki — 2 MB per read instead of 7.9; a read that needs more regrows the lists and the chunk runs again, once per handle.  Config 5 with the two-path pick: forward mean ~11 k)
     stats.clear();
@@ -396,6 +400,8 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
             sa.fmembers = w.fmembers; sa.rmembers = w.rmembers;
             sa.maxmatch = maxmatch;      // (both sweeps: the retirement bound; the forward sweep's speculative thresholds)
         }
+        sa.dsel_pick = dsel ? w.pick.p : nullptr; sa.dsel_pick2 = dsel && pick_two_used ? w.pick2.p : nullptr;
+        { const int e = L / std::max(1, (int)opt.dsel_edge); sa.dsel_lo = e; sa.dsel_hi = L - 1 - e; }      // (an eighth of the rows at the end each sweep starts from)
         sa.rbw = p.rec_band_width; sa.cand_cap = 0; sa.dir_words = dir_words; sa.cells = d_cells;
         SeedArgs se;
         se.g = gd; se.state = w.state.p; se.nreads = chunk; se.mode = pmode; se.sc = sa.sc; se.reads = d_reads; se.read_off = off;
@@ -507,7 +513,7 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
             TIMED(T, "k_search", launch_search(sr, chunk, stream));
             // largest list / record counts of the chunk, read back once after the traceback (no host round trip here)
             launch_need(w.state.p, w.nf.p, w.nr.p, use_rec ? w.nrec.p : nullptr, use_rec ? w.nrrec.p : nullptr, w.need.p, chunk, stream);
-            if (spec) launch_verify(w.state.p, w.lb.p, w.need.p + 4, w.rt_flags.p, chunk, stream);
+            if (spec) launch_verify(w.state.p, w.lb.p, w.need.p + 4, w.rt_flags.p, chunk, dsel ? w.pick.p : nullptr, dsel && pick_two_used ? w.pick2.p : nullptr, sa.dsel_lo, sa.dsel_hi, stream);
         }
         LayerArgs la;
         memset(&la, 0, sizeof la);
@@ -587,6 +593,31 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
         cells_perf += w.h_sum[5];
         const unsigned nretry = spec ? reinterpret_cast<const unsigned*>(w.h_sum + 1)[4] : 0u;
         if (debug && spec) fprintf(stderr, "[rg] speculative bound (margin %d): %u of %d reads did not reach it\n", spec_margin, nretry, chunk);
+        if (debug && dsel) {
+            // which of the second-pass reads are there because of their paths, and what the paths were
+            std::vector<ReadState> hs((size_t)chunk);
+            std::vector<int> hp((size_t)chunk), hp2((size_t)chunk * 2, -1);
+            std::vector<int> hlb((size_t)chunk);
+            HIPCHK(hipMemcpy(hs.data(), w.state.p, sizeof(ReadState) * (size_t)chunk, hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpy(hp.data(), w.pick.p, sizeof(int) * (size_t)chunk, hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpy(hlb.data(), w.lb.p, sizeof(int) * (size_t)chunk, hipMemcpyDeviceToHost));
+            if (pick_two_used) HIPCHK(hipMemcpy(hp2.data(), w.pick2.p, sizeof(int) * 2 * (size_t)chunk, hipMemcpyDeviceToHost));
+            int nb = 0, npath = 0, shown = 0;
+            for (int i = 0; i < chunk; ++i) {
+                const ReadState& r = hs[(size_t)i];
+                if (!(r.status & ST_RETRY)) continue;
+                const bool bound_bad = r.fscore < (float)hlb[(size_t)i];
+                nb += bound_bad;
+                npath += !bound_bad;
+                if (!bound_bad && shown < 24) {
+                    ++shown;
+                    fprintf(stderr, "[rg]   read %d: picks %d / %d, final paths %d -> %d (rec col %d), score %.1f, bound %d\n", i, hp[(size_t)i], hp2[2 * (size_t)i],
+                            r.fwd_path, r.rev_path, r.rec_col, r.fscore, hlb[(size_t)i]);
+                    fprintf(stderr, "[rg]        fen %d rsn %d of %d rows\n", r.fen, r.rsn, L);
+                }
+            }
+            fprintf(stderr, "[rg] second pass: %d for the bound, %d for their paths\n", nb, npath);
+        }
         if (nretry) {
             // The speculative bound of these reads was above what they reach: pairs may have been pruned.  Align them again,
             // as a batch of their own, with the provable bound, and put the records in place.

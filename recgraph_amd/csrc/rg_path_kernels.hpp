@@ -24,6 +24,17 @@ struct Cand {
     int row, col, val, path;
 };
 
+// Direction word of k_sweep16 at C <= 16 (RowOps16::dir_word, LayerArgs::dir_fmt 1) -> U and L as bit-per-column masks in the
+// lane's column order (bit q = column q of the lane): register r of the packed row holds columns r and H + r and contributes
+// bit 7 - r of byte 0 (U, column r), byte 1 (U, column H + r), byte 2 (L, column r), byte 3 (L, column H + r)
+template <int H>
+__device__ __forceinline__ void dir16_decode(unsigned w, unsigned& u16, unsigned& l16) {
+    constexpr unsigned LOWH = (1u << H) - 1u;
+    const unsigned t = __brev(w);
+    u16 = ((t >> 24) & LOWH) | (((t >> 16) & LOWH) << H);
+    l16 = ((t >> 8) & LOWH) | ((t & LOWH) << H);
+}
+
 struct SweepArgs {
     PathGraphDev g;
     DevScores sc;
@@ -74,6 +85,15 @@ struct SweepArgs {
     const int* order;                   // launch order of the reads (block b sweeps read order[b]) or null: see launch_order
     unsigned long long table_members;   // member rows of the step table in use (k_sweep16 with path retirement counts cells from it)
     unsigned long long fmembers, rmembers;
+    // k_sweep16, DIRECTION WORDS ON DEMAND: the picks of k_pick (pick[rd]; pick2[2 rd] = second path or -1) — only the (row, group)
+    // records with one of those paths among their members store a direction word; k_verify sends a read whose final paths are
+    // not among them to the second pass.  Null: every record stores its word.
+    const int* dsel_pick;
+    const int* dsel_pick2;
+    // ... and every record of the rows the sweep visits first (forward: rows < dsel_lo, reverse: rows > dsel_hi) stores its word
+    // whatever its members: the reference's search likes to switch to another path for the last few columns of a read (ties
+    // among the paths of a shared end segment go to the highest path id), and such a path's layer is only rebuilt over those rows
+    int dsel_lo, dsel_hi;
 };
 
 // expands the (row, lane) records of the forward sweep into Cand entries, keeping only cells that can still reach
@@ -239,7 +259,7 @@ void launch_pick(const PickArgs& a, int nreads, hipStream_t s);
 // paths (every lower path leads it somewhere), from a few percent of a full sweep to all of it — longest first,
 // so that the launch does not end on a few full-length waves (one block: counting sort by that id, descending).
 void launch_order(const int* pick, const int* pick2, int* order, int nreads, hipStream_t s);
-void launch_verify(ReadState* st, const int* lb, unsigned* nretry, uint8_t* flags, int nreads, hipStream_t s);
+void launch_verify(ReadState* st, const int* lb, unsigned* nretry, uint8_t* flags, int nreads, const int* dsel_pick, const int* dsel_pick2, int dsel_lo, int dsel_hi, hipStream_t s);
 void launch_gather_reads(const uint8_t* reads, const long long* off, const int* idx, const long long* sub_off, uint8_t* out, int n, hipStream_t s);
 void launch_scatter_results(const int* idx, const DevRecord* sub_rec, const uint8_t* sub_ops, DevRecord* rec, uint8_t* ops, long long ops_stride, int n, hipStream_t s);
 void launch_threshold(const ThrArgs& a, int nreads, hipStream_t s);

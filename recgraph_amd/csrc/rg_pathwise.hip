@@ -879,16 +879,32 @@ __global__ __launch_bounds__(64) void k_pick(PickArgs a) {
     if (lane == 0) { a.pick2[2 * rd] = p2; a.pick2[2 * rd + 1] = X; }
 }
 
-// After k_search: the speculation held iff the maximum found is >= the bound the forward sweep pruned with.
-__global__ __launch_bounds__(256) void k_verify(ReadState* st, const int* lb, unsigned* nretry, uint8_t* flags, int nreads) {
+// After k_search: the speculation held iff the maximum found is >= the bound the forward sweep pruned with — and, when the
+// sweeps stored direction words for the picked paths only (SweepArgs::dsel_pick), iff the paths the traceback will walk are
+// among the picks.  A read that fails either way is aligned again (rg_path_driver.hip); k_layer / k_trace skip it.
+__global__ __launch_bounds__(256) void k_verify(ReadState* st, const int* lb, unsigned* nretry, uint8_t* flags, int nreads,
+                                                const int* dsel_pick, const int* dsel_pick2, int dsel_lo, int dsel_hi) {
     const int rd = blockIdx.x * blockDim.x + threadIdx.x;
     if (rd >= nreads) return;
     ReadState* rs = st + rd;
     uint8_t f = 0;
-    if (!(rs->status & (ST_BAD_BASE | ST_WOULD_PANIC | ST_OVERFLOW)) && rs->fscore < (float)lb[rd]) {
-        rs->status |= ST_RETRY;
-        f = 1;
-        atomicAdd(nretry, 1u);
+    if (!(rs->status & (ST_BAD_BASE | ST_WOULD_PANIC | ST_OVERFLOW))) {
+        bool bad = rs->fscore < (float)lb[rd];
+        if (dsel_pick) {
+            const int p1 = dsel_pick[rd], p2 = dsel_pick2 ? dsel_pick2[2 * rd] : -1;
+            const int fp = rs->fwd_path, rp = rs->rev_path;
+            // k_layer rebuilds the forward layer over the rows of fp up to fen (the whole path without a recombination) and the
+            // reverse layer over the rows of rp from its end back to rsn: every word it reads must have been stored
+            const bool recomb = fp != rp;
+            const bool fok = fp == p1 || fp == p2 || (recomb && rs->fen < dsel_lo);
+            const bool rok = !recomb || rp == p1 || rp == p2 || rs->rsn > dsel_hi;
+            bad = bad || !fok || !rok;
+        }
+        if (bad) {
+            rs->status |= ST_RETRY;
+            f = 1;
+            atomicAdd(nretry, 1u);
+        }
     }
     flags[rd] = f;
 }
@@ -1148,7 +1164,7 @@ __global__ __launch_bounds__(kStripes ? 512 : 64) void k_layer(LayerArgs a) {
     const int dww = WAVE * (C <= 16 ? 1 : 2);                                          // words of one stripe per row
     const PathGraphDev& g = a.g;
     ReadState* rs = a.state + rd;
-    if (rs->status & (ST_BAD_BASE | ST_WOULD_PANIC | ST_OVERFLOW)) return;
+    if (rs->status & (ST_BAD_BASE | ST_WOULD_PANIC | ST_OVERFLOW | ST_RETRY)) return;      // (ST_RETRY: aligned again; its direction words may not exist)
     const bool rev = a.rev;
     const int path = rev ? rs->rev_path : rs->fwd_path;
     const bool recomb = rs->fwd_path != rs->rev_path;
@@ -1231,7 +1247,7 @@ __global__ __launch_bounds__(kStripes ? 512 : 64) void k_layer(LayerArgs a) {
         const int g_i = sct[li * 6 + GAP];
         unsigned dmask = 0, lmask = 0;
         if (a.dir_fmt == 1) {
-            if (C <= 16) { dmask = ~word0 & 0xffffu; lmask = word0 >> 16; }
+            if (C <= 16) { unsigned u16, l16; dir16_decode<C / 2>(word0, u16, l16); dmask = ~u16 & 0xffffu; lmask = l16; }
             else { dmask = ~word0; lmask = word1; }
         } else if (C <= 16) {
             const uint32_t wv = word0;
@@ -1335,8 +1351,8 @@ __global__ __launch_bounds__(64) void k_trace(TraceArgs a) {
     if (rd >= a.nreads) return;
     ReadState* rs = a.state + rd;
     DevRecord* rec = a.rec + rd;
-    if (rs->status & (ST_BAD_BASE | ST_WOULD_PANIC | ST_OVERFLOW)) {
-        rec->status = rs->status; rec->n_ops = 0; rec->n_fwd_ops = 0; rec->score = 0;
+    if (rs->status & (ST_BAD_BASE | ST_WOULD_PANIC | ST_OVERFLOW | ST_RETRY)) {
+        rec->status = rs->status & ~ST_RETRY; rec->n_ops = 0; rec->n_fwd_ops = 0; rec->score = 0;      // (ST_RETRY: the second pass writes the record)
         return;
     }
     const long long ro = a.read_off[rd];
@@ -1499,8 +1515,8 @@ __global__ __launch_bounds__(1024) void k_order(const int* pick, const int* pick
 void launch_order(const int* pick, const int* pick2, int* order, int nreads, hipStream_t s) {
     hipLaunchKernelGGL(k_order, dim3(1), dim3(1024), 0, s, pick, pick2, order, nreads);
 }
-void launch_verify(ReadState* st, const int* lb, unsigned* nretry, uint8_t* flags, int nreads, hipStream_t s) {
-    hipLaunchKernelGGL(k_verify, dim3((nreads + 255) / 256), dim3(256), 0, s, st, lb, nretry, flags, nreads);
+void launch_verify(ReadState* st, const int* lb, unsigned* nretry, uint8_t* flags, int nreads, const int* dsel_pick, const int* dsel_pick2, int dsel_lo, int dsel_hi, hipStream_t s) {
+    hipLaunchKernelGGL(k_verify, dim3((nreads + 255) / 256), dim3(256), 0, s, st, lb, nretry, flags, nreads, dsel_pick, dsel_pick2, dsel_lo, dsel_hi);
 }
 void launch_gather_reads(const uint8_t* reads, const long long* off, const int* idx, const long long* sub_off, uint8_t* out, int n, hipStream_t s) {
     hipLaunchKernelGGL(k_gather_reads, dim3(n), dim3(256), 0, s, reads, off, idx, sub_off, out);

@@ -57,6 +57,9 @@ __device__ __forceinline__ int pk_sub(int a, int b) {
 __device__ __forceinline__ int pk_max(int a, int b) {
     return __builtin_bit_cast(int, __builtin_elementwise_max(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b)));
 }
+__device__ __forceinline__ int pk_min(int a, int b) {
+    return __builtin_bit_cast(int, __builtin_elementwise_min(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b)));
+}
 __device__ __forceinline__ int pk_minu(int a, int b) {
     return __builtin_bit_cast(int, __builtin_elementwise_min(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
 }
@@ -87,25 +90,34 @@ struct RowOps16 {
     // bit r = column r of the lane (low half), bit 16 + r = column H + r (high half)
     static constexpr unsigned FULL = H >= 16 ? 0xffffffffu : ((((1u << H) - 1u) << 16) | ((1u << H) - 1u));
 
-    // need_src (wave-uniform): the group has members besides its alpha (`src` is theirs alone)
-    static __device__ __forceinline__ void alpha(int (&row)[H], const int (&s)[H], int g_i, int g0, int lane,
-                                                 int (&MU)[H], int (&ML)[H], unsigned& umask, unsigned& lmask, int& src, bool need_src = true) {
+    // The alpha's row update.  Outputs the new row and the SIGN WORDS of its decisions: per half, XU[r] < 0 where the column took
+    // U (not D), XL[r] < 0 where it took L.  What is made of them is the caller's business (round 6): the full 0 / 0xffff masks the
+    // members select with (`masks`: sixteen v_pk_ashrrev, needed only by groups with members besides the alpha), the lane of the
+    // nearest non-L column to the left (`src_lane`), the direction word that k_layer16 reads (`dir_word`: only for groups
+    // that contain a path whose layer can be asked for, see DIRECTION WORDS ON DEMAND in k_sweep16).
+    // lmax: per half chain the largest value of the lane's columns in the new row (a by-product of the stitching)
+    static __device__ __forceinline__ void alpha(int (&row)[H], const int (&s)[H], int g_i, int g0, int lane, int (&XU)[H], int (&XL)[H], int& lmax) {
         const int GI = pack16(g_i, g_i);
         const int GI0 = lane == 0 ? pack16(g0, g_i) : GI;          // border column 0 adds g0
         int prev = __builtin_amdgcn_alignbit(row[H - 1], dpp_shr1(row[H - 1], NEGPAIR), 16);
-        int run = NEGPAIR;
-        unsigned um = 0;
+        int m[H];
 #pragma unroll
         for (int r = 0; r < H; ++r) {
             const int old = row[r];
             const int d = pk_add(prev, s[r]), u = pk_add(old, r == 0 ? GI0 : GI);
             const int du = pk_max(d, u);                            // D on ties (d >= u); lane 0 column 0: d = -inf -> U
-            MU[r] = pk_sign(pk_sub(d, du));                         // d - max(d, u) < 0 where U (|d - u| is a few scores: no wrap)
-            um |= (unsigned)MU[r] & ((unsigned)ONE2 << r);
-            run = pk_max(du, run);                                  // prefix maxima of the two half chains (no carry-in)
+            XU[r] = pk_sub(d, du);                                  // d - max(d, u) < 0 where U (|d - u| is a few scores: no wrap)
             row[r] = du;
+            m[r] = du;
             prev = old;
         }
+        // maxima of the two half chains (a tree: a serial chain of dependent packed instructions pays a wait state per link)
+#pragma unroll
+        for (int w = 1; w < H; w <<= 1) {
+#pragma unroll
+            for (int r = 0; r + w < H; r += 2 * w) m[r] = pk_max(m[r], m[r + w]);
+        }
+        const int run = m[0];
         // stitch: best source inside the lane = max of both chains; left scan over the lanes in z-space is a plain
         // prefix maximum
         const int TL = lo16(run), TH = hi16(run);
@@ -115,25 +127,52 @@ struct RowOps16 {
         const int bl = max(ze, NEG16);                              // carry into the lane's first column
         const int bh = max(TL, bl);                                 // carry into column H of the lane
         int vprev = pack16(bl, bh);
-        unsigned lm = 0;
+        lmax = pk_max(run, vprev);
 #pragma unroll
         for (int r = 0; r < H; ++r) {
             const int du = row[r];
             const int v = pk_max(du, vprev);
-            ML[r] = pk_sign(pk_sub(du, v));                         // du - max(du, left) < 0 where L (left strictly better)
-            lm |= (unsigned)ML[r] & ((unsigned)ONE2 << r);
+            XL[r] = pk_sub(du, v);                                  // du - max(du, left) < 0 where L (left strictly better)
             row[r] = v;
             vprev = v;
         }
-        // nearest lane to the left that owns a non-L column: highest set bit of the ballot below this lane (0 if none)
-        src = 0;
-        if (need_src) {
-            const unsigned long long have = __ballot((lm & FULL) != FULL) & ((1ull << lane) - 1ull);
-            src = have ? 63 - __clzll((long long)have) : 0;
-        }
-        umask = um; lmask = lm;
     }
-
+    // full masks for the members; returns `lall`: per half 0xffff iff EVERY column of that half chain took L.  It stands in for
+    // the L bit mask wherever the members test "does this chain have a non-L column" (~lall & FULL is non-zero exactly then)
+    static __device__ __forceinline__ unsigned masks(const int (&XU)[H], const int (&XL)[H], int (&MU)[H], int (&ML)[H]) {
+        int al = -1;
+#pragma unroll
+        for (int r = 0; r < H; ++r) { MU[r] = pk_sign(XU[r]); ML[r] = pk_sign(XL[r]); al &= ML[r]; }
+        return (unsigned)al;
+    }
+    // nearest lane to the left that owns a non-L column: highest set bit of the ballot below this lane (0 if none)
+    static __device__ __forceinline__ int src_lane(unsigned lall, int lane) {
+        const unsigned long long have = __ballot(lall != 0xffffffffu) & ((1ull << lane) - 1ull);
+        return have ? 63 - __clzll((long long)have) : 0;
+    }
+    // bit form of the decisions (bit r = column r of the lane, bit 16 + r = column H + r): what the 32-column variants store
+    static __device__ __forceinline__ unsigned sign_bits(const int (&X)[H]) {
+        unsigned b = 0;
+#pragma unroll
+        for (int r = 0; r < H; ++r) b |= ((unsigned)X[r] >> 15 & (unsigned)ONE2) << r;
+        return b;
+    }
+    // DIRECTION WORD of a row at C <= 16 (LayerArgs::dir_fmt 1, decoded by dir_word_decode): register r contributes four
+    // flags — U low column, U high column, L low column, L high column — as bit 7 - r of bytes 0 .. 3.  One v_perm collects
+    // the four sign bytes of (XU[r], XL[r]), one arithmetic shift (a 2-cycle form) moves them to the register's bit, one
+    // v_bitop3 (2-cycle) ORs them in under a mask: 8 + 7 + 8 instructions per row for both masks, where the bit-per-column
+    // form took 16 packed shifts, 16 ANDs, 8 three-way ORs and a v_perm.
+    static __device__ __forceinline__ unsigned dir_word(const int (&XU)[H], const int (&XL)[H]) {
+        static_assert(H <= 8, "one byte per flag kind");
+        unsigned w = 0;
+#pragma unroll
+        for (int r = 0; r < H; ++r) {
+            const int p = (int)__builtin_amdgcn_perm((unsigned)XL[r], (unsigned)XU[r], 0x07050301u);
+            const int sh = r == 0 ? p : (p >> r);                   // (arithmetic: the copies of the top bit stay above bit 31 - r)
+            w = (unsigned)__builtin_amdgcn_bitop3_b32((int)w, sh, (int)(0x80808080u >> r), 0xF8);   // w | (sh & mask)
+        }
+        return w;
+    }
     // SEL[r]: per half what a member adds to the source the alpha chose there (g_i under the U cells, s - g under the D
     // cells); computed once per group that has members besides its alpha
     static __device__ __forceinline__ void select_steps(int (&SEL)[H], const int (&s)[H], const int (&MU)[H], int g_i, int g0, int lane) {
@@ -423,6 +462,7 @@ __global__ __launch_bounds__(64, C > 16 ? 2 : (kColmax != 0 ? RG_SWEEP16_FWD_WAV
 #define THRK(q) thrk[(kRec || !kTrack) ? 0 : (q)]
     int thz[kRec ? H : 1];               // packed (threshold >> 16) pairs, see below
     int minplain2 = 0;
+    int thzmin = 0;                      // per half chain of the lane: the lowest of its packed thresholds (signed)
     int next_eval = INT32_MAX;           // PATH RETIREMENT: the record index of the next evaluation (INT32_MAX: off for this read)
     int minthrk = INT32_MAX;             // lowest threshold of the lane
     int minplain = INT32_MAX;            // lowest threshold of the lane without the member rule (rows every path visits)
@@ -477,6 +517,12 @@ __global__ __launch_bounds__(64, C > 16 ? 2 : (kColmax != 0 ? RG_SWEEP16_FWD_WAV
         for (int r = 0; r < (kRec ? H : 1); ++r)
             thz[kRec ? r : 0] = pack16(thr_key(kRec ? r : 0, true) >> 16, thr_key(kRec ? r + H : 0, true) >> 16);
         minplain2 = pack16(minplain >> 16, minplain >> 16);
+        {
+            int m = thz[0];
+#pragma unroll
+            for (int r = 1; r < (kRec ? H : 1); ++r) m = pk_min(m, thz[kRec ? r : 0]);
+            thzmin = m;
+        }
 #ifdef RG_SWEEP16_LANEMIN
         // (experiment: one threshold per lane — the lowest of its columns — instead of one per column: how many more records?)
         {
@@ -568,7 +614,8 @@ __global__ __launch_bounds__(64, C > 16 ? 2 : (kColmax != 0 ? RG_SWEEP16_FWD_WAV
     unsigned long long cells = 0, done = 0;
     Cand* cand = !kRec && a.cand ? a.cand + (long long)rd * a.cand_cap : nullptr;
     uint32_t* dirs = a.dirs ? a.dirs + (long long)rd * a.dirs_stride : nullptr;
-    const bool track = kTrack && a.track_best;
+    // (the record variants always track — the driver sets track_best for every record sweep —: a compile-time constant there)
+    const bool track = kRec ? true : (kTrack && a.track_best);
     // (direction words of this read: at most 2^20 slots of 64 or 128 words)
     const __amdgpu_buffer_rsrc_t dirs_rsrc = uniform_rsrc(dirs, dirs ? (unsigned)min(a.dirs_stride * 4ll, 0x7fffffffll) : 0u);
 
@@ -696,26 +743,44 @@ __global__ __launch_bounds__(64, C > 16 ? 2 : (kColmax != 0 ? RG_SWEEP16_FWD_WAV
             ncand += (unsigned)total;
         }
     };
-    // direction words, format 1 (LayerArgs::dir_fmt): C <= 16: one word per lane, U bits of the C columns in the low
-    // half and L bits in the high half; C = 32: word 0 = U bits, word 1 = L bits (the masks already are in column order)
-    auto store_dirs = [&](int slot, unsigned umask, unsigned lmask) {
+    // direction words, format 1 (LayerArgs::dir_fmt): C <= 16: one word per lane (RowOps16::dir_word); C = 32: word 0 = U bits,
+    // word 1 = L bits (bit r = column r of the lane, bit 16 + r = column H + r)
+    auto store_dirs = [&](int slot, const int (&XU)[H], const int (&XL)[H]) {
 #ifdef RG_SWEEP16_NODIRS
         return;
 #endif
-        if (C <= 16) {
-            const unsigned u16 = (umask & ((1u << H) - 1u)) | ((umask >> (16 - H)) & (((1u << H) - 1u) << H));
-            const unsigned l16 = (lmask & ((1u << H) - 1u)) | ((lmask >> (16 - H)) & (((1u << H) - 1u) << H));
+        if constexpr (C <= 16) {
+            const unsigned w = RowOps16<C>::dir_word(XU, XL);
 #ifndef RG_SWEEP16_FLATDIRS
-            __builtin_amdgcn_raw_buffer_store_b32(u16 | (l16 << 16), dirs_rsrc, lane * 4, slot * (a.dir_words * 4), 0);
+            __builtin_amdgcn_raw_buffer_store_b32(w, dirs_rsrc, lane * 4, slot * (a.dir_words * 4), 0);
 #else
-            dirs[(long long)slot * a.dir_words + lane] = u16 | (l16 << 16);
+            dirs[(long long)slot * a.dir_words + lane] = w;
 #endif
         } else {
-            dirs[(long long)slot * a.dir_words + lane] = umask;
-            dirs[(long long)slot * a.dir_words + WAVE + lane] = lmask;
+            dirs[(long long)slot * a.dir_words + lane] = RowOps16<C>::sign_bits(XU);
+            dirs[(long long)slot * a.dir_words + WAVE + lane] = RowOps16<C>::sign_bits(XL);
         }
     };
-
+    // DIRECTION WORDS ON DEMAND (round 6).  A direction word is read by k_layer16 only when the traceback walks a path of that
+    // (row, group) — the forward layer of the read's final forward path, the reverse layer of its reverse path — and a row
+    // without members besides its alpha spent 40 % of its vector instructions on that word (sixteen packed subtractions for the
+    // signs, the bit gathering, the store).  When the batch runs on a speculative bound the final paths are all but known
+    // before the sweep: k_pick's one or two paths.  `dsel` = those paths; a (row, group) record computes and stores its word
+    // only if its members include one of them.  k_verify checks afterwards that the paths k_search chose are in `dsel` and
+    // sends the read to the second pass otherwise (it stores every word: a.pick is null there), exactly like a read whose
+    // speculative bound failed.  Sweeps without picks (no speculation: -m 4 / 5 / 9, more than 64 paths, three sweeps) store all.
+    unsigned long long dsel = ~0ull;
+    if (a.dsel_pick) {
+        const int p1 = a.dsel_pick[rd], p2 = a.dsel_pick2 ? a.dsel_pick2[2 * rd] : -1;
+        dsel = (1ull << (p1 & 63)) | (p2 >= 0 ? 1ull << (p2 & 63) : 0ull);
+    }
+    const unsigned dsel_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)dsel), dsel_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(dsel >> 32));
+    const unsigned long long dsel_u = ((unsigned long long)dsel_hi << 32) | dsel_lo;
+    // (kColmax == 1, the first sweep of the three-sweep pipeline, runs without direction words at all)
+    // (the rows a sweep visits first store every word: SweepArgs::dsel_lo / dsel_hi)
+    auto want_dirs = [&](unsigned long long members, int row) -> bool {
+        return (kColmax != 1 || dirs != nullptr) && ((members & dsel_u) != 0ull || (rev ? row > a.dsel_hi : row < a.dsel_lo));
+    };
     const int4* steps = rev ? a.rsteps : a.fsteps;
     const int nsteps = rev ? a.nrsteps : a.nfsteps;
     int4 recs = make_int4(0, 0, 0, 0);
@@ -1044,13 +1109,13 @@ __global__ __launch_bounds__(64, C > 16 ? 2 : (kColmax != 0 ? RG_SWEEP16_FWD_WAV
             for (int step = 0;; ++step) {
                 const int g_i = gcost;
                 const int g0 = kSemi ? 0 : g_i;
-                int s[H], MU[H], ML[H];
-                unsigned lmask;
-                int src;
+                int s[H], MU[H], ML[H], XU[H], XL[H];
                 load_steps(rli, s);
-                unsigned umask;
-                RowOps16<C>::alpha(A, s, g_i, g0, lane, MU, ML, umask, lmask, src);
-                if (dirs) store_dirs(rslot, umask, lmask);
+                int lmax_unused;
+                RowOps16<C>::alpha(A, s, g_i, g0, lane, XU, XL, lmax_unused);
+                if (want_dirs(gmask, ri)) store_dirs(rslot, XU, XL);      // (kbase = 0: gather runs are narrow-graph only)
+                const unsigned lmask = RowOps16<C>::masks(XU, XL, MU, ML);
+                const int src = RowOps16<C>::src_lane(lmask, lane);
                 RowOps16<C>::template member<true>(G, MU, lane, MU, ML, lmask, src);   // the gather follows the directions, adds nothing (SEL unused)
                 cells += (unsigned long long)nm;
                 done += 2ull;
@@ -1223,22 +1288,23 @@ __global__ __launch_bounds__(64, C > 16 ? 2 : (kColmax != 0 ? RG_SWEEP16_FWD_WAV
             // meet (profiles/r05_isa_sweep16.txt: 25 % of the hot loop's issue slots were SALU / branch / wait)
             auto run_rows = [&](auto rn_tag) __attribute__((always_inline)) {
             constexpr int RN = decltype(rn_tag)::value;
+            const unsigned long long run_sel = kWide ? ~0ull : rgm;     // (every row of the run — and its tail — has the run's members)
             unsigned nrows = 0;                 // rows of this run: the cell counters move once per run, not once per row
             while (true) {
                 const int g_i = gcost;
                 const int g0 = kSemi ? 0 : g_i;
-                int MU[H], ML[H];
-                unsigned lmask;
-                int src;
+                int XU[H], XL[H];
 #if defined(RG_SWEEP16_STALLSTAT) && RG_SWEEP16_STALLSTAT == 3
                 ++st_nrun;
 #endif
                 if (!kAhead) load_steps(rli, s);
-                unsigned umask;
-                // (at 32 columns per lane `src` stays unconditional: the branch costs that variant 54 more spilled registers)
-                RowOps16<C>::alpha(rr[0], s, g_i, g0, lane, MU, ML, umask, lmask, src, C > 16 || RN > 1);
-                if (dirs) store_dirs(rslot, umask, lmask);
+                int lmax;
+                RowOps16<C>::alpha(rr[0], s, g_i, g0, lane, XU, XL, lmax);
+                if (want_dirs(run_sel, ri)) store_dirs(rslot, XU, XL);
                 if constexpr (RN > 1) {
+                    int MU[H], ML[H];
+                    const unsigned lmask = RowOps16<C>::masks(XU, XL, MU, ML);
+                    const int src = RowOps16<C>::src_lane(lmask, lane);
                     // (SEL is defined and used under ONE condition: with `if (rnm > 1) select_steps` beside member loops guarded
                     // by `kk < rnm` the compiler carried its eight registers around the whole record loop)
                     int SEL[H];
@@ -1290,7 +1356,16 @@ __global__ __launch_bounds__(64, C > 16 ? 2 : (kColmax != 0 ? RG_SWEEP16_FWD_WAV
                     }
                     const int knm_row = ((rw1 >> 20) & 511) - 1;
                     int acc = -1;
-                    if (knm_row >= 0) [[likely]] {
+                    // (a row without members besides its alpha: the lane's largest value per half chain is known from the alpha's
+                    // stitching, so one packed compare against the lane's lowest threshold per half decides for the wave whether
+                    // the per-column test is needed at all — in the reverse sweep it rarely is: ~800 records per read and sweep)
+                    bool fine = true;
+                    if constexpr (RN == 1 && kRec) {
+                        if (knm_row >= 0) fine = __any(((unsigned)pk_sub_sat(lmax, thzmin) & 0x80008000u) != 0x80008000u);
+                    }
+                    if (!fine) {
+                        // no column of any lane can reach its threshold
+                    } else if (knm_row >= 0) [[likely]] {
 #pragma unroll
                         for (int r = 0; r < H; ++r) acc &= pk_sub_sat(bv[r], thz[kRec ? r : 0]);
                     } else {
@@ -1472,15 +1547,18 @@ __global__ __launch_bounds__(64, C > 16 ? 2 : (kColmax != 0 ? RG_SWEEP16_FWD_WAV
 #if defined(RG_SWEEP16_STALLSTAT) && RG_SWEEP16_STALLSTAT == 1
                 { RG_STALL_BEGIN(); RG_STALL_END(st_gen); }
 #endif
-                unsigned umask;
-                RowOps16<C>::alpha(rowa, s, g_i, g0, lane, MU, ML, umask, lmask, src);
+                int XU[H], XL[H];
+                int lmax_unused;
+                RowOps16<C>::alpha(rowa, s, g_i, g0, lane, XU, XL, lmax_unused);
                 RG_ROW_ST(ga, rowa);
+                if (want_dirs(kWide ? ~0ull : gmask, i)) store_dirs(slot, XU, XL);
+                lmask = RowOps16<C>::masks(XU, XL, MU, ML);
+                src = RowOps16<C>::src_lane(lmask, lane);
                 if (track) {
                     if (!have) set_keys(key, rowa, ga); else fold_keys(key, rowa, ga);
                     have = true;
                 }
                 if (semi_end) end_fold(ga, i, rowa);
-                if (dirs) store_dirs(slot, umask, lmask);
             }
             // (a continuation entry — members of another page of the group the previous entry started — takes MU / ML / lmask /
             // src from that entry's alpha.  SEL is built unconditionally: eight instructions on a rare path, and no array that
@@ -1727,7 +1805,7 @@ __global__ __launch_bounds__(64) void k_layer16(LayerArgs a) {
     const int lane = threadIdx.x;
     const PathGraphDev& g = a.g;
     ReadState* rs = a.state + rd;
-    if (rs->status & (ST_BAD_BASE | ST_WOULD_PANIC | ST_OVERFLOW)) return;
+    if (rs->status & (ST_BAD_BASE | ST_WOULD_PANIC | ST_OVERFLOW | ST_RETRY)) return;
     const bool rev = a.rev;
     const int path = rev ? rs->rev_path : rs->fwd_path;
     const bool recomb = rs->fwd_path != rs->rev_path;
@@ -1799,10 +1877,11 @@ __global__ __launch_bounds__(64) void k_layer16(LayerArgs a) {
         const int GI0 = lane == 0 ? pack16(g0, g_i) : GI;
         // direction masks of the row in the packed-bit form of k_sweep16 (bit r: column r of the lane, bit 16 + r: column H + r)
         unsigned um2, lm2;
-        if (C <= 16) {
-            const unsigned uu = word0 & 0xffffu, ll = word0 >> 16;
-            um2 = (uu & LOWH) | (((uu >> H) & LOWH) << 16);
-            lm2 = (ll & LOWH) | (((ll >> H) & LOWH) << 16);
+        if constexpr (C <= 16) {
+            // (RowOps16::dir_word: after a bit reversal byte 3 = U of the low columns, bit r = register r; byte 2 = U high; 1 = L low; 0 = L high)
+            const unsigned t = __brev(word0);
+            um2 = ((t >> 24) & LOWH) | (t & (LOWH << 16));
+            lm2 = ((t >> 8) & LOWH) | ((t & LOWH) << 16);
         } else { um2 = word0; lm2 = word1; }
         int s[H], MU[H], ML[H], SEL[H];
         {
