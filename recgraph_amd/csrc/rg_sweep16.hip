@@ -157,7 +157,7 @@ struct RowOps16 {
         for (int r = 0; r < H; ++r) b |= ((unsigned)X[r] >> 15 & (unsigned)ONE2) << r;
         return b;
     }
-    // DIRECTION WORD of a row at C <= 16 (LayerArgs::dir_fmt 1, decoded by dir_word_decode): register r contributes four
+    // DIRECTION WORD of a row at C <= 16 (LayerArgs::dir_fmt 1, decoded by dir16_decode, rg_path_kernels.hpp): register r contributes four
     // flags — U low column, U high column, L low column, L high column — as bit 7 - r of bytes 0 .. 3.  One v_perm collects
     // the four sign bytes of (XU[r], XL[r]), one arithmetic shift (a 2-cycle form) moves them to the register's bit, one
     // v_bitop3 (2-cycle) ORs them in under a mask: 8 + 7 + 8 instructions per row for both masks, where the bit-per-column
@@ -173,6 +173,7 @@ struct RowOps16 {
         }
         return w;
     }
+
     // SEL[r]: per half what a member adds to the source the alpha chose there (g_i under the U cells, s - g under the D
     // cells); computed once per group that has members besides its alpha
     static __device__ __forceinline__ void select_steps(int (&SEL)[H], const int (&s)[H], const int (&MU)[H], int g_i, int g0, int lane) {
@@ -315,8 +316,13 @@ __device__ __forceinline__ void run_dispatch_from(F& f, int n) {
 // kSemi = true: the semiglobal modes (-m 5 / -m 9: zero first column, per-path end rows).  A template flag since round 5: the
 // end-row bookkeeping (four per-lane registers of state, sixteen column-select masks in SGPRs) was carried — spilled — through
 // the record loop of every global-mode sweep
+#ifdef RG_SWEEP16_VGPR_CAP
+#define RG_SWEEP16_CAP_ATTR __attribute__((amdgpu_num_vgpr(RG_SWEEP16_VGPR_CAP)))      // (experiments: a hard register budget)
+#else
+#define RG_SWEEP16_CAP_ATTR
+#endif
 template <int C, int kColmax, bool kRec, bool kWide, bool kSemi>
-__global__ __launch_bounds__(64, C > 16 ? 2 : (kColmax != 0 ? RG_SWEEP16_FWD_WAVES : RG_SWEEP16_REV_WAVES)) void k_sweep16(SweepArgs a) {
+__global__ __launch_bounds__(64, C > 16 ? 2 : (kColmax != 0 ? RG_SWEEP16_FWD_WAVES : RG_SWEEP16_REV_WAVES)) RG_SWEEP16_CAP_ATTR void k_sweep16(SweepArgs a) {
     constexpr int H = C / 2;
     constexpr bool kTrack = kColmax != 0 || kRec;      // <0, false>: the -m 4 / -m 5 sweep — no best member, no thresholds, no emission
     // gather runs: not at 32 columns per lane in the record variants (a row is 16 registers there: the run's A / G / masks / steps /
@@ -324,7 +330,9 @@ __global__ __launch_bounds__(64, C > 16 ? 2 : (kColmax != 0 ? RG_SWEEP16_FWD_WAV
     constexpr bool kGather = C <= 16 || !kRec || RG_SWEEP16_GATHER32;
     constexpr bool kRet = kRec && kColmax != 1 && !kWide && !kSemi;   // PATH RETIREMENT (record pipelines of -m 8, P <= 64): see retire_eval
     // rows kept in registers across the inner rows of a segment: groups of up to 4 paths (2 at 32 columns per lane: a row is 16 registers there)
-    constexpr int KRUN = C <= 16 ? (kColmax != 0 ? RG_SWEEP16_KRUN : RG_SWEEP16_KRUN_REV) : ((kRec && kColmax == 0 && !kWide) ? 2 : 0);
+    // (the -m 4 / -m 5 variant: 3 — with 4 the specialised run loops of round 6 need 178 registers and the variant falls from three
+    // waves per SIMD to two: config 4 271 k against 296 k reads/s)
+    constexpr int KRUN = C <= 16 ? (!kTrack ? (RG_SWEEP16_KRUN < 3 ? RG_SWEEP16_KRUN : 3) : (kColmax != 0 ? RG_SWEEP16_KRUN : RG_SWEEP16_KRUN_REV)) : ((kRec && kColmax == 0 && !kWide) ? 2 : 0);
     const int rd = a.order ? a.order[blockIdx.x] : blockIdx.x;      // (launch order: see launch_order)
 #ifdef RG_SWEEP16_STALLSTAT
     // (statistics build, tools/probes/stall_stat.py: shader-clock cycles a wave spends in the waits for row loads; the cell
@@ -612,6 +620,13 @@ __global__ __launch_bounds__(64, C > 16 ? 2 : (kColmax != 0 ? RG_SWEEP16_FWD_WAV
     // 8d); done: row operators actually applied — the same number except in gather runs, which do per row the alpha and
     // the column map, and per member one pass at each end of the run instead of one update per row
     unsigned long long cells = 0, done = 0;
+#ifdef RG_SWEEP16_ROWSTAT
+    // (statistics build, gpurun_tmp: rows by kind for a few reads, printed from the device)
+    unsigned st_rn[5] = {0, 0, 0, 0, 0}, st_grow = 0, st_gmem = 0, st_gen = 0, st_genmem = 0, st_dirs = 0, st_skip = 0, st_tail = 0;
+#define RG_ROWSTAT(x) x
+#else
+#define RG_ROWSTAT(x) ((void)0)
+#endif
     Cand* cand = !kRec && a.cand ? a.cand + (long long)rd * a.cand_cap : nullptr;
     uint32_t* dirs = a.dirs ? a.dirs + (long long)rd * a.dirs_stride : nullptr;
     // (the record variants always track — the driver sets track_best for every record sweep —: a compile-time constant there)
@@ -629,7 +644,7 @@ __global__ __launch_bounds__(64, C > 16 ? 2 : (kColmax != 0 ? RG_SWEEP16_FWD_WAV
         if (has) {
             const unsigned before = __builtin_amdgcn_mbcnt_hi((unsigned)(has >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)has, 0u));
             const unsigned pos = ncand + before;
-            mine = ((has >> lane) & 1ull) && pos < a.frec_cap;
+            mine = lane_hit && pos < a.frec_cap;      // (lane_hit IS this lane's bit of `has`: no 64-bit lane mask to keep in registers)
             rp = reinterpret_cast<int4*>(reinterpret_cast<char*>(a.frec + (long long)rd * a.frec_cap * (4 + C)) + pos * (unsigned)((4 + C) * sizeof(int)));
             if (mine) rp[0] = make_int4((i << 6) | lane, 0, 0, 0);
             ncand += (unsigned)__popcll(has);
@@ -1113,6 +1128,7 @@ __global__ __launch_bounds__(64, C > 16 ? 2 : (kColmax != 0 ? RG_SWEEP16_FWD_WAV
                 load_steps(rli, s);
                 int lmax_unused;
                 RowOps16<C>::alpha(A, s, g_i, g0, lane, XU, XL, lmax_unused);
+                RG_ROWSTAT((++st_grow, st_gmem += nme, st_dirs += want_dirs(gmask, ri) ? 1 : 0));
                 if (want_dirs(gmask, ri)) store_dirs(rslot, XU, XL);      // (kbase = 0: gather runs are narrow-graph only)
                 const unsigned lmask = RowOps16<C>::masks(XU, XL, MU, ML);
                 const int src = RowOps16<C>::src_lane(lmask, lane);
@@ -1300,6 +1316,7 @@ __global__ __launch_bounds__(64, C > 16 ? 2 : (kColmax != 0 ? RG_SWEEP16_FWD_WAV
                 if (!kAhead) load_steps(rli, s);
                 int lmax;
                 RowOps16<C>::alpha(rr[0], s, g_i, g0, lane, XU, XL, lmax);
+                RG_ROWSTAT((++st_rn[RN], st_dirs += want_dirs(run_sel, ri) ? 1 : 0, st_tail += tail ? 1 : 0));
                 if (want_dirs(run_sel, ri)) store_dirs(rslot, XU, XL);
                 if constexpr (RN > 1) {
                     int MU[H], ML[H];
@@ -1551,6 +1568,7 @@ __global__ __launch_bounds__(64, C > 16 ? 2 : (kColmax != 0 ? RG_SWEEP16_FWD_WAV
                 int lmax_unused;
                 RowOps16<C>::alpha(rowa, s, g_i, g0, lane, XU, XL, lmax_unused);
                 RG_ROW_ST(ga, rowa);
+                RG_ROWSTAT((++st_gen, st_genmem += nme, st_dirs += want_dirs(kWide ? ~0ull : gmask, i) ? 1 : 0));
                 if (want_dirs(kWide ? ~0ull : gmask, i)) store_dirs(slot, XU, XL);
                 lmask = RowOps16<C>::masks(XU, XL, MU, ML);
                 src = RowOps16<C>::src_lane(lmask, lane);
@@ -1593,6 +1611,11 @@ __global__ __launch_bounds__(64, C > 16 ? 2 : (kColmax != 0 ? RG_SWEEP16_FWD_WAV
         if (e_adv) ++t;
     }
 
+#ifdef RG_SWEEP16_ROWSTAT
+    if (lane == 0 && (rd == 0 || rd == 1 || rd == 7 || rd == 100))
+        printf("[rowstat] read %d %s: run rows by members 1:%u 2:%u 3:%u 4:%u (tails %u), gather rows %u (members %u), general records %u (members %u), direction words %u, records %d\n",
+               rd, rev ? "rev" : "fwd", st_rn[1], st_rn[2], st_rn[3], st_rn[4], st_tail, st_grow, st_gmem, st_gen, st_genmem, st_dirs, nsteps);
+#endif
     // ---- outputs ----
     if (kColmax == 1 && a.colmax_out) {
 #pragma unroll
@@ -1798,8 +1821,15 @@ void launch_colmax_rec(const ExpandArgs& a, int* colmax_out, int* colarg_out, in
 // sweep's z-space (z = A - c * g): d, u and l of one cell are compared at the same column, so the comparison is the same.
 // The walkers take the L step's cost from the key ('-', read base), the sweep from (read base, '-'): the
 // driver only sends batches here whose two gap tables agree (every CLI matrix); others keep the i32 form.
+// k_layer16 at <= 16 columns per lane is compiled for 64 registers (8 waves per SIMD; 70 before, one register spilled now).  Not for
+// its own occupancy: in the stream it runs beside the sweeps of the other handles, two sweep waves of 224 registers leave 64 of a
+// SIMD's 512, and a kernel that does not fit waits for a sweep wave to retire and then holds that wave's slot (k_layer_fwd took
+// 7-8 ms in the stream against 2.7 alone).  Config 5: 117.2 k -> 119.7 k reads/s (A/B/A/B/A/B on one box, profiles/r06_notes.md).
+#ifndef RG_LAYER16_WAVES
+#define RG_LAYER16_WAVES 8
+#endif
 template <int C>
-__global__ __launch_bounds__(64) void k_layer16(LayerArgs a) {
+__global__ __launch_bounds__(64, C <= 16 ? RG_LAYER16_WAVES : 1) void k_layer16(LayerArgs a) {
     constexpr int H = C / 2;
     const int rd = blockIdx.x;
     const int lane = threadIdx.x;
@@ -1849,7 +1879,10 @@ __global__ __launch_bounds__(64) void k_layer16(LayerArgs a) {
     const int start_col = recomb ? rs->rec_col : n;
     constexpr unsigned FULL = RowOps16<C>::FULL;
     constexpr unsigned LOWH = H >= 16 ? 0xffffu : ((1u << H) - 1u);
-    constexpr int PF = 4;
+#ifndef RG_LAYER16_PF
+#define RG_LAYER16_PF 2      // (rows fetched ahead: 4 until round 6 — see RG_LAYER16_WAVES)
+#endif
+    constexpr int PF = RG_LAYER16_PF;
     int pf_li[PF], pf_row[PF];
     uint32_t pf_w0[PF], pf_w1[PF];
     auto prefetch = [&](int tt, int& li_o, int& row_o, uint32_t& w0_o, uint32_t& w1_o) {
