@@ -405,6 +405,7 @@ class StepGather:
         self.parts = []                # rank 0: per step, the list of per-rank payloads
         self.bytes = 0
         self.busy_s = 0.0
+        self.host_waits = 0            # ranks > 0: times the fixed-capacity gather had to wait for a ring slot
         self.items = []
         self.cv = threading.Condition()
         self.done = False
@@ -437,22 +438,39 @@ class StepGather:
 
     def _run(self):
         import torch
-        from recgraph_amd.shard import gather_parts
+        from recgraph_amd.shard import FixedGather, gather_parts
         try:
             if self.device != "cpu":
                 torch.cuda.set_device(self.device)
+            fixed = None
             while True:
                 with self.cv:
                     while not self.items and not self.done:
                         self.cv.wait()
                     if not self.items:
-                        return
+                        break
                     data = self.items.pop(0)
                 t0 = time.perf_counter()
-                parts, sizes = gather_parts(data, self.rank, self.world, self.device)
+                if fixed is None:
+                    # the first step goes through the variable-length gather — every rank learns every rank's size there —
+                    # and sizes the fixed-capacity gather of all later steps (4 x the largest payload: a tile's text is
+                    # within a few per cent of the next tile's): no host synchronisation on ranks > 0 from then on
+                    parts, sizes = gather_parts(data, self.rank, self.world, self.device)
+                    if self.rank == 0:
+                        self.parts.append(parts)             # kept as tensors: no per-part bytes objects
+                        self.bytes += sum(sizes)
+                    fixed = FixedGather(self.rank, self.world, self.device, cap=4 * max(1024, max(sizes)))
+                else:
+                    fixed.submit(data)
+                self.busy_s += time.perf_counter() - t0
+            if fixed is not None:
+                t0 = time.perf_counter()
+                res, sizes = fixed.finish()
                 if self.rank == 0:
-                    self.parts.append(parts)             # kept as tensors: no per-part bytes objects
-                    self.bytes += sum(sizes)
+                    for pr, sz in zip(res, sizes):
+                        self.parts.append(pr)
+                        self.bytes += sum(sz)
+                self.host_waits = fixed.host_waits
                 self.busy_s += time.perf_counter() - t0
         except Exception as ex:      # surfaced by finish()
             self.err = ex
@@ -714,6 +732,12 @@ def main():
             ct = torch.tensor([res["cells"], float(nreads), res["cells_perf"], cpu_s], dtype=torch.float64, device=cdev)
             dist.all_reduce(ct, op=dist.ReduceOp.SUM)
             res["cells"], res["reads_all"], res["cells_perf"], res["cpu_s_all"] = float(ct[0].item()), int(ct[1].item()), float(ct[2].item()), float(ct[3].item())
+            # per rank: CPU seconds of the region and the gather's ring waits (what an 8-GPU run asks of the host, rank by rank)
+            pr = torch.tensor([cpu_s, float(gather.host_waits)], dtype=torch.float64, device=cdev)
+            prs = [torch.zeros_like(pr) for _ in range(world)]
+            dist.all_gather(prs, pr)
+            res["cpu_s_per_rank"] = [float(x[0].item()) for x in prs]
+            res["gather_ring_waits_per_rank"] = [int(x[1].item()) for x in prs]
         return res
 
     k0 = main_stream.kernel_stats()
@@ -937,6 +961,8 @@ def main():
         # summed over the ranks: what an N-GPU run asks of the host
         "host_cpu_s_per_step": round(head["cpu_s_all"] / max(1, args.steps), 4),
         "host_cpus_busy": round(head["cpu_s_all"] / dt, 2),
+        "host_cpus_busy_per_rank": [round(c / dt, 2) for c in head["cpu_s_per_rank"]] if "cpu_s_per_rank" in head else None,
+        "gather_ring_waits_per_rank": head.get("gather_ring_waits_per_rank"),
         # work buffers in HBM per read of a chunk (pathwise modes; x tile reads x handles = what the stream holds)
         "hbm_work_bytes_per_read": hbm_per_read,
         "hbm_work_GB_held": round(hbm_per_read * batch * handles_used / 1e9, 2) if hbm_per_read else None,

@@ -147,3 +147,51 @@ def test_bench_step_pipeline_shapes():
     for extra in (["--handles", "1"], ["--handles", "2"], ["--handles", "3"]):
         d = _run_bench(extra, {})
         assert d["n_gpus"] == 1 and d["gaf_bytes_gathered"] == per_rank, extra
+
+
+def _fixed_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from recgraph_amd.shard import FixedGather
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = FixedGather(rank, world, "cpu", cap=64, depth=3)
+    steps = 8                                  # more steps than ring slots: every slot is reused
+    for s in range(steps):
+        data = (b"" if (s + rank) % 3 == 0 else ("r%d-s%d;" % (rank, s)).encode() * (1 + (s + rank) % 5))
+        g.submit(data)
+    res, sizes = g.finish()
+    if rank == 0:
+        q.put([[bytes(p.numpy().tobytes()) for p in step] for step in res])
+        q.put(sizes)
+    else:
+        assert res is None
+    # a payload beyond the agreed capacity is refused on the rank that holds it, before any collective is issued
+    try:
+        FixedGather(rank, world, "cpu", cap=8).submit(b"x" * 9)
+        q.put("no error")
+    except ValueError:
+        q.put("refused")
+    dist.destroy_process_group()
+
+
+def test_fixed_capacity_gather_over_gloo():
+    """`FixedGather` (the per-step gather without host synchronisation on ranks > 0): one collective per step,
+    lengths in a header, a ring of staging buffers that is reused — every byte arrives, in step order, empty payloads too."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_fixed_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(4)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    res = next(x for x in got if isinstance(x, list) and x and isinstance(x[0], list) and x[0] and isinstance(x[0][0], bytes))
+    sizes = next(x for x in got if isinstance(x, list) and x and isinstance(x[0], list) and isinstance(x[0][0], int))
+    exp = [[(b"" if (s + r) % 3 == 0 else ("r%d-s%d;" % (r, s)).encode() * (1 + (s + r) % 5)) for r in range(2)] for s in range(8)]
+    assert res == exp
+    assert sizes == [[len(x) for x in step] for step in exp]
+    assert got.count("refused") == 2
