@@ -323,12 +323,12 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
     const int score_scale = std::max(1, maxmatch / 2);
     const int spec_margin = ((nwv > 1 ? opt.spec_margin * ((max_n + 999) / 1000) : (int)opt.spec_margin) +
                              (spec_level == 1 ? 320 * ((max_n + 999) / 1000) : 0)) * (opt.spec_margin > 0 ? score_scale : 1);
-    // direction words on demand (k_sweep16, DIRECTION WORDS ON DEMAND): the record variants at <= 16 columns per lane, first pass
+    // direction words on demand (k_sweep16, DIRECTION WORDS ON DEMAND): the record variants, first pass
     // only — a read that comes back because its final paths were not the picked ones stores every word the second time
     const bool pick_two_used = spec && !semi && !opt.no_pick2;
-    const bool dsel = spec && use_rec && C <= 16 && nwv == 1 && spec_level == 0 && !opt.no_dsel;
+    const bool dsel = spec && use_rec && nwv == 1 && spec_level == 0 && !opt.no_dsel;
     const int recw = 4 + C;
-    if (w.fcap == 0) { w.fcap = (two_sweep && !use_rec) ? 1u << 20 : 1u << 15; w.rcap = use_rec ? 1u << 16 : 1u << 19; w.frec_cap = 1u << 14; w.rrec_cap = 1u << 13; }   // (round 6: 16 Ki / 8 Ki records of 80 B to start with instead of 64 Ki / 32 Ki — 2 MB per read instead of 7.9; a read that needs more regrows the lists and the chunk runs again, once per handle.  Config 5 with the two-path pick: forward mean ~11 k)
+    if (w.fcap == 0) { w.fcap = (two_sweep && !use_rec) ? 1u << 20 : 1u << 15; w.rcap = use_rec ? 1u << 16 : 1u << 19; w.frec_cap = spec ? 1u << 14 : 1u << 16; w.rrec_cap = spec ? 1u << 13 : 1u << 15; }   // (round 6: 16 Ki / 8 Ki records of 80 B to start with instead of 64 Ki / 32 Ki — 2 MB per read instead of 7.9; a read that needs more regrows the lists and the chunk runs again, once per handle; batches WITHOUT a speculative bound keep the old sizes: their forward lists hold tens of thousands of records per read, and 128-path tiles ran twice every time a tile's largest read outgrew the last one's.  Config 5 with the two-path pick: forward mean ~11 k)
     stats.clear();
     Timer T{&w, stream, pw.spin_wait};
     int done = 0;

@@ -262,7 +262,11 @@ __global__ __launch_bounds__(kStripes ? 512 : 64, kStripes ? 1 : RG_SWEEP_WAVES)
     // that a wait, not an assumption).  Hopeless stays hopeless, so a late decision is still a correct one; the closure uses
     // the lead table of the point it is applied at.
     constexpr bool kRetOK = !kStripes || C <= 16;     // (k_sweep<32, true, true> keeps the control flow it had: see below)
+#ifdef RG_NO_KOLD
+    constexpr bool kOld = false;            // (experiment: the build that returned wrong sink values at 32 columns per lane, for the hazard scan)
+#else
     constexpr bool kOld = kStripes && !kRetOK;
+#endif
     constexpr int RT_SLOTS = 4, RT_LAG = 2;
     int* rt_base = fifo_lds + 8 * (FIFO_WORDS + 2);                 // stripes only: [pub 4 | app 4 | smin 8 | val 4 x 8 x 64]
     unsigned* rt_pub = (unsigned*)rt_base;

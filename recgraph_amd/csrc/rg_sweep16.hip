@@ -263,7 +263,7 @@ __device__ __forceinline__ void run_dispatch_from(F& f, int n) {
 #define RG_GATHER_PER_MEMBER_RUN 90
 #endif
 #ifndef RG_SWEEP16_GATHER32
-#define RG_SWEEP16_GATHER32 0        // gather runs in the record variants at 32 columns per lane (see kGather)
+#define RG_SWEEP16_GATHER32 1        // gather runs in the record variants at 32 columns per lane (see kGather): round 6 — 32 spilled registers, and still 21.4 k -> 24.9 k reads/s at 1.5 kbp
 #endif
 #ifndef RG_SWEEP16_RUNWAIT
 #define RG_SWEEP16_RUNWAIT 1
@@ -277,6 +277,9 @@ __device__ __forceinline__ void run_dispatch_from(F& f, int n) {
 // sweep (37.4 vs 37.5 ms, and the variant spills 48 registers with it) and 0.7 ms SLOWER in the reverse one (34.3 vs
 // 33.6): their runs end in tails, whose epilogue separates the loads from the stores anyway (profiles/r04_notes.md)
 #define RG_SWEEP16_CHAIN 1
+#endif
+#ifndef RG_SWEEP16_KRUN32_M4
+#define RG_SWEEP16_KRUN32_M4 1       // register runs of two rows in the -m 4 / -m 5 variant at 32 columns per lane (reads of 1 024 - 2 047 bases)
 #endif
 #ifndef RG_SWEEP16_KRUN_REV
 #define RG_SWEEP16_KRUN_REV RG_SWEEP16_KRUN     // the variant without column maxima (reverse sweep of the record pipeline)
@@ -332,7 +335,7 @@ __global__ __launch_bounds__(64, C > 16 ? 2 : (kColmax != 0 ? RG_SWEEP16_FWD_WAV
     // rows kept in registers across the inner rows of a segment: groups of up to 4 paths (2 at 32 columns per lane: a row is 16 registers there)
     // (the -m 4 / -m 5 variant: 3 — with 4 the specialised run loops of round 6 need 178 registers and the variant falls from three
     // waves per SIMD to two: config 4 271 k against 296 k reads/s)
-    constexpr int KRUN = C <= 16 ? (!kTrack ? (RG_SWEEP16_KRUN < 3 ? RG_SWEEP16_KRUN : 3) : (kColmax != 0 ? RG_SWEEP16_KRUN : RG_SWEEP16_KRUN_REV)) : ((kRec && kColmax == 0 && !kWide) ? 2 : 0);
+    constexpr int KRUN = C <= 16 ? (!kTrack ? (RG_SWEEP16_KRUN < 3 ? RG_SWEEP16_KRUN : 3) : (kColmax != 0 ? RG_SWEEP16_KRUN : RG_SWEEP16_KRUN_REV)) : (((kRec && kColmax == 0 && !kWide) || (!kTrack && !kWide && RG_SWEEP16_KRUN32_M4)) ? 2 : 0);
     const int rd = a.order ? a.order[blockIdx.x] : blockIdx.x;      // (launch order: see launch_order)
 #ifdef RG_SWEEP16_STALLSTAT
     // (statistics build, tools/probes/stall_stat.py: shader-clock cycles a wave spends in the waits for row loads; the cell

@@ -183,7 +183,7 @@ def test_full_launch_every_wave_slot_vs_oracle(oracle, cfg):
         assert not bad, (cfg, attempt, len(bad), bad[:12])
 
 
-@pytest.mark.parametrize("case", ["c8_400bp", "c4_200bp", "semi_1kbp", "wide_70_paths", "m4_semi_600bp"])
+@pytest.mark.parametrize("case", ["c8_400bp", "c4_200bp", "semi_1kbp", "wide_70_paths", "m4_semi_600bp", "len1500", "m4_len1500", "wide_128_paths"])
 def test_full_launches_of_the_other_sweep_variants_vs_oracle(oracle, case):
     """The same for the variants configs 4 and 5 do not reach — 8 and 4 columns per lane (four and six-plus waves per SIMD: more
     row stores in flight per CU than anywhere else), the semiglobal flag, more than 64 paths — each as ONE launch that fills
@@ -195,6 +195,11 @@ def test_full_launches_of_the_other_sweep_variants_vs_oracle(oracle, case):
         "semi_1kbp": (api.MODE_RECOMBINATION_SEMI, oracle.M9_ABS, 10000, 32, 1000, 4096, 0.5),
         "wide_70_paths": (api.MODE_RECOMBINATION, oracle.M8_ABS, 6000, 70, 600, 4096, 0.5),
         "m4_semi_600bp": (api.MODE_PATHWISE_SEMI, oracle.M5_ABS, 6000, 16, 600, 8192, 0.0),
+        # 32 columns per lane (reads of 1 024 - 2 047 bases): the record variant with gather runs and register runs of two rows, the
+        # -m 4 variant with register runs (round 6); 128 paths: two 64-path pages per row
+        "len1500": (api.MODE_RECOMBINATION, oracle.M8_ABS, 15000, 32, 1500, 2048, 0.5),
+        "m4_len1500": (api.MODE_PATHWISE, oracle.M4_ABS, 15000, 32, 1500, 2048, 0.0),
+        "wide_128_paths": (api.MODE_RECOMBINATION, oracle.M8_ABS, 10000, 128, 1000, 1024, 0.5),
     }[case]
     sg = synth.haplotype_graph(rows, P, path_len=rlen, seed=4242)
     g = api.Graph.from_gfa_text(sg.gfa())
@@ -202,7 +207,7 @@ def test_full_launches_of_the_other_sweep_variants_vs_oracle(oracle, case):
     if "semi" in case:
         reads = [r[: len(r) * 3 // 4] for r in reads]
     names = ["read%d" % i for i in range(len(reads))]
-    check = sorted(set(list(range(0, nreads, nreads // 96)) + [nreads - 1]))
+    check = sorted(set(list(range(0, nreads, nreads // (48 if rlen > 1000 or P > 64 else 96))) + [nreads - 1]))
     og = oracle.Graph.from_gfa_text(sg.gfa())
     _, _, exp = og.bench_text(om, [reads[i] for i in check], nthreads=min(os.cpu_count() or 1, 96), name_prefix="x")
     texts, status = api.align_batch(g, reads, names, mode=mode)
@@ -344,3 +349,35 @@ def test_poa_full_launches_with_real_alignments(oracle, case):
         # a real alignment: a GAF line with a CIGAR, not the reference's "band not enough" record
         walked += 1 if "band not enough" not in texts[i] and re.search(r"\t(\d+[MXID])+", texts[i]) else 0
     assert walked > 0.9 * len(check), (case, walked, len(check))
+
+
+@pytest.mark.parametrize("stripe_c", [8, 16, 32])
+def test_full_launch_of_striped_long_reads_vs_oracle(oracle, stripe_c):
+    """ADVICE r5 (medium).  The column-striped i32 sweep (reads of 2 048 bases and more: one wave per stripe, FIFO pipeline) met
+    the oracle only in batches of a handful of reads, and its 32-columns-per-lane instantiation once returned wrong sink
+    values that only its `kOld` control flow avoids (not a hardware hazard — s_nop padding and forced waitcnts
+    do not cure it — but a miscompile suspect in a kernel with ~700 spilled registers).  Here each stripe width runs ONE launch
+    that gives every CU its workgroups — 512 reads of 2 600 bases, -m 8 and -m 4 — and a stride over the whole index range is
+    compared byte for byte with the oracle."""
+    from recgraph_amd import api, synth
+    sg = synth.haplotype_graph(6500, 4, path_len=2600, seed=2600)
+    g = api.Graph.from_gfa_text(sg.gfa())
+    nreads = 512
+    reads = synth.haplotype_reads(sg, nreads, 2600, seed=4211, mosaic_frac=0.5)
+    names = ["read%d" % i for i in range(nreads)]
+    check = sorted(set(list(range(0, nreads, 16)) + [nreads - 1]))
+    og = oracle.Graph.from_gfa_text(sg.gfa())
+    try:
+        api.set_option("stripe_c", stripe_c if stripe_c != 16 else 0)
+        for mode, om in ((api.MODE_RECOMBINATION, oracle.M8_ABS), (api.MODE_PATHWISE, oracle.M4_ABS)):
+            _, _, exp = og.bench_text(om, [reads[i] for i in check], nthreads=_host_threads(16), name_prefix="x")
+            texts, status = api.align_batch(g, reads, names, mode=mode)
+            assert not any(status)
+            bad = []
+            for k, i in enumerate(check):
+                e = exp[k].decode().replace("x%d\t" % k, "read%d\t" % i, 1)
+                if texts[i].rsplit("\t", 1)[0] != e.rsplit("\t", 1)[0]:
+                    bad.append(i)
+            assert not bad, (stripe_c, mode, len(bad), bad[:12])
+    finally:
+        api.set_option("stripe_c", 0)

@@ -173,34 +173,65 @@ def _vregs(tok):
     return {int(m.group(1))} if m else set()
 
 
-def store_hazards(src, defines=()):
-    """gfx950: a VALU write to the data registers of a buffer_store_dwordx3/x4 within the ONE wait state behind it corrupts
-    the store — also when the store's scalar offset is an SGPR, the case LLVM's hazard recognizer exempts (found in round 5:
-    rg_sweep16.hip, st_row).  Returns [(kernel, line, store, overwriting instruction)] over every kernel of `src`; the
-    kernels keep an `s_nop` behind such stores, so the list must be empty."""
+WIDE_STORES = ("buffer_store_dwordx4", "buffer_store_dwordx3", "global_store_dwordx4", "global_store_dwordx3", "scratch_store_dwordx4",
+               "scratch_store_dwordx3", "flat_store_dwordx4", "flat_store_dwordx3")
+# (64-bit stores: the documented hazard starts above 64 bits and none was ever observed at 64; listed, not counted as hits)
+STORES_64 = ("buffer_store_dwordx2", "global_store_dwordx2", "scratch_store_dwordx2", "flat_store_dwordx2")
+
+
+def _valu_dests(u):
+    """VGPRs a VALU instruction writes: its first operand, and for the VOP3 forms with a second destination (v_mad_u64_u32,
+    v_div_scale ...: `vdst, sdst`) nothing more in VGPRs — carry-outs go to SGPR pairs / vcc.  v_swap_b32 writes both operands;
+    DPP / SDWA forms write their first operand like everything else; v_readlane / v_readfirstlane / v_cmp write no VGPR."""
+    mn = u.split()[0]
+    if mn.startswith(("v_cmp", "v_readlane", "v_readfirstlane", "v_nop")):
+        return set()
+    ops = [o.strip() for o in u[len(mn):].split(",")]
+    d = _vregs(ops[0]) if ops else set()
+    if mn.startswith("v_swap") and len(ops) > 1:
+        d |= _vregs(ops[1])
+    return d
+
+
+def _data_operand(t):
+    """data registers of a store: buffer_store: first operand; global / flat: second (after the address); scratch: second"""
+    mn = t.split()[0]
+    ops = [o.strip() for o in t[len(mn):].split(",")]
+    if mn.startswith("buffer_store"):
+        return _vregs(ops[0])
+    return _vregs(ops[1]) if len(ops) > 1 else set()
+
+
+def store_hazards(src, defines=(), want64=False):
+    """gfx950: a VALU write to the data registers of a store of more than 64 bits within the ONE wait state behind it corrupts
+    the store — also when the store takes its offset from an SGPR, the case LLVM's hazard recognizer exempts (found in round 5:
+    rg_sweep16.hip, st_row: buffer stores; round 6 extends the scan to global / flat / SCRATCH stores — register spills are
+    scratch_store_dwordx4 with an SGPR offset, and the register allocator reuses a spilled register at once — and to every
+    kernel source).  Returns ([(kernel, line, store, overwriting instruction)], wide stores seen) over every kernel of `src`."""
     with tempfile.TemporaryDirectory() as td:
         out = os.path.join(td, "k.s")
         cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off", "--cuda-device-only", "-S",
                os.path.join(CSRC, src), "-o", out] + list(defines)
         subprocess.run(cmd, capture_output=True, text=True, cwd=CSRC, check=True)
         text = open(out).read().split("\n")
+    kinds = WIDE_STORES + (STORES_64 if want64 else ())
     hits, cur, stores = [], None, 0
     for i, ln in enumerate(text):
         m = re.match(r"^(_Z[A-Za-z0-9_]+):", ln)
         if m:
             cur = m.group(1)
         t = ln.strip()
-        if not t.startswith(("buffer_store_dwordx4", "buffer_store_dwordx3")):
+        if not t.startswith(kinds):
             continue
         stores += 1
-        data = _vregs(t.split()[1].rstrip(","))
+        data = _data_operand(t)
         j = i + 1
         while j < len(text):      # the next INSTRUCTION (labels, comments and directives are not wait states)
             u = text[j].split(";")[0].strip()
             j += 1
             if not u or u.startswith(".") or u.endswith(":"):
                 continue
-            if u.startswith("v_") and _vregs(u.split()[1].rstrip(",")) & data:
+            if u.startswith("v_") and _valu_dests(u) & data:
                 hits.append((cur, i + 1, t, u))
             break
     names = demangle(sorted({h[0] for h in hits}))
@@ -209,11 +240,11 @@ def store_hazards(src, defines=()):
 
 def main():
     if "--hazards" in sys.argv:
-        files = [a for a in sys.argv[1:] if not a.startswith("-")] or ["rg_sweep16.hip"]
+        files = [a for a in sys.argv[1:] if not a.startswith("-")] or sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
         defs = [a for a in sys.argv[1:] if a.startswith("-D")]
         for f in files:
-            hits, stores = store_hazards(f, defs)
-            print("%s: %d wide buffer stores, %d with their data overwritten by the next instruction" % (f, stores, len(hits)))
+            hits, stores = store_hazards(f, defs, want64="--64" in sys.argv)
+            print("%s: %d wide stores, %d with their data overwritten by the next instruction" % (f, stores, len(hits)))
             for h in hits:
                 print("  %s  line %d: %s  ||  %s" % h)
         return
