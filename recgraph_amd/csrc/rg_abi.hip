@@ -45,6 +45,7 @@ Options& options() {
         { const char* v = getenv("RG_NO_RETIRE"); o.no_retire = v ? atoi(v) : 0; }
         o.no_pick2 = env("RG_NO_PICK2");
         o.no_dsel = env("RG_NO_DSEL");
+        o.sweep_prio = env("RG_SWEEP_PRIO");
         if (getenv("RG_DSEL_EDGE")) o.dsel_edge = std::max(1, atoi(getenv("RG_DSEL_EDGE")));
         o.no_order = env("RG_NO_ORDER");
         o.spin_wait = env("RG_SPIN_WAIT");
@@ -376,6 +377,7 @@ static std::atomic<int>* option_slot(const char* name) {
     if (!strcmp(name, "no_retire")) return &o.no_retire;
     if (!strcmp(name, "no_pick2")) return &o.no_pick2;
     if (!strcmp(name, "no_dsel")) return &o.no_dsel;
+    if (!strcmp(name, "sweep_prio")) return &o.sweep_prio;
     if (!strcmp(name, "dsel_edge")) return &o.dsel_edge;
     if (!strcmp(name, "no_order")) return &o.no_order;
     if (!strcmp(name, "spin_wait")) return &o.spin_wait;
@@ -574,7 +576,14 @@ int32_t rg_batch_create(const rg_graph* gc, const rg_params* p, const char* read
     b->gt = gt;
     b->p = *p;
     HIPCHK(hipGetDevice(&b->dev));
-    HIPCHK(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
+    {
+        // the handle's stream at the highest priority: it carries the small kernels; the pathwise sweeps run on a low-priority
+        // stream of their own (rg_path_driver.hip, SWEEPS ON A LOW-PRIORITY STREAM)
+        int least = 0, greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+        if (hipStreamCreateWithPriority(&b->stream, hipStreamNonBlocking, greatest) != hipSuccess)
+            HIPCHK(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
+    }
     if (is_poa(mode)) {
         // column-0 chain of m0 (global_abpoa.rs:36-46): depends on graph + scores only
         const HostGraph& h = g->h;

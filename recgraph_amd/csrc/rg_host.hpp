@@ -37,6 +37,7 @@ struct Options {
     std::atomic<int> no_retire{0};      // RG_NO_RETIRE: k_sweep16 computes every path to the end (no path retirement)
     std::atomic<int> no_order{0};       // RG_NO_ORDER: the sweeps' waves in read order (no longest-first launch order)
     std::atomic<int> dsel_edge{8};      // RG_DSEL_EDGE: the 1 / dsel_edge of the rows each sweep visits first always store their direction words
+    std::atomic<int> sweep_prio{0};     // RG_SWEEP_PRIO: the pathwise sweeps on a low-priority stream of their own (measured: -1..-3 % at config 5, +2.5 % at 1.5 kbp: off)
     std::atomic<int> no_dsel{0};        // RG_NO_DSEL: every (row, group) record of the packed sweeps stores its direction word (round 6: only those with a picked path)
     std::atomic<int> no_pick2{0};       // RG_NO_PICK2: the speculative bound from one-path picks only (no two-path picks)
     std::atomic<int> layer_i32{0};      // RG_LAYER_I32: k_layer in its i32 form even when the sweep ran packed (test hook)

@@ -84,7 +84,17 @@ struct PathWorkImpl {
     Buf<unsigned long long> rt_cells;
     PathWork retry;                     // work buffers of that second pass (a handful of reads)
     unsigned long long* h_sum = nullptr;  // pinned: {cell updates of the chunk, need[0..3]} read back once per chunk
+    // SWEEPS ON A LOW-PRIORITY STREAM (round 6, option `sweep_prio`, OFF).  The handle's own stream has the highest priority
+    // (rg_abi.hip) and carries the small kernels; with the option the sweeps go to this stream, fenced by two events.  The idea: in
+    // the stream of several handles the small kernels of one tile compete with the sweep workgroups of the other handles for every
+    // register slot a retiring wave frees (a 1 ms kernel takes 4-40 ms there).  Measured: the small kernels wait just as long —
+    // what they wait for is a FREE slot, not their turn — config 5 118.4 / 115.0 k against 120.1 / 119.6 k reads/s, 1.5 kbp +2.6 %.
+    hipStream_t sweep_stream = nullptr;
+    hipEvent_t sw_before = nullptr, sw_after = nullptr;
     ~PathWorkImpl() {
+        if (sweep_stream) (void)hipStreamDestroy(sweep_stream);
+        if (sw_before) (void)hipEventDestroy(sw_before);
+        if (sw_after) (void)hipEventDestroy(sw_after);
         for (auto e : ev) (void)hipEventDestroy(e);
         if (done_ev) (void)hipEventDestroy(done_ev);
         if (h_sum) (void)hipHostFree(h_sum);
@@ -195,8 +205,28 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
             const hipError_t e = hipMemsetAsync(sa_.ncand_out, 0, sizeof(unsigned) * nr, stream);
             if (e != hipSuccess) memset_err = e;
         }
-        if (use16) launch_sweep16(sa_, nr, C, stream);
-        else launch_sweep(sa_, nr, C, stream);
+        hipStream_t ss = stream;
+        if (opt.sweep_prio) {
+            if (!w.sweep_stream) {
+                int least = 0, greatest = 0;
+                (void)hipDeviceGetStreamPriorityRange(&least, &greatest);        // (numerically: least >= greatest)
+                if (hipStreamCreateWithPriority(&w.sweep_stream, hipStreamNonBlocking, least) != hipSuccess) w.sweep_stream = nullptr;
+                if (w.sweep_stream && (hipEventCreateWithFlags(&w.sw_before, hipEventDisableTiming) != hipSuccess ||
+                                       hipEventCreateWithFlags(&w.sw_after, hipEventDisableTiming) != hipSuccess)) {
+                    (void)hipStreamDestroy(w.sweep_stream);
+                    w.sweep_stream = nullptr;
+                }
+            }
+            if (w.sweep_stream && hipEventRecord(w.sw_before, stream) == hipSuccess && hipStreamWaitEvent(w.sweep_stream, w.sw_before, 0) == hipSuccess)
+                ss = w.sweep_stream;
+        }
+        if (use16) launch_sweep16(sa_, nr, C, ss);
+        else launch_sweep(sa_, nr, C, ss);
+        if (ss != stream) {
+            const hipError_t e1 = hipEventRecord(w.sw_after, ss);
+            const hipError_t e2 = e1 == hipSuccess ? hipStreamWaitEvent(stream, w.sw_after, 0) : e1;
+            if (e2 != hipSuccess) memset_err = e2;      // (reported with the chunk's other asynchronous errors)
+        }
     };
     int rc;
     if (!w.h_sum) HIPCHK(hipHostMalloc((void**)&w.h_sum, 8 * sizeof(unsigned long long), hipHostMallocDefault));
