@@ -104,12 +104,14 @@ __global__ __launch_bounds__(64) void k_poa_banded(PoaArgs a) {
         for (int kk = 1; kk < KC; ++kk) { r = k == kk ? arr[kk] : r; asm volatile("" : "+v"(r)); }
         return r;
     };
+#ifdef RG_POA_TWO_BPERMUTE
     // stored cell of the row above at absolute column `col` (band-relative index col - p_left; chunk base k0 uniform)
     auto prev_at = [&](int col, int k0, int lo, int hi) -> int {
         const int idx = col - p_left;
         const int sh_lo = __shfl(lo, idx & (WAVE - 1), WAVE), sh_hi = __shfl(hi, idx & (WAVE - 1), WAVE);
         return (idx >> 6) == k0 ? sh_lo : sh_hi;
     };
+#endif
 
     // per-row metadata: one 16-byte scalar load, a row ahead (PoaArgs::rowmeta_b; as six loads at the top of the row — one of
     // them dependent — every row waited for the scalar cache several times)
@@ -164,8 +166,26 @@ __global__ __launch_bounds__(64) void k_poa_banded(PoaArgs a) {
                 const int k0 = (left + cb - 1 - p_left) >> 6;          // columns c-1 .. c of this chunk span chunks k0, k0+1
                 const int ka = k0 < 0 ? 0 : (k0 < KC ? k0 : KC - 1), kb = k0 + 1 < 0 ? 0 : (k0 + 1 < KC ? k0 + 1 : KC - 1);
                 const int mlo = chunk_of(pvm, ka), mhi = chunk_of(pvm, kb);
+#ifdef RG_POA_TWO_BPERMUTE
                 f_md = prev_at(c - 1, k0, mlo, mhi);
                 f_mu = prev_at(c, k0, mlo, mhi);
+#else
+                // ONE cross-lane fetch per plane (round 6; two ds_bpermute per value and three values per chunk before).  The
+                // lanes of a chunk read consecutive band cells: lane l reads cell base + l — a ROTATION of the lanes by
+                // rot = base mod 64 over the two register chunks k0 (cells whose lane is >= rot) and k0 + 1 (the others).  So
+                // the SOURCE lane selects which of its two chunk values is wanted (a lane is read exactly once), one
+                // ds_bpermute rotates, and column c (the cell behind column c - 1) is the next lane's fetch: a one-lane wave
+                // shift, with lane 63's value — cell base + 64: lane rot of chunk k0 + 1 — through a v_readlane.
+                const int base = left + cb - 1 - p_left;               // band cell of column c - 1 for lane 0 (wave-uniform)
+                const int rot = base & (WAVE - 1);
+                const int rsel = ((rot + lane) & (WAVE - 1)) * 4;      // byte address of the lane ds_bpermute reads
+                f_md = __builtin_amdgcn_ds_bpermute(rsel, lane >= rot ? mlo : mhi);
+                {
+                    const int last = __builtin_amdgcn_readlane(mhi, rot);
+                    const int sh = dpp_mov<0x130, 0xf>(0, f_md);       // wave_shl:1 — lane l takes lane l + 1's value
+                    f_mu = lane == WAVE - 1 ? last : sh;
+                }
+#endif
                 if (kGap) {
                     int ylo = pvy[0], yhi = pvy[0];
 #pragma unroll
@@ -173,7 +193,19 @@ __global__ __launch_bounds__(64) void k_poa_banded(PoaArgs a) {
                         ylo = ka == kk ? pvy[kGap ? kk : 0] : ylo; yhi = kb == kk ? pvy[kGap ? kk : 0] : yhi;
                         asm volatile("" : "+v"(ylo), "+v"(yhi));
                     }
+#ifdef RG_POA_TWO_BPERMUTE
                     f_yu = prev_at(c, k0, ylo, yhi);
+#else
+                    {
+                        // column c of y: band cell base + 1 + l — the same rotation one cell further
+                        const int rot1 = (base + 1) & (WAVE - 1);
+                        const int rsel1 = ((rot1 + lane) & (WAVE - 1)) * 4;
+                        const int k1 = (base + 1) >> 6;               // chunk of lane 0's cell; k1 == k0 except when rot == 63
+                        // (rot == 63: base + 1 is a multiple of 64, every lane's cell lies in chunk k0 + 1 and every lane is >= rot1 = 0)
+                        const int ylo1 = k1 == k0 ? ylo : yhi;
+                        f_yu = __builtin_amdgcn_ds_bpermute(rsel1, lane >= rot1 ? ylo1 : yhi);
+                    }
+#endif
                 }
             }
             const int first_prev = __builtin_amdgcn_readlane(pvm[0], 0);   // first stored cell of the row above
