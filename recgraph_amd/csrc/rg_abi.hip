@@ -394,6 +394,7 @@ int32_t rg_set_option(const char* name, int64_t value) {
     else if (s == &o.chunk_reads) *s = (int)std::max<int64_t>(0, std::min<int64_t>(value, 1 << 20));
     else if (s == &retire_shift_option()) *s = (int)std::max<int64_t>(2, std::min<int64_t>(value, 12));
     else if (s == &o.lds_pad) *s = (int)std::max<int64_t>(0, std::min<int64_t>(value, 40 << 10));
+    else if (s == &o.dsel_edge) *s = (int)std::max<int64_t>(1, std::min<int64_t>(value, 1 << 20));     // 1 / dsel_edge of the rows always store their direction words
     else if (s == &o.spec_margin) *s = (int)std::max<int64_t>(-(1 << 24), std::min<int64_t>(value, 1 << 24));
     else if (s == &o.no_retire) *s = (int)std::max<int64_t>(0, std::min<int64_t>(value, 3));     // 1: off, 2: forward sweep only, 3: reverse sweep only
     else *s = value ? 1 : 0;

@@ -88,12 +88,14 @@ def test_c5_m8_properties(oracle, c5):
     assert not bad, (len(bad), bad[:5], texts[bad[0]][-200:], exp[bad[0]][-200:])
     # the same reads with a ZERO speculation margin (k_verify sends every read whose optimum is not its picked path's score
     # through the second pass with the provable bound) and with the plain step tables: the same bytes
-    for name, val in (("spec_margin", 0), ("no_split", 1), ("no_retire", 1), ("no_pick2", 1), ("no_order", 1)):
+    # (dsel_edge 1000: no always-stored edge rows — about half of these reads end on another path for their last columns and come
+    # back for the second pass, which stores every direction word; no_dsel: every word in the first pass)
+    for name, val in (("spec_margin", 0), ("no_split", 1), ("no_retire", 1), ("no_pick2", 1), ("no_order", 1), ("dsel_edge", 1000), ("no_dsel", 1)):
         try:
             api.set_option(name, val)
             again, _ = api.align_batch(g, reads[:64], names[:64], mode=api.MODE_RECOMBINATION)
         finally:
-            api.set_option(name, SPEC_MARGIN_DEFAULT if name == "spec_margin" else 0)
+            api.set_option(name, SPEC_MARGIN_DEFAULT if name == "spec_margin" else (8 if name == "dsel_edge" else 0))
         assert again == texts[:64], name
 
 

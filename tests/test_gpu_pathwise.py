@@ -389,10 +389,14 @@ def test_random_dag_graphs_in_every_switch_family(oracle):
              (240, 5, 303, {"max_jump": 2, "max_seg": 4}))
     switches = (("sweep_i32", 1), ("no_frec", 1), ("three_sweeps", 1), ("no_spec", 1), ("spec_margin", 0), ("spec_margin", -1000000),
                 ("no_gather", 1), ("no_split", 1), ("chunk_reads", 5), ("layer_i32", 1), ("no_retire", 1), ("no_retire", 2), ("no_retire", 3),
-                ("no_pick2", 1), ("no_order", 1), ("retire_shift", 4), ("retire_shift", 2))
+                ("no_pick2", 1), ("no_order", 1), ("retire_shift", 4), ("retire_shift", 2),
+                # direction words on demand (round 6): off; without the always-stored edge rows (1 / 1000 of the rows: reads whose
+                # final paths are not the picked ones come back for the second pass); with half of the rows always stored
+                ("no_dsel", 1), ("dsel_edge", 1000), ("dsel_edge", 2))
     pairs = ((("three_sweeps", 1), ("sweep_i32", 1)), (("no_split", 1), ("no_gather", 1)), (("spec_margin", -1000000), ("chunk_reads", 4)),
              (("no_frec", 1), ("no_spec", 1)), (("no_retire", 1), ("no_split", 1)), (("no_spec", 1), ("no_gather", 1)),
              (("no_pick2", 1), ("spec_margin", 0)), (("no_retire", 3), ("no_split", 1)),
+             (("dsel_edge", 1000), ("no_pick2", 1)), (("dsel_edge", 1000), ("retire_shift", 4)), (("dsel_edge", 1000), ("spec_margin", 0)), (("dsel_edge", 1000), ("chunk_reads", 5)),
              # evaluation every 16 / 4 records: graphs of this size only retire paths with a short period
              (("retire_shift", 4), ("spec_margin", 0)), (("retire_shift", 3), ("no_split", 1)), (("retire_shift", 4), ("no_retire", 2)),
              (("retire_shift", 4), ("no_retire", 3)), (("retire_shift", 4), ("no_gather", 1)), (("retire_shift", 4), ("no_pick2", 1)),
@@ -400,7 +404,7 @@ def test_random_dag_graphs_in_every_switch_family(oracle):
              (("sweep_i32", 1), ("retire_shift", 4)), (("sweep_i32", 1), ("retire_shift", 3), ("spec_margin", 0)), (("sweep_i32", 1), ("no_retire", 1)),
              (("sweep_i32", 1), ("retire_shift", 4), ("no_retire", 2)), (("sweep_i32", 1), ("retire_shift", 4), ("no_retire", 3)),
              (("sweep_i32", 1), ("retire_shift", 4), ("no_spec", 1)), (("sweep_i32", 1), ("retire_shift", 2), ("no_order", 1)))
-    defaults = {"spec_margin": SPEC_MARGIN_DEFAULT, "retire_shift": 8}
+    defaults = {"spec_margin": SPEC_MARGIN_DEFAULT, "retire_shift": 8, "dsel_edge": 8}
     for nseg, P, seed, kw in cases:
         g = synth.random_dag_graph(nseg, P, seed=seed, **kw)
         plen = min(len(g.path_sequence(k)) for k in range(P))
