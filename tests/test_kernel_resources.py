@@ -21,8 +21,15 @@ def test_headline_sweep_variants_use_no_scratch():
     assert ks["rg::k_sweep16<16, 0, false, false, false>"]["Occupancy [waves/SIMD]"] >= 3
     # reads of 1024-2047 bases (32 columns per lane): a row is 16 registers and the record variant is at the 256-register limit —
     # a few spilled registers are tolerated, a relapse (one uniform branch in the alpha took it from 13 to 67) is not
+    # (round 6: gather runs are compiled into this variant — 32 spilled registers, 132 bytes of scratch per lane — because they
+    # pay all the same: 21.4 k -> 24.9 k reads/s at 1.5 kbp, profiles/r06_notes.md)
     k32 = ks["rg::k_sweep16<32, 0, true, false, false>"]
-    assert k32["VGPRs Spill"] <= 24 and k32["ScratchSize [bytes/lane]"] <= 96, k32
+    assert k32["VGPRs Spill"] <= 40 and k32["ScratchSize [bytes/lane]"] <= 160, k32
+    # the record variant leaves 64 of a SIMD's 512 registers to the other handles' small kernels (two waves of <= 224), and
+    # k_layer16 at <= 16 columns per lane fits into them: one more allocation granule on either side costs 2-3 % in the stream
+    assert ks["rg::k_sweep16<16, 0, true, false, false>"]["VGPRs"] <= 224, ks["rg::k_sweep16<16, 0, true, false, false>"]
+    kl = next(k for n, k in ks.items() if n.startswith("rg::k_layer16<16>"))
+    assert kl["VGPRs"] <= 64 and kl["VGPRs Spill"] <= 2, kl
     # the narrower instantiations of the same variants (shorter reads) and their semiglobal forms do not spill either
     for c in (4, 8):
         for v in ("0, true, false, false", "0, false, false, false", "0, true, false, true", "0, false, false, true"):
@@ -42,8 +49,31 @@ def test_no_valu_write_into_a_wide_buffer_store_in_flight():
     csrc = os.path.join(ROOT, "recgraph_amd", "csrc")
     users = [f for f in os.listdir(csrc) if f.endswith((".hip", ".hpp", ".cpp")) and "raw_buffer_store" in open(os.path.join(csrc, f)).read()]
     assert users == ["rg_sweep16.hip"], users
-    hits, _ = kernel_resources.store_hazards("rg_sweep16.hip", ["-DRG_SWEEP16_NO_STORE_NOP"])
-    assert any("k_sweep16<16, 0, false, false, false>" in h[0] for h in hits), hits[:4]
+    # round 6: the scan reads global / flat / SCRATCH stores too (register spills are scratch_store_dwordx4 with an SGPR offset) and
+    # every destination operand; the other big kernel source — the i32 sweeps, hundreds of spilled registers — is clean as well
+    hits2, stores2 = kernel_resources.store_hazards("rg_pathwise.hip")
+    assert stores2 > 100 and not hits2, hits2[:4]
+    # ... and the scan finds the pattern when it is there (round 5 checked this on the build without the s_nop; the round-6 tree
+    # happens to schedule no such pair even then, so the positive control is a listing written by hand: the round-5 instruction
+    # pair, a spill store whose register is reused at once, a v_swap's second operand — and three pairs that must NOT count)
+    listing = """_Z3foov:
+	buffer_store_dwordx4 v[126:129], v119, s[44:47], s8 offen
+	v_and_b32_e32 v126, 1, v3
+	buffer_store_dwordx4 v[10:13], v119, s[44:47], s8 offen
+	s_nop 1
+	v_and_b32_e32 v10, 1, v3
+	scratch_store_dwordx4 off, v[20:23], s32 offset:16 ; 16-byte Folded Spill
+	v_mov_b32_e32 v22, 0
+	global_store_dwordx3 v[2:3], v[30:32], off
+	v_add_u32_e32 v5, v30, v31
+	global_store_dwordx4 v40, v[50:53], s[4:5]
+	v_swap_b32 v9, v53
+	scratch_store_dwordx2 off, v[60:61], off offset:8
+	v_mov_b32_e32 v60, 0
+""".split("\n")
+    hits, stores = kernel_resources.scan_store_hazards(listing)
+    assert stores == 5 and [h[1] for h in hits] == [2, 7, 11], hits
+    assert len(kernel_resources.scan_store_hazards(listing, want64=True)[0]) == 4
 
 
 def test_poa_kernels_use_no_scratch():

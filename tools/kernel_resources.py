@@ -24,11 +24,25 @@ def demangle(names):
     return dict(zip(names, out))
 
 
+_COMPILED = {}
+
+
+def compile_once(src, defines=()):
+    """(remark text, assembly lines) of one device-only hipcc run of `src` (cached per process: the register report and the hazard
+    scan of a source share it — a compile of rg_sweep16.hip takes a minute)."""
+    key = (src, tuple(defines))
+    if key not in _COMPILED:
+        with tempfile.TemporaryDirectory() as td:
+            out = os.path.join(td, "k.s")
+            cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off", "--cuda-device-only", "-S",
+                   "-Rpass-analysis=kernel-resource-usage", os.path.join(CSRC, src), "-o", out] + list(defines)
+            r = subprocess.run(cmd, capture_output=True, text=True, cwd=CSRC, check=True)
+            _COMPILED[key] = (r.stderr, open(out).read().split("\n"))
+    return _COMPILED[key]
+
+
 def report(src, defines=()):
-    with tempfile.TemporaryDirectory() as td:
-        cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off",
-               "-Rpass-analysis=kernel-resource-usage", "-c", os.path.join(CSRC, src), "-o", os.path.join(td, "o.o")] + list(defines)
-        err = subprocess.run(cmd, capture_output=True, text=True, cwd=CSRC).stderr
+    err = compile_once(src, defines)[0]
     kernels, cur = [], None
     for line in err.splitlines():
         m = re.search(r"remark:\s+(.*?)\s+\[-Rpass-analysis", line)
@@ -95,12 +109,7 @@ def classify(mn, ops, spill_regs):
 
 def isa_report(src, defines, want):
     """Per kernel whose demangled name contains one of `want`: totals and the loops (back edges) with their class histograms."""
-    with tempfile.TemporaryDirectory() as td:
-        out = os.path.join(td, "k.s")
-        cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off", "--cuda-device-only", "-S",
-               os.path.join(CSRC, src), "-o", out] + list(defines)
-        subprocess.run(cmd, capture_output=True, text=True, cwd=CSRC, check=True)
-        text = open(out).read().split("\n")
+    text = compile_once(src, defines)[1]
     starts = [(i, m.group(1)) for i, ln in enumerate(text) for m in [re.match(r"^(_Z[A-Za-z0-9_]+):", ln)] if m]
     names = demangle([n for _, n in starts])
     res = {}
@@ -208,12 +217,14 @@ def store_hazards(src, defines=(), want64=False):
     rg_sweep16.hip, st_row: buffer stores; round 6 extends the scan to global / flat / SCRATCH stores — register spills are
     scratch_store_dwordx4 with an SGPR offset, and the register allocator reuses a spilled register at once — and to every
     kernel source).  Returns ([(kernel, line, store, overwriting instruction)], wide stores seen) over every kernel of `src`."""
-    with tempfile.TemporaryDirectory() as td:
-        out = os.path.join(td, "k.s")
-        cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off", "--cuda-device-only", "-S",
-               os.path.join(CSRC, src), "-o", out] + list(defines)
-        subprocess.run(cmd, capture_output=True, text=True, cwd=CSRC, check=True)
-        text = open(out).read().split("\n")
+    text = compile_once(src, defines)[1]
+    hits, stores = scan_store_hazards(text, want64)
+    names = demangle(sorted({h[0] for h in hits}))
+    return [(names.get(k, k), ln, st, u) for k, ln, st, u in hits], stores
+
+
+def scan_store_hazards(text, want64=False):
+    """The scan itself, on the lines of an assembly listing: ([(mangled kernel, line, store, overwriting instruction)], stores seen)."""
     kinds = WIDE_STORES + (STORES_64 if want64 else ())
     hits, cur, stores = [], None, 0
     for i, ln in enumerate(text):
@@ -234,8 +245,7 @@ def store_hazards(src, defines=(), want64=False):
             if u.startswith("v_") and _valu_dests(u) & data:
                 hits.append((cur, i + 1, t, u))
             break
-    names = demangle(sorted({h[0] for h in hits}))
-    return [(names.get(k, k), ln, st, u) for k, ln, st, u in hits], stores
+    return hits, stores
 
 
 def main():
