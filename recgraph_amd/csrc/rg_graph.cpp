@@ -473,7 +473,9 @@ std::string dump_graph(const HostGraph& g, int which) {
             const std::vector<StepRec>& recs = split ? T.split : T.plain;
             const std::vector<unsigned long long>& lead = split ? T.lead_split : T.lead_plain;
             char tmp[96];
-            snprintf(tmp, sizeof tmp, "members=%llu;points=%zu;", T.members, lead.size() / 64);
+            // (lead tables: [point][path, padded to whole 64-path pages][word of the member set], rg_steps.cpp)
+            const size_t NW = (size_t)((g.P + 63) / 64), PP = 64 * NW;
+            snprintf(tmp, sizeof tmp, "members=%llu;points=%zu;", T.members, lead.size() / (PP * NW));
             s = tmp;
             for (size_t t = 0; t < recs.size(); ++t) {
                 snprintf(tmp, sizeof tmp, "%s%x:%x:%x:%x", t ? "," : "", (unsigned)recs[t].x, (unsigned)recs[t].y, (unsigned)recs[t].z, (unsigned)recs[t].w);
@@ -481,8 +483,21 @@ std::string dump_graph(const HostGraph& g, int which) {
             }
             s += ";";
             bool first = true;
-            for (size_t e = 0; e < lead.size(); ++e)
-                if (lead[e]) { snprintf(tmp, sizeof tmp, "%s%zu:%zu:%llx", first ? "" : ",", e / 64, e % 64, lead[e]); s += tmp; first = false; }
+            for (size_t e = 0; e + NW <= lead.size(); e += NW) {
+                bool any = false;
+                for (size_t w = 0; w < NW; ++w) any = any || lead[e + w];
+                if (!any) continue;
+                snprintf(tmp, sizeof tmp, "%s%zu:%zu:", first ? "" : ",", (e / NW) / PP, (e / NW) % PP);
+                s += tmp;
+                bool lead0 = true;      // the member set as ONE hexadecimal number, most significant word first
+                for (size_t w = NW; w-- > 0;) {
+                    if (lead0 && !lead[e + w] && w > 0) continue;
+                    snprintf(tmp, sizeof tmp, lead0 ? "%llx" : "%016llx", lead[e + w]);
+                    s += tmp;
+                    lead0 = false;
+                }
+                first = false;
+            }
             s += ";";
             break;
         }

@@ -253,15 +253,17 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
         std::vector<int> po, pr, ps;
         build(h.fgoff, h.fgroups, true, po, pr, ps);
         if ((rc = w.fpoff.upload(po)) || (rc = w.fprow.upload(pr)) || (rc = w.fpslot.upload(ps))) return rc;
-        if (P <= 64) {
-            // 12-mers of every path -> paths that contain them (k_pick votes with it): open addressing, 24-bit keys
+        {
+            // 12-mers of every path -> paths that contain them (k_pick votes with it): open addressing, 24-bit keys; NW words of
+            // path bits per entry (one up to 64 paths)
+            const size_t NW = (size_t)((P + 63) / 64);
             constexpr int K = 12;
             size_t total = 0;
             for (int k = 0; k < P; ++k) total += (size_t)std::max(0, po[k + 1] - po[k] - K + 1);
             size_t size = 64;
             while (size < 2 * total + 2) size <<= 1;
             std::vector<uint32_t> keys(size, 0xffffffffu);
-            std::vector<unsigned long long> masks(size, 0ull);
+            std::vector<unsigned long long> masks(size * NW, 0ull);
             for (int k = 0; k < P; ++k) {
                 unsigned key = 0;
                 int valid = 0;
@@ -274,7 +276,7 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
                     for (unsigned probe = 0;; ++probe) {
                         const size_t slot = (hsh + probe) & (size - 1);
                         if (keys[slot] == 0xffffffffu) keys[slot] = key;
-                        if (keys[slot] == key) { masks[slot] |= 1ull << k; break; }
+                        if (keys[slot] == key) { masks[slot * NW + (size_t)(k >> 6)] |= 1ull << (k & 63); break; }
                     }
                 }
             }
@@ -300,13 +302,13 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
         w.nfsteps = (int)st.plain.size();
         w.fmembers = st.members;
         w.retire_shift = st.retire_shift;
-        if (P <= 64 && (rc = w.flead.upload(st.lead_plain))) return rc;
+        if ((rc = w.flead.upload(st.lead_plain))) return rc;
         if (w.have_split && ((rc = up_recs(w.fsplit, st.split)) || (rc = w.fslead.upload(st.lead_split)))) return rc;
         build_step_tables(h, false, w.have_split, st);
         if ((rc = up_recs(w.rsteps, st.plain))) return rc;
         w.nrsteps = (int)st.plain.size();
         w.rmembers = st.members;
-        if (P <= 64 && (rc = w.rlead.upload(st.lead_plain))) return rc;
+        if ((rc = w.rlead.upload(st.lead_plain))) return rc;
         if (w.have_split && ((rc = up_recs(w.rsplit, st.split)) || (rc = w.rslead.upload(st.lead_split)))) return rc;
         w.tables = true;
     }
@@ -346,7 +348,8 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
     const bool allow_spec = spec_level < 2;
     // (round 5: the i32 sweep of reads that fit one wave takes it as well — score matrices outside the 16-bit budget, HOXD70 /
     // HOXD55 with their -200 gaps, emitted every forward cell within (seed - path-0 score) of a diagonal as a Cand)
-    const bool spec = two_sweep && allow_spec && !semi && P <= 64 && !opt.no_spec;
+    // (round 6: more than 64 paths too — on packed rows: k_pick votes over up to 256 paths, k_sweep16 retires over several words)
+    const bool spec = two_sweep && allow_spec && !semi && (P <= 64 || (use16 && nwv == 1)) && !opt.no_spec;
     // (a follower path's sink value lies below its own NW optimum — measured up to 72 at 1 kbp — and the gap grows with the
     // read: long reads scale the margin with their length, or every read would fail the check and run again)
     // The margin is in units of the default scores (match 2): other matrices scale it with their best match (HOXD70: 100 -> x50).
@@ -425,7 +428,7 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
             sa.use_split = w.have_split && sa.gather_ok && !semi && C <= 16 && !opt.no_split ? 1 : 0;
             // path retirement: the record pipelines of -m 8 (global), P <= 64
             sa.flead = w.flead.p; sa.rlead = w.rlead.p; sa.fslead = w.fslead.p; sa.rslead = w.rslead.p;
-            sa.retire = (use16 || nwv == 1 || C <= 16) && P <= 64 && !semi && mode == RG_MODE_RECOMBINATION && gaps_nonpos && opt.no_retire != 1 ? 1 : 0;   // (round 5: the i32 sweep too — one wave, or stripes of <= 16 columns per lane)
+            sa.retire = (use16 || nwv == 1 || C <= 16) && (P <= 64 || (use16 && nwv == 1)) && !semi && mode == RG_MODE_RECOMBINATION && gaps_nonpos && opt.no_retire != 1 ? 1 : 0;   // (round 5: the i32 sweep too — one wave, or stripes of <= 16 columns per lane)
             sa.retire_shift = w.retire_shift;
             sa.fmembers = w.fmembers; sa.rmembers = w.rmembers;
             sa.maxmatch = maxmatch;      // (both sweeps: the retirement bound; the forward sweep's speculative thresholds)

@@ -811,14 +811,16 @@ __global__ __launch_bounds__(64) void k_pick(PickArgs a) {
     const int lane = threadIdx.x;
     const long long ro = a.read_off[rd];
     const int n = (int)(a.read_off[rd + 1] - ro);
-    __shared__ unsigned long long smask[256];
+    // (up to 256 paths since round 6: NW words of path bits per table entry, lane b counts the votes of paths b, 64 + b, ...)
+    __shared__ unsigned long long smask[256 * RG_PW];
     constexpr int K = 12;
+    const int nw = (a.P + 63) >> 6;
     const int npos = n - K + 1;
     if (a.bad[rd] || npos < 1) { if (lane == 0) { a.pick[rd] = 0; if (a.pick2) { a.pick2[2 * rd] = -1; a.pick2[2 * rd + 1] = 0; } } return; }
     const int step = (npos + 255) / 256;
     const int nsamp = (npos + step - 1) / step;             // <= 256
     for (int t = lane; t < 256; t += WAVE) {
-        unsigned long long m = 0;
+        unsigned long long m[RG_PW] = {0, 0, 0, 0};
         if (t < nsamp) {
             const uint8_t* p = a.reads + ro + (long long)t * step;
             unsigned key = 0;
@@ -829,29 +831,45 @@ __global__ __launch_bounds__(64) void k_pick(PickArgs a) {
                 for (int probe = 0; probe < 64; ++probe) {
                     const unsigned slot = (h + probe) & a.table_mask;
                     const unsigned kk = a.keys[slot];
-                    if (kk == key) { m = a.masks[slot]; break; }
+                    if (kk == key) {
+                        for (int w = 0; w < nw; ++w) m[w] = a.masks[(long long)slot * nw + w];
+                        break;
+                    }
                     if (kk == 0xffffffffu) break;
                 }
             }
         }
-        smask[t] = m;
+#pragma unroll
+        for (int w = 0; w < RG_PW; ++w) smask[t * RG_PW + w] = m[w];
     }
     __syncthreads();
-    int votes = 0;
-    for (int t = 0; t < nsamp; ++t) votes += (int)((smask[t] >> lane) & 1ull);
-    if (lane >= a.P) votes = -1;
-    int key = (votes << 8) | (255 - lane);                   // most votes, lowest path id on ties
+    int votes[RG_PW];
+    int key = -1;
+#pragma unroll
+    for (int w = 0; w < RG_PW; ++w) {
+        votes[w] = 0;
+        if (w < nw) for (int t = 0; t < nsamp; ++t) votes[w] += (int)((smask[t * RG_PW + w] >> lane) & 1ull);
+        if (w * 64 + lane >= a.P) votes[w] = -1;
+        if (votes[w] >= 0) key = max(key, (votes[w] << 8) | (255 - (w * 64 + lane)));      // most votes, lowest path id on ties
+    }
     for (int d = WAVE / 2; d >= 1; d >>= 1) key = max(key, __shfl_xor(key, d, WAVE));
     const int best1 = key >> 8;
     const int p_one = best1 > 0 ? 255 - (key & 255) : 0;
     if (lane == 0) a.pick[rd] = p_one;
     if (!a.pick2) return;
     // two-path pick: split t in [1, nsamp): pre = this path's votes among samples [0, t)
-    int pre = 0, bestsum = -1, bt = 0, bp1 = 0, bp2 = 0;
+    int pre[RG_PW] = {0, 0, 0, 0};
+    int bestsum = -1, bt = 0, bp1 = 0, bp2 = 0;
     for (int t = 1; t < nsamp; ++t) {
-        pre += (int)((smask[t - 1] >> lane) & 1ull);
-        int k1 = lane < a.P ? ((pre << 8) | (255 - lane)) : -1;
-        int k2 = lane < a.P ? (((votes - pre) << 8) | (255 - lane)) : -1;
+        int k1 = -1, k2 = -1;
+#pragma unroll
+        for (int w = 0; w < RG_PW; ++w) {
+            if (w < nw) pre[w] += (int)((smask[(t - 1) * RG_PW + w] >> lane) & 1ull);
+            if (votes[w] >= 0) {
+                k1 = max(k1, (pre[w] << 8) | (255 - (w * 64 + lane)));
+                k2 = max(k2, ((votes[w] - pre[w]) << 8) | (255 - (w * 64 + lane)));
+            }
+        }
         k1 = __builtin_amdgcn_readlane(dpp_incl_max(k1, INT32_MIN), WAVE - 1);
         k2 = __builtin_amdgcn_readlane(dpp_incl_max(k2, INT32_MIN), WAVE - 1);
         const int sum = (k1 >> 8) + (k2 >> 8);

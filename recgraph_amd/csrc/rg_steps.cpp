@@ -155,18 +155,31 @@ auto split_tails = [&](const std::vector<StepRec>& in, std::vector<StepRec>& out
 // groups k LEADS in the records from there on (groups with other members only): a path that is hopeless for a read may
 // stop being computed once no path that is still needed appears in that union
 auto lead_table = [&](const std::vector<StepRec>& recs) {
+    // Layout: [evaluation point][path, padded to whole 64-path pages][word of the member set]: out[(e * PP + k) * NW + w], NW =
+    // 64-bit words per path set (1 up to 64 paths: the round-4 layout), PP = 64 * NW.  A group that spans pages is an alpha
+    // entry followed by continuation entries (y < 0) with the members of the other pages: walking backwards the continuation
+    // entries come first and are held until their alpha entry closes the group.
     const size_t EV = (size_t)1 << T.retire_shift;                    // records per evaluation point
     const size_t E = recs.size() / EV + 2;
-    std::vector<unsigned long long> out(E * 64, 0ull);
-    unsigned long long cur[64] = {};
+    const size_t NW = (size_t)((h.P + 63) / 64), PP = 64 * NW;
+    std::vector<unsigned long long> out(E * PP * NW, 0ull);
+    std::vector<unsigned long long> cur(PP * NW, 0ull);
+    unsigned long long grp[RG_PW] = {};
     for (size_t t = recs.size(); t-- > 0;) {
         const unsigned x = (unsigned)recs[t].x;
         const unsigned long long mask = ((unsigned long long)(unsigned)recs[t].w << 32) | (unsigned)recs[t].z;
-        if (recs[t].y >= 0 && mask && (mask & (mask - 1))) {          // not a continuation entry, more than one member
-            const int alpha = ((x >> 23) & 4u) ? __builtin_ctzll(mask) : (int)((x >> 26) & 63u);
-            cur[alpha] |= mask;
+        const size_t page = ((unsigned)recs[t].y >> 29) & 3u;
+        grp[page] |= mask;
+        if (recs[t].y >= 0) {                                         // the group's alpha entry: the group is complete
+            int members = 0;
+            for (size_t w = 0; w < NW; ++w) members += __builtin_popcountll(grp[w]);
+            if (mask && members > 1) {
+                const size_t alpha = page * 64 + (size_t)(((x >> 23) & 4u) ? __builtin_ctzll(mask) : (int)((x >> 26) & 63u));
+                for (size_t w = 0; w < NW; ++w) cur[alpha * NW + w] |= grp[w];
+            }
+            for (size_t w = 0; w < RG_PW; ++w) grp[w] = 0ull;
         }
-        if (t % EV == 0) for (int k = 0; k < 64; ++k) out[(t / EV) * 64 + k] = cur[k];
+        if (t % EV == 0) std::copy(cur.begin(), cur.end(), out.begin() + (long long)((t / EV) * PP * NW));
     }
     return out;
 };
@@ -178,10 +191,10 @@ auto lead_table = [&](const std::vector<StepRec>& recs) {
     T.lead_plain.clear();
     T.lead_split.clear();
     T.split.clear();
-    if (h.P <= 64) T.lead_plain = lead_table(T.plain);
+    T.lead_plain = lead_table(T.plain);
     if (want_split) {
         split_tails(T.plain, T.split);
-        if (h.P <= 64) T.lead_split = lead_table(T.split);
+        T.lead_split = lead_table(T.split);
     }
 }
 

@@ -319,6 +319,14 @@ __device__ __forceinline__ void run_dispatch_from(F& f, int n) {
 // kSemi = true: the semiglobal modes (-m 5 / -m 9: zero first column, per-path end rows).  A template flag since round 5: the
 // end-row bookkeeping (four per-lane registers of state, sixteen column-select masks in SGPRs) was carried — spilled — through
 // the record loop of every global-mode sweep
+// A path set of up to RG_PW 64-bit words as NAMED scalars: as an array (indexed by a page that is only known at run time, or
+// passed by reference) the compiler kept it in scratch — a scratch load per step record (round 6, the wide variants).
+struct PathWords {
+    unsigned long long w0, w1, w2, w3;
+    __device__ __forceinline__ unsigned long long get(int i) const { return i == 0 ? w0 : (i == 1 ? w1 : (i == 2 ? w2 : w3)); }
+    __device__ __forceinline__ void set(int i, unsigned long long v) { if (i == 0) w0 = v; else if (i == 1) w1 = v; else if (i == 2) w2 = v; else w3 = v; }
+};
+
 #ifdef RG_SWEEP16_VGPR_CAP
 #define RG_SWEEP16_CAP_ATTR __attribute__((amdgpu_num_vgpr(RG_SWEEP16_VGPR_CAP)))      // (experiments: a hard register budget)
 #else
@@ -331,7 +339,8 @@ __global__ __launch_bounds__(64, C > 16 ? 2 : (kColmax != 0 ? RG_SWEEP16_FWD_WAV
     // gather runs: not at 32 columns per lane in the record variants (a row is 16 registers there: the run's A / G / masks / steps /
     // values / paths alone are 112, and with retirement and register runs compiled in the variant spilled 78)
     constexpr bool kGather = C <= 16 || !kRec || RG_SWEEP16_GATHER32;
-    constexpr bool kRet = kRec && kColmax != 1 && !kWide && !kSemi;   // PATH RETIREMENT (record pipelines of -m 8, P <= 64): see retire_eval
+    constexpr bool kRet = kRec && kColmax != 1 && !kSemi;   // PATH RETIREMENT (record pipelines of -m 8; since round 6 also more than 64 paths): see retire_eval
+    constexpr int NW = kWide ? RG_PW : 1;                   // 64-bit words of a path set
     // rows kept in registers across the inner rows of a segment: groups of up to 4 paths (2 at 32 columns per lane: a row is 16 registers there)
     // (the -m 4 / -m 5 variant: 3 — with 4 the specialised run loops of round 6 need 178 registers and the variant falls from three
     // waves per SIMD to two: config 4 271 k against 296 k reads/s)
@@ -787,17 +796,23 @@ __global__ __launch_bounds__(64, C > 16 ? 2 : (kColmax != 0 ? RG_SWEEP16_FWD_WAV
     // only if its members include one of them.  k_verify checks afterwards that the paths k_search chose are in `dsel` and
     // sends the read to the second pass otherwise (it stores every word: a.pick is null there), exactly like a read whose
     // speculative bound failed.  Sweeps without picks (no speculation: -m 4 / 5 / 9, more than 64 paths, three sweeps) store all.
-    unsigned long long dsel = ~0ull;
+    PathWords dsel_w{~0ull, ~0ull, ~0ull, ~0ull};
     if (a.dsel_pick) {
         const int p1 = a.dsel_pick[rd], p2 = a.dsel_pick2 ? a.dsel_pick2[2 * rd] : -1;
-        dsel = (1ull << (p1 & 63)) | (p2 >= 0 ? 1ull << (p2 & 63) : 0ull);
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            unsigned long long m = ((p1 >> 6) == w) ? 1ull << (p1 & 63) : 0ull;
+            if (p2 >= 0 && (p2 >> 6) == w) m |= 1ull << (p2 & 63);
+            const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)m), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(m >> 32));
+            dsel_w.set(w, ((unsigned long long)hi << 32) | lo);
+        }
     }
-    const unsigned dsel_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)dsel), dsel_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(dsel >> 32));
-    const unsigned long long dsel_u = ((unsigned long long)dsel_hi << 32) | dsel_lo;
+    // (a wave-uniform word by a wave-uniform page: selects over named scalars; the narrow variants only have word 0)
+    auto word_of = [&](const PathWords& pw, int page) -> unsigned long long { return kWide ? pw.get(page) : pw.w0; };
     // (kColmax == 1, the first sweep of the three-sweep pipeline, runs without direction words at all)
     // (the rows a sweep visits first store every word: SweepArgs::dsel_lo / dsel_hi)
-    auto want_dirs = [&](unsigned long long members, int row) -> bool {
-        return (kColmax != 1 || dirs != nullptr) && ((members & dsel_u) != 0ull || (rev ? row > a.dsel_hi : row < a.dsel_lo));
+    auto want_dirs = [&](unsigned long long members, int page, int row) -> bool {
+        return (kColmax != 1 || dirs != nullptr) && ((members & word_of(dsel_w, page)) != 0ull || (rev ? row > a.dsel_hi : row < a.dsel_lo));
     };
     const int4* steps = rev ? a.rsteps : a.fsteps;
     const int nsteps = rev ? a.nrsteps : a.nfsteps;
@@ -808,12 +823,18 @@ __global__ __launch_bounds__(64, C > 16 ? 2 : (kColmax != 0 ? RG_SWEEP16_FWD_WAV
     // PATH RETIREMENT: the records of the block in `recs` that still have to be looked at — a needed member, or the last group
     // of a row with several groups (it closes the row even when skipped); the record loop jumps over the others
     unsigned long long live = ~0ull;
-    unsigned long long needed = a.g.P >= 64 ? ~0ull : ((1ull << a.g.P) - 1ull);
+    PathWords needed{0ull, 0ull, 0ull, 0ull};       // (one word per 64-path page; wave-uniform)
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+        const int left = a.g.P - 64 * w;
+        needed.set(w, left >= 64 ? ~0ull : (left <= 0 ? 0ull : ((1ull << left) - 1ull)));
+    }
     auto block_live = [&]() -> unsigned long long {
         const unsigned f = ((unsigned)recs.x >> 23) & 7u, field = ((unsigned)recs.x >> 26) & 63u;
         const bool is_run = (f & 4u) && field != 0u;
         const unsigned long long m = ((unsigned long long)(unsigned)recs.w << 32) | (unsigned)recs.z;
-        return __ballot((m & needed) != 0ull || (!is_run && (f & 3u) == 2u));
+        const unsigned long long nd = kWide ? needed.get((recs.y >> 29) & 3) : needed.w0;      // (per lane: the page of this lane's record)
+        return __ballot((m & nd) != 0ull || (!is_run && (f & 3u) == 2u));
     };
     // Records are taken in order and a look-ahead never goes back: whoever first touches a record of the next block moves
     // `recs` there.  The block is waited for at once (an L2 hit once per 64 records): round 4 kept the block behind the
@@ -840,6 +861,10 @@ __global__ __launch_bounds__(64, C > 16 ? 2 : (kColmax != 0 ? RG_SWEEP16_FWD_WAV
     auto peek_w0 = [&](int tt) -> int {
         if ((tt >> 6) != blk) to_block(tt >> 6);
         return __builtin_amdgcn_readlane(recs.x, tt & (WAVE - 1));
+    };
+    auto peek_w1 = [&](int tt) -> int {
+        if ((tt >> 6) != blk) to_block(tt >> 6);
+        return __builtin_amdgcn_readlane(recs.y, tt & (WAVE - 1));
     };
     auto peek_gm = [&](int tt) -> unsigned long long {
         if ((tt >> 6) != blk) to_block(tt >> 6);
@@ -952,46 +977,76 @@ __global__ __launch_bounds__(64, C > 16 ? 2 : (kColmax != 0 ? RG_SWEEP16_FWD_WAV
     unsigned long long stat_e = 0, stat_n = 0, stat_h = 0;
 #endif
     auto retire_eval = [&](int e) {
-        unsigned long long hop = 0, todo = needed;
+        PathWords hop{0ull, 0ull, 0ull, 0ull};
         // (four rows in flight per wait: one row per wait made the evaluations ~8 % of the sweep)
         constexpr int EB = C <= 16 ? 4 : 2;
         int rvc[H];
         ld_row(PR_RVL, rvc);
-        while (todo) {
-            int kq[EB];
-            int tmp[EB][H];
 #pragma unroll
-            for (int u = 0; u < EB; ++u) {
-                kq[u] = -1;
-                if (todo) {
-                    kq[u] = __builtin_ctzll(todo);
-                    todo &= todo - 1;
-                    ld_row(kq[u], tmp[u]);
+        for (int pg = 0; pg < NW; ++pg) {
+            unsigned long long todo = needed.get(pg), hp = 0ull;
+            while (todo) {
+                int kq[EB];
+                int tmp[EB][H];
+#pragma unroll
+                for (int u = 0; u < EB; ++u) {
+                    kq[u] = -1;
+                    if (todo) {
+                        kq[u] = __builtin_ctzll(todo);
+                        todo &= todo - 1;
+                        ld_row(pg * 64 + kq[u], tmp[u]);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < EB; ++u) {
+                    if (kq[u] < 0) break;
+                    int m = pk_add_sat(tmp[u][0], rvc[0]);
+#pragma unroll
+                    for (int r = 1; r < H; ++r) m = pk_max(m, pk_add_sat(tmp[u][r], rvc[r]));
+                    const int v = max(lo16(m), hi16(m));
+                    if (__builtin_amdgcn_readlane(dpp_incl_max(v, INT32_MIN), WAVE - 1) < 0) hp |= 1ull << kq[u];
                 }
             }
-#pragma unroll
-            for (int u = 0; u < EB; ++u) {
-                if (kq[u] < 0) break;
-                int m = pk_add_sat(tmp[u][0], rvc[0]);
-#pragma unroll
-                for (int r = 1; r < H; ++r) m = pk_max(m, pk_add_sat(tmp[u][r], rvc[r]));
-                const int v = max(lo16(m), hi16(m));
-                if (__builtin_amdgcn_readlane(dpp_incl_max(v, INT32_MIN), WAVE - 1) < 0) hop |= 1ull << kq[u];
-            }
+            hop.set(pg, hp);
         }
-        const unsigned long long lead_k = lane < P ? (rev ? a.rlead : a.flead)[(long long)e * 64 + lane] : 0ull;
-        unsigned long long nd = needed & ~hop;
+        // lead table (rg_steps.cpp): [evaluation point][path, padded to whole pages][word]: lane l of page pg asks for path 64 pg + l
+        const int nw = kWide ? (P + 63) >> 6 : 1;
+        const unsigned long long* lead = (rev ? a.rlead : a.flead) + (long long)e * (64 * nw) * nw;
+        PathWords nd{0ull, 0ull, 0ull, 0ull};
+#pragma unroll
+        for (int pg = 0; pg < NW; ++pg) nd.set(pg, needed.get(pg) & ~hop.get(pg));
 #ifdef RG_SWEEP16_RETSTAT
-        const unsigned long long nd_first = nd;
+        const unsigned long long nd_first = nd.w0;
 #endif
-        for (;;) {
-            const unsigned long long ad = __ballot(((needed >> lane) & 1ull) && !((nd >> lane) & 1ull) && (lead_k & nd) != 0ull);
-            if (!ad) break;
-            nd |= ad;
+        if constexpr (!kWide) {
+            const unsigned long long lead_k = lane < P ? lead[lane] : 0ull;
+            for (;;) {
+                const unsigned long long ad = __ballot(((needed.w0 >> lane) & 1ull) && !((nd.w0 >> lane) & 1ull) && (lead_k & nd.w0) != 0ull);
+                if (!ad) break;
+                nd.w0 |= ad;
+            }
+        } else {
+            // (the lead words are read again in every round of the closure — sixteen 64-bit values per lane would otherwise sit in
+            // registers across the evaluation: it runs once per 256 records, the loads are L2 hits)
+            for (;;) {
+                bool grown = false;
+#pragma unroll
+                for (int pg = 0; pg < NW; ++pg) {
+                    bool leads = false;
+                    if (pg < nw && pg * 64 + lane < P && ((needed.get(pg) >> lane) & 1ull) && !((nd.get(pg) >> lane) & 1ull)) {
+#pragma unroll
+                        for (int w = 0; w < NW; ++w)
+                            if (w < nw) leads = leads || (lead[(long long)(pg * 64 + lane) * nw + w] & nd.get(w)) != 0ull;
+                    }
+                    const unsigned long long ad = __ballot(leads);
+                    if (ad) { nd.set(pg, nd.get(pg) | ad); grown = true; }
+                }
+                if (!grown) break;
+            }
         }
         needed = nd;
 #ifdef RG_SWEEP16_RETSTAT
-        stat_e += 1ull; stat_n += (unsigned long long)__popcll(nd); stat_h += (unsigned long long)__popcll(nd_first);
+        stat_e += 1ull; stat_n += (unsigned long long)__popcll(nd.w0); stat_h += (unsigned long long)__popcll(nd_first);
 #endif
     };
     while (t < nsteps) {
@@ -1031,7 +1086,8 @@ __global__ __launch_bounds__(64, C > 16 ? 2 : (kColmax != 0 ? RG_SWEEP16_FWD_WAV
         // pays when R * (84 (nm - 1) - 160) >= 90 (nm - 1)  (16 or 32 paths: 2 rows, 8 paths: 2, 5 paths: 3; round 4 had
         // 77 / 160 / 200: 3 / 4 / 6 rows.  Config 4's lone sweep 15.2 -> 14.8 ms, config 5 unchanged)
         const int run_left = (flags & F_INNER) ? ((w0 >> 26) & 63) : 0;
-        const unsigned long long gm = kRet ? (gmask & needed) : gmask;     // the members still computed
+        const int page = kWide ? (w1 >> 29) & 3 : 0;
+        const unsigned long long gm = kRet ? (gmask & word_of(needed, page)) : gmask;     // the members still computed
         const int nme = kRet ? __popcll(gm) : nm;
         if (kRet && gm == 0ull) {
             // every member retired (and with them the alpha: it would be needed otherwise): the record is skipped; a row
@@ -1131,8 +1187,8 @@ __global__ __launch_bounds__(64, C > 16 ? 2 : (kColmax != 0 ? RG_SWEEP16_FWD_WAV
                 load_steps(rli, s);
                 int lmax_unused;
                 RowOps16<C>::alpha(A, s, g_i, g0, lane, XU, XL, lmax_unused);
-                RG_ROWSTAT((++st_grow, st_gmem += nme, st_dirs += want_dirs(gmask, ri) ? 1 : 0));
-                if (want_dirs(gmask, ri)) store_dirs(rslot, XU, XL);      // (kbase = 0: gather runs are narrow-graph only)
+                RG_ROWSTAT((++st_grow, st_gmem += nme, st_dirs += want_dirs(gmask, 0, ri) ? 1 : 0));
+                if (want_dirs(gmask, 0, ri)) store_dirs(rslot, XU, XL);      // (page 0: gather runs are narrow-graph only)
                 const unsigned lmask = RowOps16<C>::masks(XU, XL, MU, ML);
                 const int src = RowOps16<C>::src_lane(lmask, lane);
                 RowOps16<C>::template member<true>(G, MU, lane, MU, ML, lmask, src);   // the gather follows the directions, adds nothing (SEL unused)
@@ -1307,7 +1363,8 @@ __global__ __launch_bounds__(64, C > 16 ? 2 : (kColmax != 0 ? RG_SWEEP16_FWD_WAV
             // meet (profiles/r05_isa_sweep16.txt: 25 % of the hot loop's issue slots were SALU / branch / wait)
             auto run_rows = [&](auto rn_tag) __attribute__((always_inline)) {
             constexpr int RN = decltype(rn_tag)::value;
-            const unsigned long long run_sel = kWide ? ~0ull : rgm;     // (every row of the run — and its tail — has the run's members)
+            const unsigned long long run_sel = rgm;     // (every row of the run — and its tail — has the run's members, all of one page)
+            const int run_page = kWide ? kbase >> 6 : 0;
             unsigned nrows = 0;                 // rows of this run: the cell counters move once per run, not once per row
             while (true) {
                 const int g_i = gcost;
@@ -1319,8 +1376,8 @@ __global__ __launch_bounds__(64, C > 16 ? 2 : (kColmax != 0 ? RG_SWEEP16_FWD_WAV
                 if (!kAhead) load_steps(rli, s);
                 int lmax;
                 RowOps16<C>::alpha(rr[0], s, g_i, g0, lane, XU, XL, lmax);
-                RG_ROWSTAT((++st_rn[RN], st_dirs += want_dirs(run_sel, ri) ? 1 : 0, st_tail += tail ? 1 : 0));
-                if (want_dirs(run_sel, ri)) store_dirs(rslot, XU, XL);
+                RG_ROWSTAT((++st_rn[RN], st_dirs += want_dirs(run_sel, run_page, ri) ? 1 : 0, st_tail += tail ? 1 : 0));
+                if (want_dirs(run_sel, run_page, ri)) store_dirs(rslot, XU, XL);
                 if constexpr (RN > 1) {
                     int MU[H], ML[H];
                     const unsigned lmask = RowOps16<C>::masks(XU, XL, MU, ML);
@@ -1571,8 +1628,12 @@ __global__ __launch_bounds__(64, C > 16 ? 2 : (kColmax != 0 ? RG_SWEEP16_FWD_WAV
                 int lmax_unused;
                 RowOps16<C>::alpha(rowa, s, g_i, g0, lane, XU, XL, lmax_unused);
                 RG_ROW_ST(ga, rowa);
-                RG_ROWSTAT((++st_gen, st_genmem += nme, st_dirs += want_dirs(kWide ? ~0ull : gmask, i) ? 1 : 0));
-                if (want_dirs(kWide ? ~0ull : gmask, i)) store_dirs(slot, XU, XL);
+                // (a group that spans pages — continuation entries follow — may hold a picked path in a page this entry does not
+                // see: it stores its word whatever its own members are)
+                bool wd = want_dirs(gmask, page, i);
+                if (kWide && !wd && t + 1 < nsteps) wd = peek_w1(t + 1) < 0;
+                RG_ROWSTAT((++st_gen, st_genmem += nme, st_dirs += wd ? 1 : 0));
+                if (wd) store_dirs(slot, XU, XL);
                 lmask = RowOps16<C>::masks(XU, XL, MU, ML);
                 src = RowOps16<C>::src_lane(lmask, lane);
                 if (track) {
@@ -1650,7 +1711,7 @@ __global__ __launch_bounds__(64, C > 16 ? 2 : (kColmax != 0 ? RG_SWEEP16_FWD_WAV
         for (int k = lane; k < P; k += WAVE) {
             const int pv = rows[(long long)k * wrow + ln * H + (ql % H)];
             // (a retired path's row is stale: its true final score is below the bound k_verify checks the result against)
-            rs->sink_val[k] = (kRet && !((needed >> k) & 1ull)) ? NEG32 : (ql >= H ? hi16(pv) : lo16(pv)) + n * gcost;
+            rs->sink_val[k] = (kRet && !((word_of(needed, k >> 6) >> (k & 63)) & 1ull)) ? NEG32 : (ql >= H ? hi16(pv) : lo16(pv)) + n * gcost;
         }
     }
     if (semi_end) {

@@ -185,7 +185,7 @@ def test_full_launch_every_wave_slot_vs_oracle(oracle, cfg):
         assert not bad, (cfg, attempt, len(bad), bad[:12])
 
 
-@pytest.mark.parametrize("case", ["c8_400bp", "c4_200bp", "semi_1kbp", "wide_70_paths", "m4_semi_600bp", "len1500", "m4_len1500", "wide_128_paths"])
+@pytest.mark.parametrize("case", ["c8_400bp", "c4_200bp", "semi_1kbp", "wide_70_paths", "m4_semi_600bp", "len1500", "m4_len1500", "wide_128_paths", "wide_200_paths"])
 def test_full_launches_of_the_other_sweep_variants_vs_oracle(oracle, case):
     """The same for the variants configs 4 and 5 do not reach — 8 and 4 columns per lane (four and six-plus waves per SIMD: more
     row stores in flight per CU than anywhere else), the semiglobal flag, more than 64 paths — each as ONE launch that fills
@@ -201,7 +201,8 @@ def test_full_launches_of_the_other_sweep_variants_vs_oracle(oracle, case):
         # -m 4 variant with register runs (round 6); 128 paths: two 64-path pages per row
         "len1500": (api.MODE_RECOMBINATION, oracle.M8_ABS, 15000, 32, 1500, 2048, 0.5),
         "m4_len1500": (api.MODE_PATHWISE, oracle.M4_ABS, 15000, 32, 1500, 2048, 0.0),
-        "wide_128_paths": (api.MODE_RECOMBINATION, oracle.M8_ABS, 10000, 128, 1000, 1024, 0.5),
+        "wide_128_paths": (api.MODE_RECOMBINATION, oracle.M8_ABS, 10000, 128, 1000, 2048, 0.5),
+        "wide_200_paths": (api.MODE_RECOMBINATION, oracle.M8_ABS, 6000, 200, 600, 2048, 0.5),
     }[case]
     sg = synth.haplotype_graph(rows, P, path_len=rlen, seed=4242)
     g = api.Graph.from_gfa_text(sg.gfa())

@@ -620,3 +620,42 @@ def test_longest_supported_reads_eight_stripes_of_2048_columns(oracle):
     assert int(re.search(r"score: (-?\d+)\t", t8[0]).group(1)) == int(re.search(r"score: (-?\d+)\t", t4[0]).group(1))
     t8d, st = api.align_batch(gg, rd, ["r0"], mode=api.MODE_RECOMBINATION)
     assert not any(st)
+
+
+def test_wide_graphs_retire_paths_and_speculate(oracle):
+    """Round 6: graphs with more than 64 paths run on the speculative bound, retire paths (several 64-bit words of `needed`,
+    lead tables of several words, groups that span pages) and store direction words on demand like the narrow ones.  70, 130
+    and 200 paths, block-built and random-walk graphs, against the oracle — with the retirement evaluated every 16 / 4 records
+    (graphs of this size retire nothing at the default period), forward / reverse only, speculation off / zero margin / forced
+    second pass, one-path picks, and without the always-stored edge rows; and the counters say that paths WERE retired."""
+    from recgraph_amd import api, synth
+    cases = [(synth.haplotype_graph(900, 70, path_len=150, seed=71), 150), (synth.haplotype_graph(1300, 130, path_len=180, seed=72), 180),
+             (synth.haplotype_graph(1100, 200, path_len=140, seed=73), 140)]
+    g4 = synth.random_dag_graph(170, 90, seed=74, max_jump=4, max_seg=9, similar=0.6)
+    cases.append((g4, min(len(g4.path_sequence(k)) for k in range(90))))
+    switches = ((), (("retire_shift", 4),), (("retire_shift", 2),), (("retire_shift", 4), ("no_retire", 2)), (("retire_shift", 4), ("no_retire", 3)),
+                (("no_retire", 1),), (("no_spec", 1),), (("retire_shift", 4), ("spec_margin", 0)), (("spec_margin", -1000000),),
+                (("retire_shift", 4), ("no_pick2", 1)), (("retire_shift", 3), ("dsel_edge", 1000)), (("no_dsel", 1),), (("retire_shift", 4), ("chunk_reads", 5)))
+    defaults = {"spec_margin": SPEC_MARGIN_DEFAULT, "retire_shift": 8, "dsel_edge": 8}
+    retired = 0
+    for g, plen in cases:
+        P = len(g.paths)
+        rd = synth.haplotype_reads(g, 14, length=plen, seed=700 + P, mosaic_frac=0.6) + [g.path_sequence(P - 1)[:plen], g.path_sequence(65)[:plen]]
+        gg = api.Graph.from_gfa_text(g.gfa())
+        names = ["r%d" % i for i in range(len(rd))]
+        base = _check(oracle, g.gfa(), rd, api.MODE_RECOMBINATION, oracle.M8_ABS)
+        for combo in switches:
+            try:
+                for name, val in combo:
+                    api.set_option(name, val)
+                b = api.Batch(gg, rd, api.make_params(api.MODE_RECOMBINATION))
+                b.run()
+                b.fetch()
+                texts = [b.gaf_text(i, names[i], i + 1) for i in range(len(rd))]
+                if combo == (("retire_shift", 4),) and b.cell_updates_performed < 0.9 * b.cell_updates:
+                    retired += 1
+            finally:
+                for name, _ in combo:
+                    api.set_option(name, defaults.get(name, 0))
+            assert texts == base, (P, combo)
+    assert retired >= 2, retired

@@ -316,7 +316,26 @@ def test_step_tables_of_the_pathwise_sweeps():
                     cont_run = nxt is not None and nxt["flags"] == 7
                     assert r["field"] == (min(nxt["field"] + 1, 63) if cont_run else 1), (t, r, nxt)
             if P > 64:
-                assert points == 0 and any(r["cont"] for r in f)
+                # more than 64 paths: continuation entries, no split table; the retirement table (round 6) holds member sets of
+                # several words — checked against its definition below with the groups reassembled from their entries
+                assert any(r["cont"] for r in f)
+                ev = 256
+                assert points == len(f) // ev + 2
+                cur, want, grp = {}, {}, 0
+                for t in range(len(f) - 1, -1, -1):
+                    r = f[t]
+                    grp |= r["mask"] << (64 * r["page"])
+                    if not r["cont"]:
+                        if bin(grp).count("1") > 1:
+                            a_bit = (r["mask"] & -r["mask"]).bit_length() - 1 if r["flags"] & 4 else r["field"]
+                            alpha = 64 * r["page"] + a_bit
+                            assert (grp >> alpha) & 1
+                            cur[alpha] = cur.get(alpha, 0) | grp
+                        grp = 0
+                    if t % ev == 0:
+                        for k, m in cur.items():
+                            want[(t // ev, k)] = m
+                assert lead == want and len(lead) > 10
                 continue
             # ---- split table ----
             m2, p2, split, lead2 = _parse_steps(g.dump(cs))

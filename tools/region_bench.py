@@ -22,7 +22,7 @@ CASES = {
     "hoxd70": (8, 10000, 32, 1000, {"mtx": "HOXD70.mtx"}, 2048, 4),
     "len1500": (8, 15000, 32, 1500, {}, 2048, 6),
     "len600": (8, 6000, 32, 600, {}, 4096, 6),
-    "p128": (8, 10000, 128, 1000, {}, 1024, 4),
+    "p128": (8, 10000, 128, 1000, {}, 2048, 6),
     "m4_len1500": (4, 15000, 32, 1500, {}, 2048, 6),
     "len5000": (8, 50000, 32, 5000, {}, 256, 4),
 }
