@@ -468,7 +468,7 @@ std::string dump_graph(const HostGraph& g, int which) {
             // "point:path:mask" entries (non-zero masks only)
             if (g.P == 0) break;
             StepTables T;
-            build_step_tables(g, which <= 32, g.P <= 64, T);
+            build_step_tables(g, which <= 32, true, T);
             const bool split = which == 32 || which == 34;
             const std::vector<StepRec>& recs = split ? T.split : T.plain;
             const std::vector<unsigned long long>& lead = split ? T.lead_split : T.lead_plain;

@@ -295,7 +295,7 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
             if (!v.empty()) HIPCHK(hipMemcpy(dst.p, v.data(), v.size() * sizeof(StepRec), hipMemcpyHostToDevice));
             return RG_OK;
         };
-        w.have_split = P <= 64;
+        w.have_split = true;       // (up to 64 paths: TAILs behind their register runs; more: the wide-run table, rg_steps.cpp)
         StepTables st;
         build_step_tables(h, true, w.have_split, st);
         if ((rc = up_recs(w.fsteps, st.plain))) return rc;

@@ -151,6 +151,46 @@ auto split_tails = [&](const std::vector<StepRec>& in, std::vector<StepRec>& out
         q = e;
     }
 };
+// WIDE RUNS (more than 64 paths, k_sweep16 record variants; round 6).  In the plain table only a row with ONE ENTRY starts a register
+// run, and in a graph with more than 64 paths the group of nearly every row spans pages (an alpha entry + continuation entries): no
+// runs at all, every member row loaded and stored in every row.  This form of the table — it takes the place of the split table,
+// which exists only up to 64 paths — flags the alpha entry of a row with ONE GROUP led by its lowest member as the HEAD / inner row
+// of a run like the narrow tables do (run field = rows left in the segment, this one included, capped at 63), continuation entries
+// or not: the kernel gathers the members that are still needed from the alpha entry and the continuation entries behind it,
+// and when at most KRUN are left it runs the segment's rows with those in registers, stepping over the continuation entries.
+auto wide_runs = [&](const std::vector<StepRec>& in, std::vector<StepRec>& out) {
+    out = in;
+    std::vector<size_t> alpha_of_row;          // index of the flagged alpha entry per flagged row, in table order
+    size_t q = 0;
+    while (q < in.size()) {
+        size_t e = q;
+        while (e < in.size() && meta[e].row == meta[q].row) ++e;
+        bool one_group = in[q].y >= 0 && meta[q].low;
+        for (size_t j = q + 1; j < e; ++j) one_group = one_group && in[j].y < 0;
+        // (the alpha must be the lowest path of the WHOLE group: the entries of a group come in ascending page order, the
+        // alpha entry first, so its page must not lie above a continuation entry's)
+        const unsigned pg0 = ((unsigned)in[q].y >> 29) & 3u;
+        for (size_t j = q + 1; j < e; ++j) one_group = one_group && ((((unsigned)in[j].y >> 29) & 3u) > pg0);
+        if (one_group) {
+            const int i = meta[q].row;
+            const bool inner = forward ? (h.node_id[i] == h.node_id[i - 1] && i > 1) : (h.node_id[i] == h.node_id[i + 1]);
+            const unsigned fl = inner ? 7u : 4u;
+            out[q].x = (int)(((unsigned)out[q].x & ~(7u << 23)) | (fl << 23));
+        }
+        q = e;
+    }
+    // run fields (the narrow rule, with the continuation entries stepped over)
+    int left = 0;
+    for (size_t t = out.size(); t-- > 0;) {
+        if (out[t].y < 0) continue;                                   // a continuation entry: part of the row of its alpha entry
+        const bool inner = ((unsigned)out[t].x >> 23) & 4u;
+        left = inner ? std::min(left + 1, 63) : 0;
+        if (inner) {
+            out[t].x = (int)(((unsigned)out[t].x & 0x03ffffffu) | ((unsigned)left << 26));
+            if ((((unsigned)out[t].x >> 23) & 7u) == 4u) left = 0;
+        }
+    }
+};
 // PATH RETIREMENT (k_sweep16): per evaluation point e (record e << retire_shift) and path k, the union of the member masks of the
 // groups k LEADS in the records from there on (groups with other members only): a path that is hopeless for a read may
 // stop being computed once no path that is still needed appears in that union
@@ -193,7 +233,8 @@ auto lead_table = [&](const std::vector<StepRec>& recs) {
     T.split.clear();
     T.lead_plain = lead_table(T.plain);
     if (want_split) {
-        split_tails(T.plain, T.split);
+        if (h.P <= 64) split_tails(T.plain, T.split);
+        else wide_runs(T.plain, T.split);
         T.lead_split = lead_table(T.split);
     }
 }

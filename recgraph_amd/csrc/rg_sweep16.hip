@@ -1297,11 +1297,47 @@ __global__ __launch_bounds__(64, C > 16 ? 2 : (kColmax != 0 ? RG_SWEEP16_FWD_WAV
         }
         int e_i = i, e_w1 = w1, e_flags = flags;   // the row whose epilogue runs at the end of this iteration
         bool e_adv = true;
+        // WIDE RUNS (more than 64 paths; the wide-run table of rg_steps.cpp): the alpha entry of a row with one group led by its
+        // lowest member is flagged like the narrow tables' HEAD / inner rows, continuation entries or not.  Here the members
+        // that are still needed are gathered from this entry and the continuation entries behind it; when at most KRUN are left the
+        // segment's rows run with those in registers (the run loop steps over the continuation entries: `went` records per row),
+        // otherwise the entries take the general path one by one (this entry then must not close the row: its continuation
+        // entries do).
+        int went = 1, wide_n = 0, wide_total = nm;
+        int wide_ids[KRUN > 0 ? KRUN : 1];
+        bool wide_sel = false;
+        if (kWide && KRUN > 0 && (flags & F_INNER) && run_left > 0) {
+#pragma unroll
+            for (int kk = 0; kk < KRUN; ++kk) wide_ids[kk] = 0;
+            auto add = [&](unsigned long long m, int base) {
+                while (m) {
+                    const int id = base + __builtin_ctzll(m);
+                    m &= m - 1;
+#pragma unroll
+                    for (int kk = 0; kk < KRUN; ++kk) if (kk == wide_n) wide_ids[kk] = id;       // (no dynamically indexed array)
+                    ++wide_n;
+                }
+            };
+            add(gm, kbase);
+            wide_sel = (gmask & word_of(dsel_w, page)) != 0ull;
+            while (t + went < nsteps) {
+                const int nw1 = peek_w1(t + went);
+                if (nw1 >= 0) break;
+                const unsigned long long mm = peek_gm(t + went);
+                const int pg = (nw1 >> 29) & 3;
+                wide_total += __popcll(mm);
+                add(mm & word_of(needed, pg), pg * 64);
+                wide_sel = wide_sel || (mm & word_of(dsel_w, pg)) != 0ull;
+                ++went;
+            }
+            if (went > 1) e_flags &= ~F_LAST;
+        }
+        const bool wide_run = kWide && KRUN > 0 && (flags & F_INNER) && run_left > 0 && wide_n >= 1 && wide_n <= KRUN;
         // (PATH RETIREMENT: a wide group of which <= KRUN members are left runs here too — a gather run costs two member
         // updates per row whatever is left of the group; like a gather run it leaves bkey alone, which is what the split
         // tables count on for the runs between the groups of a row)
-        if (KRUN > 0 && (flags & F_INNER) && (nm <= KRUN || (kRet && nme <= KRUN && RG_SWEEP16_GATHER && kGather && !kWide && a.gather_ok && !semi_end &&
-                                                             run_left * (RG_GATHER_PER_MEMBER_ROW * (nm - 1) - RG_GATHER_PER_ROW) >= RG_GATHER_PER_MEMBER_RUN * (nm - 1))) && run_left > 0) {
+        if (kWide ? wide_run : (KRUN > 0 && (flags & F_INNER) && (nm <= KRUN || (kRet && nme <= KRUN && RG_SWEEP16_GATHER && kGather && a.gather_ok && !semi_end &&
+                                                             run_left * (RG_GATHER_PER_MEMBER_ROW * (nm - 1) - RG_GATHER_PER_ROW) >= RG_GATHER_PER_MEMBER_RUN * (nm - 1))) && run_left > 0)) {
             // ---- inner rows of a segment with a small group: the same paths, one group, predecessor = previous row.
             // Their rows stay in registers for the whole run: no row load/store latency, no HBM traffic.  The group
             // alpha of an inner row is its lowest path (alphas[row] == alphas[pred], rg_graph.cpp) = member 0.
@@ -1311,10 +1347,13 @@ __global__ __launch_bounds__(64, C > 16 ? 2 : (kColmax != 0 ? RG_SWEEP16_FWD_WAV
             // drains every store issued before them — in the old order (stores, next record, loads, wait) that was the whole
             // run's rows on every run boundary.  Here the wait covers loads only and the stores drain behind the next run's
             // arithmetic.  rnm / rgm / mk: the run in progress.)
-            int rnm = nme;                        // members computed (PATH RETIREMENT: the needed ones)
+            int rnm = kWide ? wide_n : nme;       // members computed (PATH RETIREMENT: the needed ones)
             unsigned long long rgm = gmask;       // the run's record mask (what its continuation records carry)
             int mk[KRUN > 0 ? KRUN : 1];
-            {
+            if (kWide) {
+#pragma unroll
+                for (int kk = 0; kk < KRUN; ++kk) mk[kk] = wide_ids[kk];
+            } else {
                 unsigned long long tm = kRet ? gm : rgm;
 #pragma unroll
                 for (int kk = 0; kk < KRUN; ++kk) { mk[kk] = tm ? kbase + __builtin_ctzll(tm) : 0; tm = tm ? (tm & (tm - 1)) : 0; }
@@ -1363,8 +1402,9 @@ __global__ __launch_bounds__(64, C > 16 ? 2 : (kColmax != 0 ? RG_SWEEP16_FWD_WAV
             // meet (profiles/r05_isa_sweep16.txt: 25 % of the hot loop's issue slots were SALU / branch / wait)
             auto run_rows = [&](auto rn_tag) __attribute__((always_inline)) {
             constexpr int RN = decltype(rn_tag)::value;
-            const unsigned long long run_sel = rgm;     // (every row of the run — and its tail — has the run's members, all of one page)
-            const int run_page = kWide ? kbase >> 6 : 0;
+            // (every row of the run — and its tail — has the run's members; wide runs: a member of any page may be a picked path)
+            const unsigned long long run_sel = kWide ? (wide_sel ? ~0ull : 0ull) : rgm;
+            const int run_page = 0;
             unsigned nrows = 0;                 // rows of this run: the cell counters move once per run, not once per row
             while (true) {
                 const int g_i = gcost;
@@ -1376,8 +1416,8 @@ __global__ __launch_bounds__(64, C > 16 ? 2 : (kColmax != 0 ? RG_SWEEP16_FWD_WAV
                 if (!kAhead) load_steps(rli, s);
                 int lmax;
                 RowOps16<C>::alpha(rr[0], s, g_i, g0, lane, XU, XL, lmax);
-                RG_ROWSTAT((++st_rn[RN], st_dirs += want_dirs(run_sel, run_page, ri) ? 1 : 0, st_tail += tail ? 1 : 0));
-                if (want_dirs(run_sel, run_page, ri)) store_dirs(rslot, XU, XL);
+                RG_ROWSTAT((++st_rn[RN], st_dirs += (kWide ? wide_sel : want_dirs(run_sel, run_page, ri)) ? 1 : 0, st_tail += tail ? 1 : 0));
+                if (kWide ? ((kColmax != 1 || dirs != nullptr) && (wide_sel || (rev ? ri > a.dsel_hi : ri < a.dsel_lo))) : want_dirs(run_sel, run_page, ri)) store_dirs(rslot, XU, XL);
                 if constexpr (RN > 1) {
                     int MU[H], ML[H];
                     const unsigned lmask = RowOps16<C>::masks(XU, XL, MU, ML);
@@ -1490,7 +1530,7 @@ __global__ __launch_bounds__(64, C > 16 ? 2 : (kColmax != 0 ? RG_SWEEP16_FWD_WAV
                     for (int kk = 0; kk < KRUN; ++kk) if (kk < RN) end_fold(mk[kk], ri, rr[kk]);
                     end_row_done(ri);
                 }
-                ++t;
+                t += kWide ? went : 1;                          // (wide runs: over the row's continuation entries)
                 if (tail || t >= nsteps) break;                 // (a tail ends its run)
                 if (rleft > 1) {
                     // the run goes on: a record whose run field counts more rows than itself is followed by the next inner row
@@ -1517,7 +1557,7 @@ __global__ __launch_bounds__(64, C > 16 ? 2 : (kColmax != 0 ? RG_SWEEP16_FWD_WAV
                 rleft = to_tail ? 0 : (nw0 >> 26) & 63;
                 if (kAhead) load_steps(rli, s);
             }
-            cells += (unsigned long long)nrows * (unsigned long long)__popcll(rgm);
+            cells += (unsigned long long)nrows * (unsigned long long)(kWide ? wide_total : __popcll(rgm));
             done += (unsigned long long)nrows * (unsigned long long)RN;
             };
             run_dispatch_from<1, (KRUN > 0 ? KRUN : 1)>(run_rows, rnm);
@@ -2194,7 +2234,8 @@ void launch_sweep16(const SweepArgs& a_, int nreads, int C, hipStream_t s) {
     SweepArgs a = a_;
     // split step tables (TAIL records): the record variants with lazy keys, register runs of 4 and gather runs compiled in
     constexpr bool split_built = RG_SWEEP16_KRUN == 4 && RG_SWEEP16_KRUN_REV == 4 && RG_SWEEP16_GATHER && RG_SWEEP16_GATHER_FWD;
-    if (split_built && a.use_split && a.fsplit && a.rsplit && a.frec && !(a.colmax_out && a.colarg_out) && a.g.P <= 64 && C <= 16) {
+    // (more than 64 paths: the wide-run table takes the split table's place)
+    if (split_built && a.use_split && a.fsplit && a.rsplit && a.frec && !(a.colmax_out && a.colarg_out) && C <= 16) {
         a.fsteps = a.fsplit;
         a.rsteps = a.rsplit;
         a.flead = a.fslead;

@@ -336,6 +336,31 @@ def test_step_tables_of_the_pathwise_sweeps():
                         for k, m in cur.items():
                             want[(t // ev, k)] = m
                 assert lead == want and len(lead) > 10
+                # the WIDE-RUN table (round 6; it takes the split table's place): the same records in the same order; the alpha
+                # entry of a row with one group led by its lowest path is flagged HEAD / inner whatever continuation entries
+                # follow, its run field counts the rows left in the segment over the continuation entries; the same lead table
+                m2, p2, wide, lead2 = _parse_steps(g.dump(cs))
+                fw = [_rec_fields(r) for r in wide]
+                assert m2 == members and p2 == points and lead2 == want
+                assert [(r["row"], r["slot"], r["mask"], r["page"], r["cont"]) for r in fw] == [(r["row"], r["slot"], r["mask"], r["page"], r["cont"]) for r in f]
+                nflag = nspan = 0
+                alphas = [t for t, r in enumerate(fw) if not r["cont"]]
+                for a_i, t in enumerate(alphas):
+                    r = fw[t]
+                    rowrecs = [x for x in fw if x["row"] == r["row"]]
+                    one_group = sum(1 for x in rowrecs if not x["cont"]) == 1
+                    if r["flags"] & 4:
+                        nflag += 1
+                        nspan += len(rowrecs) > 1
+                        assert one_group and r["flags"] in (4, 7) and r["field"] >= 1
+                        assert all(x["page"] > r["page"] for x in rowrecs if x["cont"])
+                        assert (r["mask"] & -r["mask"]).bit_length() - 1 == (f[t]["field"] if not (f[t]["flags"] & 4) else (r["mask"] & -r["mask"]).bit_length() - 1)
+                        nxt = fw[alphas[a_i + 1]] if a_i + 1 < len(alphas) else None
+                        cont_run = nxt is not None and nxt["flags"] == 7
+                        assert r["field"] == (min(nxt["field"] + 1, 63) if cont_run else 1), (t, r, nxt)
+                    else:
+                        assert r["flags"] == f[t]["flags"] and r["field"] == f[t]["field"]
+                assert nflag > 50 and nspan > 20, (nflag, nspan)
                 continue
             # ---- split table ----
             m2, p2, split, lead2 = _parse_steps(g.dump(cs))
