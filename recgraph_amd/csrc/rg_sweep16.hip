@@ -1106,8 +1106,63 @@ __global__ __launch_bounds__(64, C > 16 ? 2 : (kColmax != 0 ? RG_SWEEP16_FWD_WAV
             ++t;
             continue;
         }
-        if (RG_SWEEP16_GATHER && kGather && (kRec ? (kColmax == 0 || (kColmax == 2 && RG_SWEEP16_GATHER_FWD)) : !track) && !kWide && a.gather_ok && !semi_end && (flags & F_INNER) && nm > KRUN &&
-            (!kRet || nme > KRUN) && run_left * (RG_GATHER_PER_MEMBER_ROW * (nm - 1) - RG_GATHER_PER_ROW) >= RG_GATHER_PER_MEMBER_RUN * (nm - 1)) {
+        // WIDE RUNS (more than 64 paths; the wide-run table of rg_steps.cpp): the alpha entry of a row with one group led by its
+        // lowest member is flagged like the narrow tables' HEAD / inner rows, continuation entries or not.  Here the members
+        // that are still needed are gathered from this entry and the continuation entries behind it; when at most KRUN are left the
+        // segment's rows run with those in registers (the run loop steps over the continuation entries: `went` records per row),
+        // otherwise the entries take the general path one by one (this entry then must not close the row: its continuation
+        // entries do).
+        int went = 1, wide_n = 0, wide_total = nm, wide_needed = 0;
+        PathWords wide_gw{0ull, 0ull, 0ull, 0ull};      // the needed members of the whole group, page by page
+        int wide_ids[KRUN > 0 ? KRUN : 1];
+        bool wide_sel = false;
+        if (kWide && KRUN > 0 && (flags & F_INNER) && run_left > 0) {
+#pragma unroll
+            for (int kk = 0; kk < KRUN; ++kk) wide_ids[kk] = 0;
+            auto add = [&](unsigned long long m, int base) {
+                while (m) {
+                    const int id = base + __builtin_ctzll(m);
+                    m &= m - 1;
+#pragma unroll
+                    for (int kk = 0; kk < KRUN; ++kk) if (kk == wide_n) wide_ids[kk] = id;       // (no dynamically indexed array)
+                    ++wide_n;
+                }
+            };
+            add(gm, kbase);
+            wide_gw.set(page, gm);
+            wide_needed = nme;
+            wide_sel = (gmask & word_of(dsel_w, page)) != 0ull;
+            while (t + went < nsteps) {
+                const int nw1 = peek_w1(t + went);
+                if (nw1 >= 0) break;
+                const unsigned long long mm = peek_gm(t + went);
+                const int pg = (nw1 >> 29) & 3;
+                wide_total += __popcll(mm);
+                add(mm & word_of(needed, pg), pg * 64);
+                wide_gw.set(pg, mm & word_of(needed, pg));
+                wide_needed += __popcll(mm & word_of(needed, pg));
+                wide_sel = wide_sel || (mm & word_of(dsel_w, pg)) != 0ull;
+                ++went;
+            }
+        }
+        const bool wide_run = kWide && KRUN > 0 && (flags & F_INNER) && run_left > 0 && wide_n >= 1 && wide_n <= KRUN;
+        // (members of a run in ascending path order, the alpha left out: one word up to 64 paths, the needed members of every page of
+        // the group beyond)
+        struct MemberIter {
+            PathWords w;
+            int pg;
+            __device__ __forceinline__ int next() {
+                while (pg < NW) {
+                    const unsigned long long m = w.get(pg);
+                    if (m) { w.set(pg, m & (m - 1)); return pg * 64 + __builtin_ctzll(m); }
+                    ++pg;
+                }
+                return -1;
+            }
+        };
+        const int g_nm = kWide ? wide_total : nm, g_nme = kWide ? wide_needed : nme;      // members of the group | the needed ones
+        if (RG_SWEEP16_GATHER && kGather && (kRec ? (kColmax == 0 || (kColmax == 2 && RG_SWEEP16_GATHER_FWD)) : !track) && a.gather_ok && !semi_end && (flags & F_INNER) && g_nm > KRUN &&
+            (!kWide || run_left > 0) && (!kRet || g_nme > KRUN) && run_left * (RG_GATHER_PER_MEMBER_ROW * (g_nm - 1) - RG_GATHER_PER_ROW) >= RG_GATHER_PER_MEMBER_RUN * (g_nm - 1)) {
             // ---- GATHER RUN: R consecutive inner rows of a segment that a wide group (nm paths, one group, alpha = its lowest
             // path) runs through.  Every member follows the alpha's directions, and a direction only MOVES values (D: from
             // column c - 1 of the row above, U: from column c, L: from column c - 1 of the new row) and adds a constant that
@@ -1134,22 +1189,18 @@ __global__ __launch_bounds__(64, C > 16 ? 2 : (kColmax != 0 ? RG_SWEEP16_FWD_WAV
                 int bd[H], bk[H];
 #pragma unroll
                 for (int r = 0; r < H; ++r) { bd[r] = 0; bk[r] = pack16(ka, ka); }
-                unsigned long long rest = gm & ~(1ull << (ka - kbase));
+                MemberIter it{kWide ? wide_gw : PathWords{gm, 0ull, 0ull, 0ull}, 0};
+                it.w.set(ka >> 6, it.w.get(ka >> 6) & ~(1ull << (ka & 63)));        // (narrow: page 0, path ids below 64)
                 int nx[H];
-                int kn = -1;
-                if (rest) {
-                    kn = kbase + __builtin_ctzll(rest); rest &= rest - 1;
-                    ld_row(kn, nx);
-                }
+                int kn = it.next();
+                if (kn >= 0) ld_row(kn, nx);
                 while (kn >= 0) {
                     const int k = kn;
                     int cur[H];
 #pragma unroll
                     for (int r = 0; r < H; ++r) cur[r] = nx[r];
-                    if (rest) {
-                        kn = kbase + __builtin_ctzll(rest); rest &= rest - 1;
-                        ld_row(kn, nx);
-                    } else kn = -1;
+                    kn = it.next();
+                    if (kn >= 0) ld_row(kn, nx);
                     int kk = k;
                     asm volatile("" : "+v"(kk));
                     const int K2 = (int)(((unsigned)kk << 16) | (unsigned)kk);
@@ -1187,12 +1238,13 @@ __global__ __launch_bounds__(64, C > 16 ? 2 : (kColmax != 0 ? RG_SWEEP16_FWD_WAV
                 load_steps(rli, s);
                 int lmax_unused;
                 RowOps16<C>::alpha(A, s, g_i, g0, lane, XU, XL, lmax_unused);
-                RG_ROWSTAT((++st_grow, st_gmem += nme, st_dirs += want_dirs(gmask, 0, ri) ? 1 : 0));
-                if (want_dirs(gmask, 0, ri)) store_dirs(rslot, XU, XL);      // (page 0: gather runs are narrow-graph only)
+                const bool gdirs = kWide ? ((kColmax != 1 || dirs != nullptr) && (wide_sel || (rev ? ri > a.dsel_hi : ri < a.dsel_lo))) : want_dirs(gmask, 0, ri);
+                RG_ROWSTAT((++st_grow, st_gmem += g_nme, st_dirs += gdirs ? 1 : 0));
+                if (gdirs) store_dirs(rslot, XU, XL);
                 const unsigned lmask = RowOps16<C>::masks(XU, XL, MU, ML);
                 const int src = RowOps16<C>::src_lane(lmask, lane);
                 RowOps16<C>::template member<true>(G, MU, lane, MU, ML, lmask, src);   // the gather follows the directions, adds nothing (SEL unused)
-                cells += (unsigned long long)nm;
+                cells += (unsigned long long)g_nm;
                 done += 2ull;
 #ifndef RG_G_NOKEYS
                 if (kRec && track) {
@@ -1235,14 +1287,14 @@ __global__ __launch_bounds__(64, C > 16 ? 2 : (kColmax != 0 ? RG_SWEEP16_FWD_WAV
                     }
                 }
 #endif
-                ++t;
+                t += kWide ? went : 1;          // (wide: over the row's continuation entries)
                 if (step + 1 >= R || t >= nsteps) break;
                 int nw0, nw1;
                 unsigned long long ngm;
                 fetch(t, nw0, nw1, ngm);
                 ri = nw0 & 0xfffff; rli = (nw0 >> 20) & 7; rslot = nw1 & 0xfffff; rw1 = nw1;
             }
-            done += (unsigned long long)(nme - 1) * ((kRec && track) ? 2ull : 1ull);    // passes (1) and (3)
+            done += (unsigned long long)(g_nme - 1) * ((kRec && track) ? 2ull : 1ull);    // passes (1) and (3)
             // (3) every member once: row_k(end)[c] = A(end)[c] - A0[G(c)] + row_k(start)[G(c)]
 #ifndef RG_G_NOPH3
             {
@@ -1264,22 +1316,18 @@ __global__ __launch_bounds__(64, C > 16 ? 2 : (kColmax != 0 ? RG_SWEEP16_FWD_WAV
                     B[r] = pk_sub_sat(A[r], pack16(a0, a1));
                 }
                 st_row(ka, A);
-                unsigned long long rest = gm & ~(1ull << (ka - kbase));
+                MemberIter it{kWide ? wide_gw : PathWords{gm, 0ull, 0ull, 0ull}, 0};
+                it.w.set(ka >> 6, it.w.get(ka >> 6) & ~(1ull << (ka & 63)));        // (narrow: page 0, path ids below 64)
                 int nx[H];
-                int kn = -1;
-                if (rest) {
-                    kn = kbase + __builtin_ctzll(rest); rest &= rest - 1;
-                    ld_row(kn, nx);
-                }
+                int kn = it.next();
+                if (kn >= 0) ld_row(kn, nx);
                 while (kn >= 0) {
                     const int k = kn;
                     __syncthreads();
 #pragma unroll
                     for (int r = 0; r < H; ++r) gS[r * WAVE + lane] = nx[r];
-                    if (rest) {
-                        kn = kbase + __builtin_ctzll(rest); rest &= rest - 1;
-                        ld_row(kn, nx);
-                    } else kn = -1;
+                    kn = it.next();
+                    if (kn >= 0) ld_row(kn, nx);
                     __syncthreads();
                     int outr[H];
 #pragma unroll
@@ -1297,42 +1345,7 @@ __global__ __launch_bounds__(64, C > 16 ? 2 : (kColmax != 0 ? RG_SWEEP16_FWD_WAV
         }
         int e_i = i, e_w1 = w1, e_flags = flags;   // the row whose epilogue runs at the end of this iteration
         bool e_adv = true;
-        // WIDE RUNS (more than 64 paths; the wide-run table of rg_steps.cpp): the alpha entry of a row with one group led by its
-        // lowest member is flagged like the narrow tables' HEAD / inner rows, continuation entries or not.  Here the members
-        // that are still needed are gathered from this entry and the continuation entries behind it; when at most KRUN are left the
-        // segment's rows run with those in registers (the run loop steps over the continuation entries: `went` records per row),
-        // otherwise the entries take the general path one by one (this entry then must not close the row: its continuation
-        // entries do).
-        int went = 1, wide_n = 0, wide_total = nm;
-        int wide_ids[KRUN > 0 ? KRUN : 1];
-        bool wide_sel = false;
-        if (kWide && KRUN > 0 && (flags & F_INNER) && run_left > 0) {
-#pragma unroll
-            for (int kk = 0; kk < KRUN; ++kk) wide_ids[kk] = 0;
-            auto add = [&](unsigned long long m, int base) {
-                while (m) {
-                    const int id = base + __builtin_ctzll(m);
-                    m &= m - 1;
-#pragma unroll
-                    for (int kk = 0; kk < KRUN; ++kk) if (kk == wide_n) wide_ids[kk] = id;       // (no dynamically indexed array)
-                    ++wide_n;
-                }
-            };
-            add(gm, kbase);
-            wide_sel = (gmask & word_of(dsel_w, page)) != 0ull;
-            while (t + went < nsteps) {
-                const int nw1 = peek_w1(t + went);
-                if (nw1 >= 0) break;
-                const unsigned long long mm = peek_gm(t + went);
-                const int pg = (nw1 >> 29) & 3;
-                wide_total += __popcll(mm);
-                add(mm & word_of(needed, pg), pg * 64);
-                wide_sel = wide_sel || (mm & word_of(dsel_w, pg)) != 0ull;
-                ++went;
-            }
-            if (went > 1) e_flags &= ~F_LAST;
-        }
-        const bool wide_run = kWide && KRUN > 0 && (flags & F_INNER) && run_left > 0 && wide_n >= 1 && wide_n <= KRUN;
+        if (kWide && went > 1) e_flags &= ~F_LAST;      // (a flagged alpha entry on the general path: its continuation entries close the row)
         // (PATH RETIREMENT: a wide group of which <= KRUN members are left runs here too — a gather run costs two member
         // updates per row whatever is left of the group; like a gather run it leaves bkey alone, which is what the split
         // tables count on for the runs between the groups of a row)
