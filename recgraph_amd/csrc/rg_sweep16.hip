@@ -1116,7 +1116,7 @@ __global__ __launch_bounds__(64, C > 16 ? 2 : (kColmax != 0 ? RG_SWEEP16_FWD_WAV
         PathWords wide_gw{0ull, 0ull, 0ull, 0ull};      // the needed members of the whole group, page by page
         int wide_ids[KRUN > 0 ? KRUN : 1];
         bool wide_sel = false;
-        if (kWide && KRUN > 0 && (flags & F_INNER) && run_left > 0) {
+        if (kWide && (flags & F_INNER) && run_left > 0) {      // (also where KRUN is 0 — the -m 4 variant at 32 columns per lane —: its gather runs iterate wide_gw)
 #pragma unroll
             for (int kk = 0; kk < KRUN; ++kk) wide_ids[kk] = 0;
             auto add = [&](unsigned long long m, int base) {

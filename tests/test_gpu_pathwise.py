@@ -659,3 +659,9 @@ def test_wide_graphs_retire_paths_and_speculate(oracle):
                     api.set_option(name, defaults.get(name, 0))
             assert texts == base, (P, combo)
     assert retired >= 2, retired
+    # reads of more than 1 023 bases on a wide graph (32 columns per lane: no register runs there, gather runs whose member
+    # passes iterate the pages of the group — the -m 4 variant included: a fuzz campaign found it reading an empty member set)
+    g = synth.haplotype_graph(3300, 70, path_len=1150, seed=75)
+    rd = synth.haplotype_reads(g, 6, length=1150, seed=775, mosaic_frac=0.5) + [g.path_sequence(69)[:1150]]
+    _check(oracle, g.gfa(), rd, api.MODE_PATHWISE, oracle.M4_ABS)
+    _check(oracle, g.gfa(), rd, api.MODE_RECOMBINATION, oracle.M8_ABS)
