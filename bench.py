@@ -459,11 +459,25 @@ class StepGather:
                     if self.rank == 0:
                         self.parts.append(parts)             # kept as tensors: no per-part bytes objects
                         self.bytes += sum(sizes)
-                    fixed = FixedGather(self.rank, self.world, self.device, cap=4 * max(1024, max(sizes)))
+                    # (RG_BENCH_VARIABLE_GATHER=1 keeps the variable-length gather for every step; so does a FixedGather that
+                    # cannot be set up — every rank runs the same code on the same sizes, so they all fall back together)
+                    if os.environ.get("RG_BENCH_VARIABLE_GATHER", "0") not in ("", "0"):
+                        fixed = False
+                    else:
+                        try:
+                            fixed = FixedGather(self.rank, self.world, self.device, cap=4 * max(1024, max(sizes)))
+                        except Exception as ex:
+                            print("bench: FixedGather unavailable (%r): variable-length gather for every step" % (ex,), file=sys.stderr, flush=True)
+                            fixed = False
+                elif fixed is False:
+                    parts, sizes = gather_parts(data, self.rank, self.world, self.device)
+                    if self.rank == 0:
+                        self.parts.append(parts)
+                        self.bytes += sum(sizes)
                 else:
                     fixed.submit(data)
                 self.busy_s += time.perf_counter() - t0
-            if fixed is not None:
+            if fixed:
                 t0 = time.perf_counter()
                 res, sizes = fixed.finish()
                 if self.rank == 0:
