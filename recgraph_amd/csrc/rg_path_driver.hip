@@ -360,6 +360,11 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
     // only — a read that comes back because its final paths were not the picked ones stores every word the second time
     const bool pick_two_used = spec && !semi && !opt.no_pick2;
     const bool dsel = spec && use_rec && nwv == 1 && spec_level == 0 && !opt.no_dsel;
+    // -m 4 on a speculative bound (round 6): k_pick's path, k_opt0's score against it minus the margin as the bound the sweep retires
+    // paths against, direction words for the picked path only; k_verify4 sends a read whose best final score does not reach the bound
+    // (or whose best path is not the pick) to a second pass without any of it.  Packed rows, one wave per read, the default scores' sign
+    // conditions (gap entries <= 0: the hopeless bound counts on them).
+    const bool spec4 = mode == RG_MODE_PATHWISE && !semi && use16 && nwv == 1 && gaps_nonpos && spec_level == 0 && !opt.no_spec;
     const int recw = 4 + C;
     if (w.fcap == 0) { w.fcap = (two_sweep && !use_rec) ? 1u << 20 : 1u << 15; w.rcap = use_rec ? 1u << 16 : 1u << 19; w.frec_cap = spec ? 1u << 14 : 1u << 16; w.rrec_cap = spec ? 1u << 13 : 1u << 15; }   // (round 6: 16 Ki / 8 Ki records of 80 B to start with instead of 64 Ki / 32 Ki — 2 MB per read instead of 7.9; a read that needs more regrows the lists and the chunk runs again, once per handle; batches WITHOUT a speculative bound keep the old sizes: their forward lists hold tens of thousands of records per read, and 128-path tiles ran twice every time a tile's largest read outgrew the last one's.  Config 5 with the two-path pick: forward mean ~11 k)
     stats.clear();
@@ -398,6 +403,7 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
                                 (rc = w.nrrec.alloc(chunk))))
                     return rc;
             }
+            if (spec4 && ((rc = w.lb.alloc(chunk)) || (rc = w.pick.alloc(chunk)) || (rc = w.order.alloc(chunk)) || (rc = w.rt_flags.alloc(chunk)))) return rc;
             return RG_OK;
         };
         g_alloc_oom = false;
@@ -441,8 +447,24 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
         if (mode == RG_MODE_PATHWISE) {
             SweepArgs f = sa;
             f.rev = 0; f.track_best = 0; f.dirs = w.fdirs.p; f.dirs_stride = fdirs_stride; f.count_cells = 1;
+            f.retire = 0;
+            if (spec4) {
+                PickArgs pa{d_reads, off, bad, w.kmer_keys.p, w.kmer_masks.p, w.kmer_mask, P, w.pick.p, w.fpoff.p, w.fprow.p, nullptr};
+                TIMED(T, "k_pick", launch_pick(pa, chunk, stream));
+                // (the margin: a follower path's final score lies below its own alignment optimum — up to 180 at 1 kbp in config 4, where
+                // -m 8's search maximum rarely does: 2.5 x the -m 8 margin; RG_SPEC4_MARGIN_X10 scales it for experiments)
+                static const int m4x10 = getenv("RG_SPEC4_MARGIN_X10") ? atoi(getenv("RG_SPEC4_MARGIN_X10")) : 25;
+                Opt0Args oa{gd, sa.sc, d_reads, off, bad, w.fpoff.p, w.fprow.p, w.lb.p, 0, w.pick.p, spec_margin * m4x10 / 10, nwv, nullptr, 0};
+                TIMED(T, "k_opt0", launch_opt0_16(oa, chunk, C, stream));
+                if (opt.no_retire != 1) {
+                    f.retire = 1; f.lb = w.lb.p; f.maxmatch = maxmatch;
+                    if (!opt.no_order) { launch_order(w.pick.p, nullptr, w.order.p, chunk, stream); f.order = w.order.p; }
+                }
+                if (!opt.no_dsel) { f.dsel_pick = w.pick.p; f.dsel_pick2 = nullptr; f.dsel_lo = 0; f.dsel_hi = L; }     // (no recombination: no edge rows)
+            }
             TIMED(T, use16 ? "k_sweep16_fwd" : "k_sweep_fwd", sweep(f, chunk));
             TIMED(T, "k_seed", launch_seed(se, stream));
+            if (spec4) launch_verify4(w.state.p, w.lb.p, w.need.p + 4, w.rt_flags.p, chunk, f.dsel_pick, stream);
         } else {
             if (two_sweep) {
                 Opt0Args oa{gd, sa.sc, d_reads, off, bad, w.fpoff.p, w.fprow.p, w.lb.p, semi ? 1 : 0, nullptr, 0, nwv, nullptr, 0};
@@ -624,8 +646,21 @@ int path_driver_run(const HostGraph& h, const PathGraphDev& gd, const rg_params&
         }
         const unsigned long long chunk_cells = w.h_sum[0];
         cells_perf += w.h_sum[5];
-        const unsigned nretry = spec ? reinterpret_cast<const unsigned*>(w.h_sum + 1)[4] : 0u;
-        if (debug && spec) fprintf(stderr, "[rg] speculative bound (margin %d): %u of %d reads did not reach it\n", spec_margin, nretry, chunk);
+        const unsigned nretry = (spec || spec4) ? reinterpret_cast<const unsigned*>(w.h_sum + 1)[4] : 0u;
+        if (debug && (spec || spec4)) fprintf(stderr, "[rg] speculative bound (margin %d): %u of %d reads did not reach it\n", spec_margin, nretry, chunk);
+        if (debug && spec4 && nretry) {
+            std::vector<ReadState> hs((size_t)chunk);
+            std::vector<int> hp((size_t)chunk), hlb((size_t)chunk);
+            HIPCHK(hipMemcpy(hs.data(), w.state.p, sizeof(ReadState) * (size_t)chunk, hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpy(hp.data(), w.pick.p, sizeof(int) * (size_t)chunk, hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpy(hlb.data(), w.lb.p, sizeof(int) * (size_t)chunk, hipMemcpyDeviceToHost));
+            int shown = 0;
+            for (int i = 0; i < chunk && shown < 16; ++i)
+                if (hs[(size_t)i].status & ST_RETRY) {
+                    ++shown;
+                    fprintf(stderr, "[rg]   -m 4 read %d: pick %d, best path %d, best score %d, bound %d\n", i, hp[(size_t)i], hs[(size_t)i].fwd_path, hs[(size_t)i].s0, hlb[(size_t)i]);
+                }
+        }
         if (debug && dsel) {
             // which of the second-pass reads are there because of their paths, and what the paths were
             std::vector<ReadState> hs((size_t)chunk);

@@ -259,6 +259,7 @@ void launch_pick(const PickArgs& a, int nreads, hipStream_t s);
 // paths (every lower path leads it somewhere), from a few percent of a full sweep to all of it — longest first,
 // so that the launch does not end on a few full-length waves (one block: counting sort by that id, descending).
 void launch_order(const int* pick, const int* pick2, int* order, int nreads, hipStream_t s);
+void launch_verify4(ReadState* st, const int* lb, unsigned* nretry, uint8_t* flags, int nreads, const int* dsel_pick, hipStream_t s);
 void launch_verify(ReadState* st, const int* lb, unsigned* nretry, uint8_t* flags, int nreads, const int* dsel_pick, const int* dsel_pick2, int dsel_lo, int dsel_hi, hipStream_t s);
 void launch_gather_reads(const uint8_t* reads, const long long* off, const int* idx, const long long* sub_off, uint8_t* out, int n, hipStream_t s);
 void launch_scatter_results(const int* idx, const DevRecord* sub_rec, const uint8_t* sub_ops, DevRecord* rec, uint8_t* ops, long long ops_stride, int n, hipStream_t s);

@@ -931,6 +931,25 @@ __global__ __launch_bounds__(256) void k_verify(ReadState* st, const int* lb, un
     flags[rd] = f;
 }
 
+// -m 4 on a speculative bound (round 6): the sweep retired the paths whose final score could not reach lb[rd] and stored direction
+// words for the picked path only; that was exact iff the best final score reaches the bound (every retired path then lies strictly
+// below the best) and the best path is the picked one.  A read that fails is aligned again without the speculation.
+__global__ __launch_bounds__(256) void k_verify4(ReadState* st, const int* lb, unsigned* nretry, uint8_t* flags, int nreads, const int* dsel_pick) {
+    const int rd = blockIdx.x * blockDim.x + threadIdx.x;
+    if (rd >= nreads) return;
+    ReadState* rs = st + rd;
+    uint8_t f = 0;
+    if (!(rs->status & (ST_BAD_BASE | ST_WOULD_PANIC | ST_OVERFLOW))) {
+        const bool bad = rs->s0 < lb[rd] || (dsel_pick && rs->fwd_path != dsel_pick[rd]);
+        if (bad) {
+            rs->status |= ST_RETRY;
+            f = 1;
+            atomicAdd(nretry, 1u);
+        }
+    }
+    flags[rd] = f;
+}
+
 // bases of the reads to align again, compacted (sub_off: their offsets in `out`)
 __global__ __launch_bounds__(256) void k_gather_reads(const uint8_t* reads, const long long* off, const int* idx, const long long* sub_off,
                                                       uint8_t* out) {
@@ -1539,6 +1558,9 @@ void launch_order(const int* pick, const int* pick2, int* order, int nreads, hip
 }
 void launch_verify(ReadState* st, const int* lb, unsigned* nretry, uint8_t* flags, int nreads, const int* dsel_pick, const int* dsel_pick2, int dsel_lo, int dsel_hi, hipStream_t s) {
     hipLaunchKernelGGL(k_verify, dim3((nreads + 255) / 256), dim3(256), 0, s, st, lb, nretry, flags, nreads, dsel_pick, dsel_pick2, dsel_lo, dsel_hi);
+}
+void launch_verify4(ReadState* st, const int* lb, unsigned* nretry, uint8_t* flags, int nreads, const int* dsel_pick, hipStream_t s) {
+    hipLaunchKernelGGL(k_verify4, dim3((nreads + 255) / 256), dim3(256), 0, s, st, lb, nretry, flags, nreads, dsel_pick);
 }
 void launch_gather_reads(const uint8_t* reads, const long long* off, const int* idx, const long long* sub_off, uint8_t* out, int n, hipStream_t s) {
     hipLaunchKernelGGL(k_gather_reads, dim3(n), dim3(256), 0, s, reads, off, idx, sub_off, out);

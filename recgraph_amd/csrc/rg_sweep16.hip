@@ -278,6 +278,9 @@ __device__ __forceinline__ void run_dispatch_from(F& f, int n) {
 // 33.6): their runs end in tails, whose epilogue separates the loads from the stores anyway (profiles/r04_notes.md)
 #define RG_SWEEP16_CHAIN 1
 #endif
+#ifndef RG_SWEEP16_M4_WAVES
+#define RG_SWEEP16_M4_WAVES 3
+#endif
 #ifndef RG_SWEEP16_KRUN32_M4
 #define RG_SWEEP16_KRUN32_M4 1       // register runs of two rows in the -m 4 / -m 5 variant at 32 columns per lane (reads of 1 024 - 2 047 bases)
 #endif
@@ -333,13 +336,17 @@ struct PathWords {
 #define RG_SWEEP16_CAP_ATTR
 #endif
 template <int C, int kColmax, bool kRec, bool kWide, bool kSemi>
-__global__ __launch_bounds__(64, C > 16 ? 2 : (kColmax != 0 ? RG_SWEEP16_FWD_WAVES : RG_SWEEP16_REV_WAVES)) RG_SWEEP16_CAP_ATTR void k_sweep16(SweepArgs a) {
+// (the -m 4 / -m 5 variants at <= 16 columns per lane are COMPILED for three waves per SIMD: with the path retirement of round 6
+// compiled in they would otherwise take 196 registers — from 148 — and config 4 lives on the third wave)
+__global__ __launch_bounds__(64, C > 16 ? 2 : ((kColmax == 0 && !kRec) ? RG_SWEEP16_M4_WAVES : (kColmax != 0 ? RG_SWEEP16_FWD_WAVES : RG_SWEEP16_REV_WAVES))) RG_SWEEP16_CAP_ATTR void k_sweep16(SweepArgs a) {
     constexpr int H = C / 2;
     constexpr bool kTrack = kColmax != 0 || kRec;      // <0, false>: the -m 4 / -m 5 sweep — no best member, no thresholds, no emission
     // gather runs: not at 32 columns per lane in the record variants (a row is 16 registers there: the run's A / G / masks / steps /
     // values / paths alone are 112, and with retirement and register runs compiled in the variant spilled 78)
     constexpr bool kGather = C <= 16 || !kRec || RG_SWEEP16_GATHER32;
-    constexpr bool kRet = kRec && kColmax != 1 && !kSemi;   // PATH RETIREMENT (record pipelines of -m 8; since round 6 also more than 64 paths): see retire_eval
+    // PATH RETIREMENT: the record pipelines of -m 8 (since round 6 also beyond 64 paths) and — round 6 — the -m 4 sweep: there a path is
+    // hopeless when its final score cannot reach the bound k_verify4 checks the best final score against (see retire_eval)
+    constexpr bool kRet = ((kRec && kColmax != 1) || !kTrack) && !kSemi;
     constexpr int NW = kWide ? RG_PW : 1;                   // 64-bit words of a path set
     // rows kept in registers across the inner rows of a segment: groups of up to 4 paths (2 at 32 columns per lane: a row is 16 registers there)
     // (the -m 4 / -m 5 variant: 3 — with 4 the specialised run loops of round 6 need 178 registers and the variant falls from three
@@ -574,6 +581,8 @@ __global__ __launch_bounds__(64, C > 16 ? 2 : (kColmax != 0 ? RG_SWEEP16_FWD_WAV
         if (kRet && a.retire && !kSemi) {
             const int mmx = max(a.maxmatch, 0);
             int tv[C];
+#pragma unroll
+            for (int q = 0; q < C; ++q) tv[q] = -32768;
             bool ovf = false;
             if (!rev) {
                 const int lbv = a.lb ? a.lb[rd] : INT32_MIN / 2;
@@ -584,7 +593,7 @@ __global__ __launch_bounds__(64, C > 16 ? 2 : (kColmax != 0 ? RG_SWEEP16_FWD_WAV
                     ovf = ovf || (c < ncols && v > 32767);
                     tv[q] = c < ncols ? (int)max(-32768ll, min(32767ll, v)) : -32768;
                 }
-            } else {
+            } else if constexpr (kTrack) {       // (the -m 4 variant never sweeps in reverse: the branch — thirty-odd registers of it — is not compiled there)
                 // Tmin over mirrored columns c' >= c  (real columns j' <= j)
                 int tq[C], ltot = INT32_MAX;
 #pragma unroll
@@ -979,7 +988,7 @@ __global__ __launch_bounds__(64, C > 16 ? 2 : (kColmax != 0 ? RG_SWEEP16_FWD_WAV
     auto retire_eval = [&](int e) {
         PathWords hop{0ull, 0ull, 0ull, 0ull};
         // (four rows in flight per wait: one row per wait made the evaluations ~8 % of the sweep)
-        constexpr int EB = C <= 16 ? 4 : 2;
+        constexpr int EB = !kTrack ? 1 : (C <= 16 ? 4 : 2);      // (the -m 4 variant: one row at a time — it has to stay under 168 registers, three waves per SIMD)
         int rvc[H];
         ld_row(PR_RVL, rvc);
 #pragma unroll
@@ -1581,7 +1590,8 @@ __global__ __launch_bounds__(64, C > 16 ? 2 : (kColmax != 0 ? RG_SWEEP16_FWD_WAV
             }
             bool chain = false;
             unsigned long long gm2 = 0;
-            if ((RG_SWEEP16_CHAIN == 2 || (RG_SWEEP16_CHAIN == 1 && !kTrack)) && !kWide && !semi_end && t < nsteps) {
+            // (not while paths are being retired: the chained run's members would have to be masked and may all be gone)
+            if ((RG_SWEEP16_CHAIN == 2 || (RG_SWEEP16_CHAIN == 1 && !kTrack)) && !kWide && !semi_end && t < nsteps && (!kRet || next_eval == INT32_MAX)) {
                 const int pw = peek_w0(t);
                 // a HEAD (4 alone) or an inner row (7) with rows left starts a register / gather run; <= KRUN paths: a register run
                 if ((((pw >> 23) & 7) & F_INNER) && ((pw >> 26) & 63) != 0) {

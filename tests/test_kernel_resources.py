@@ -15,7 +15,12 @@ def test_headline_sweep_variants_use_no_scratch():
                 "rg::k_sweep16<16, 0, false, false, false>"]    # -m 4: no tracking at all
     for name in headline:
         k = ks[name]
-        assert k["ScratchSize [bytes/lane]"] == 0 and k["VGPRs Spill"] == 0, (name, k)
+        if ", false, false, false>" in name and "0, false" in name:
+            # the -m 4 variant is COMPILED for three waves per SIMD since the path retirement of round 6 went in (196 registers
+            # otherwise): 25 spilled registers, and still the faster form (lone sweep 11.5 ms against 13.3 at two waves)
+            assert k["ScratchSize [bytes/lane]"] <= 128 and k["VGPRs Spill"] <= 32, (name, k)
+        else:
+            assert k["ScratchSize [bytes/lane]"] == 0 and k["VGPRs Spill"] == 0, (name, k)
         assert k["VGPRs"] <= 256 and k["Occupancy [waves/SIMD]"] >= 2, (name, k)
     # the -m 4 sweep fits three waves per SIMD (168 registers, 13 KB of LDS per wave)
     assert ks["rg::k_sweep16<16, 0, false, false, false>"]["Occupancy [waves/SIMD]"] >= 3
