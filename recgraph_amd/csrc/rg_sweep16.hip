@@ -279,7 +279,10 @@ __device__ __forceinline__ void run_dispatch_from(F& f, int n) {
 #define RG_SWEEP16_CHAIN 1
 #endif
 #ifndef RG_SWEEP16_M4_WAVES
-#define RG_SWEEP16_M4_WAVES 3
+#define RG_SWEEP16_M4_WAVES 2
+#endif
+#ifndef RG_SWEEP16_KRUN_M4
+#define RG_SWEEP16_KRUN_M4 3
 #endif
 #ifndef RG_SWEEP16_KRUN32_M4
 #define RG_SWEEP16_KRUN32_M4 1       // register runs of two rows in the -m 4 / -m 5 variant at 32 columns per lane (reads of 1 024 - 2 047 bases)
@@ -351,7 +354,7 @@ __global__ __launch_bounds__(64, C > 16 ? 2 : ((kColmax == 0 && !kRec) ? RG_SWEE
     // rows kept in registers across the inner rows of a segment: groups of up to 4 paths (2 at 32 columns per lane: a row is 16 registers there)
     // (the -m 4 / -m 5 variant: 3 — with 4 the specialised run loops of round 6 need 178 registers and the variant falls from three
     // waves per SIMD to two: config 4 271 k against 296 k reads/s)
-    constexpr int KRUN = C <= 16 ? (!kTrack ? (RG_SWEEP16_KRUN < 3 ? RG_SWEEP16_KRUN : 3) : (kColmax != 0 ? RG_SWEEP16_KRUN : RG_SWEEP16_KRUN_REV)) : (((kRec && kColmax == 0 && !kWide) || (!kTrack && !kWide && RG_SWEEP16_KRUN32_M4)) ? 2 : 0);
+    constexpr int KRUN = C <= 16 ? (!kTrack ? (RG_SWEEP16_KRUN < RG_SWEEP16_KRUN_M4 ? RG_SWEEP16_KRUN : RG_SWEEP16_KRUN_M4) : (kColmax != 0 ? RG_SWEEP16_KRUN : RG_SWEEP16_KRUN_REV)) : (((kRec && kColmax == 0 && !kWide) || (!kTrack && !kWide && RG_SWEEP16_KRUN32_M4)) ? 2 : 0);
     const int rd = a.order ? a.order[blockIdx.x] : blockIdx.x;      // (launch order: see launch_order)
 #ifdef RG_SWEEP16_STALLSTAT
     // (statistics build, tools/probes/stall_stat.py: shader-clock cycles a wave spends in the waits for row loads; the cell

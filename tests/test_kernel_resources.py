@@ -15,15 +15,11 @@ def test_headline_sweep_variants_use_no_scratch():
                 "rg::k_sweep16<16, 0, false, false, false>"]    # -m 4: no tracking at all
     for name in headline:
         k = ks[name]
-        if ", false, false, false>" in name and "0, false" in name:
-            # the -m 4 variant is COMPILED for three waves per SIMD since the path retirement of round 6 went in (196 registers
-            # otherwise): 25 spilled registers, and still the faster form (lone sweep 11.5 ms against 13.3 at two waves)
-            assert k["ScratchSize [bytes/lane]"] <= 128 and k["VGPRs Spill"] <= 32, (name, k)
-        else:
-            assert k["ScratchSize [bytes/lane]"] == 0 and k["VGPRs Spill"] == 0, (name, k)
+        assert k["ScratchSize [bytes/lane]"] == 0 and k["VGPRs Spill"] == 0, (name, k)
         assert k["VGPRs"] <= 256 and k["Occupancy [waves/SIMD]"] >= 2, (name, k)
-    # the -m 4 sweep fits three waves per SIMD (168 registers, 13 KB of LDS per wave)
-    assert ks["rg::k_sweep16<16, 0, false, false, false>"]["Occupancy [waves/SIMD]"] >= 3
+    # the -m 4 sweep: two waves per SIMD since the path retirement of round 6 went in (196 registers; compiled for three it spills
+    # 25 and the stream loses: 279-319 k against 324-370 k reads/s at config 4) — and it must leave the small kernels their room
+    assert ks["rg::k_sweep16<16, 0, false, false, false>"]["VGPRs"] <= 200
     # reads of 1024-2047 bases (32 columns per lane): a row is 16 registers and the record variant is at the 256-register limit —
     # a few spilled registers are tolerated, a relapse (one uniform branch in the alpha took it from 13 to 67) is not
     # (round 6: gather runs are compiled into this variant — 32 spilled registers, 132 bytes of scratch per lane — because they
