@@ -2015,25 +2015,35 @@ __global__ __launch_bounds__(64, C <= 16 ? RG_LAYER16_WAVES : 1) void k_layer16(
     constexpr int PF = RG_LAYER16_PF;
     int pf_li[PF], pf_row[PF];
     uint32_t pf_w0[PF], pf_w1[PF];
-    auto prefetch = [&](int tt, int& li_o, int& row_o, uint32_t& w0_o, uint32_t& w1_o) {
-        li_o = 4; row_o = -1; w0_o = 0; w1_o = 0;
-        if (tt < nrows) {
-            const int ii = prow[poff[path] + tt];
-            const int sl = pslot[poff[path] + tt];
-            row_o = ii;
-            li_o = g.lnz[ii];
-            w0_o = dirs[(long long)sl * a.dir_words + lane];
-            if (C > 16) w1_o = dirs[(long long)sl * a.dir_words + WAVE + lane];
+    // TWO-STAGE look-ahead (round 6).  A row needs its base code and its direction word, and their addresses come from the path's
+    // row / slot lists: two DEPENDENT loads.  Until round 6 both were issued in one step — `poff[path]` (loop-invariant) was even
+    // reloaded in front of them — and the row loop opened with two full memory round trips every iteration (the ISA: three loads
+    // behind three `s_waitcnt vmcnt(0)`; 2.7 us per row, all of it latency).  Now the list entries of row t + PF + 1 are loaded
+    // while row t is computed, and the loads they address are issued one iteration later, when they have landed.
+    const int pbase = poff[path];
+    int nx_row = -1, nx_slot = 0;               // list entries of the NEXT row to be fetched (index nx_t)
+    auto fetch_idx = [&](int tt) {
+        nx_row = -1; nx_slot = 0;
+        if (tt < nrows) { nx_row = prow[pbase + tt]; nx_slot = pslot[pbase + tt]; }
+    };
+    auto prefetch = [&](int& li_o, int& row_o, uint32_t& w0_o, uint32_t& w1_o) {       // the row whose list entries are in nx_row / nx_slot
+        li_o = 4; row_o = nx_row; w0_o = 0; w1_o = 0;
+        if (nx_row >= 0) {
+            li_o = g.lnz[nx_row];
+            w0_o = dirs[(long long)nx_slot * a.dir_words + lane];
+            if (C > 16) w1_o = dirs[(long long)nx_slot * a.dir_words + WAVE + lane];
         }
     };
 #pragma unroll
-    for (int k = 0; k < PF; ++k) prefetch(k, pf_li[k], pf_row[k], pf_w0[k], pf_w1[k]);
+    for (int k = 0; k < PF; ++k) { fetch_idx(k); prefetch(pf_li[k], pf_row[k], pf_w0[k], pf_w1[k]); }
+    fetch_idx(PF);
     for (int t = 0; t < nrows; ++t) {
         const int li = pf_li[0], irow = pf_row[0];
         const uint32_t word0 = pf_w0[0], word1 = pf_w1[0];
 #pragma unroll
         for (int k = 0; k + 1 < PF; ++k) { pf_li[k] = pf_li[k + 1]; pf_row[k] = pf_row[k + 1]; pf_w0[k] = pf_w0[k + 1]; pf_w1[k] = pf_w1[k + 1]; }
-        prefetch(t + PF, pf_li[PF - 1], pf_row[PF - 1], pf_w0[PF - 1], pf_w1[PF - 1]);
+        prefetch(pf_li[PF - 1], pf_row[PF - 1], pf_w0[PF - 1], pf_w1[PF - 1]);       // row t + PF: its list entries were loaded an iteration ago
+        fetch_idx(t + PF + 1);
         const int g_i = gcost;
         const int g0 = a.semi ? 0 : g_i;
         const int GI = pack16(g_i, g_i);
@@ -2175,9 +2185,13 @@ __global__ __launch_bounds__(64) void k_opt0_16(Opt0Args a) {
     const int ln = n / C, ql = n % C;
     int semibest = NEG32;
     bool second = false;
-    int li_next = cnt > 0 ? g.lnz[a.fprow[beg]] : 4;
+    // TWO-STAGE look-ahead (round 6): the row index of row t + 2 and the base code of row t + 1 are in flight while row t is
+    // computed.  The loop used to load `fprow[beg + t]` at the top of every iteration — for the two-path switch test — and waited
+    // for it: one memory round trip per row, ~0.7 of the kernel's 0.86 ms per 4096 reads.
+    int i_cur = cnt > 0 ? a.fprow[beg] : 0, i_nx = cnt > 1 ? a.fprow[beg + 1] : 0;
+    int li_cur = cnt > 0 ? g.lnz[i_cur] : 4;
     for (int t = 0; t < cnt; ++t) {
-        const int i = a.fprow[beg + t];
+        const int i = i_cur;
         if (i > X && !second) {
             // switch lists: first row of p2 above X (its list is ascending)
             second = true;
@@ -2185,11 +2199,17 @@ __global__ __launch_bounds__(64) void k_opt0_16(Opt0Args a) {
             int lo = 0, hi = cnt;
             while (lo < hi) { const int mid = (lo + hi) >> 1; if (a.fprow[beg + mid] <= X) lo = mid + 1; else hi = mid; }
             t = lo - 1;
-            li_next = lo < cnt ? g.lnz[a.fprow[beg + lo]] : 4;
+            i_cur = lo < cnt ? a.fprow[beg + lo] : 0;
+            i_nx = lo + 1 < cnt ? a.fprow[beg + lo + 1] : 0;
+            li_cur = lo < cnt ? g.lnz[i_cur] : 4;
             continue;
         }
-        const int li = li_next;
-        if (t + 1 < cnt) li_next = g.lnz[a.fprow[beg + t + 1]];      // (one row ahead: off the dependency chain)
+        const int li = li_cur;
+        // (issued now, consumed by the next iterations: the base code of row t + 1 — its index was loaded an iteration ago —
+        // and the index of row t + 2)
+        const int li_nx = t + 1 < cnt ? g.lnz[i_nx] : 4;
+        const int i_nx2 = t + 2 < cnt ? a.fprow[beg + t + 2] : 0;
+        i_cur = i_nx; i_nx = i_nx2; li_cur = li_nx;
         int s[H];
         {
             const int* sp = sprof + (li * WAVE + lane) * H;
